@@ -1,0 +1,181 @@
+/*
+ * zrk_hot.h -- C ABI of libzrk_hot.so: the per-tick hot path of the ZRK simulator
+ * (advance every air object, sweep every sector radar over them, compact the
+ * detections, step every in-flight missile) as HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (Ollegorii/ZRK_modulation) is pure Python and has no FFI; the entry
+ * points below are what a binding for this path replaces, cited as reference
+ * file:line (paths relative to the reference root).  INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - Every pointer marked DEVICE is HIP device memory owned by the caller; the
+ *     library never allocates or frees across this boundary.  `workspace` is a
+ *     caller-owned DEVICE scratch buffer of at least zrk_workspace_bytes() bytes.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work
+ *     is enqueued there and nothing synchronises unless stated.
+ *   - One host thread per context.  Return value 0 = ok, negative = ZRK_E_*;
+ *     zrk_last_error(ctx) gives the message of the last failure.
+ *   - Vec3 arrays are structure-of-arrays plane sets: double[3*capacity], component
+ *     c of slot i at p[c*capacity + i].  All arithmetic is IEEE binary64 with the
+ *     rounding sequence of the reference ("Numerics").
+ */
+#ifndef ZRK_HOT_H
+#define ZRK_HOT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZRK_ABI_VERSION 1
+#define ZRK_MAX_RADARS 32           /* one bit per radar in the visibility mask */
+#define ZRK_BLOCK 256               /* entities per sweep/compaction block */
+
+#define ZRK_E_INVALID (-1)          /* bad argument (null pointer, size out of range) */
+#define ZRK_E_HIP (-2)              /* a HIP call failed; see zrk_last_error */
+#define ZRK_E_CAPACITY (-3)         /* an output buffer is too small */
+
+/* flags of zrk_tick_sweep */
+#define ZRK_F_ADVANCE 1u            /* recompute pos from the trajectory before sweeping */
+#define ZRK_F_PHILOX 2u             /* counter-based measurement noise inside the sweep */
+#define ZRK_F_EXACT_ONLY 4u         /* diagnostics: skip the float32 pre-classification */
+
+typedef struct zrk_ctx zrk_ctx;
+
+/* Entity table: AirEnv's object list (modules/AirEnv.py:24) as SoA columns.
+ * Slots are never reused; slot order is list order (targets, then missiles as appended). */
+typedef struct {
+    int64_t capacity;               /* plane stride of every vec3 column */
+    const double *start_pos;        /* DEVICE [3][cap]  Trajectory.start_pos   modules/AirObject.py:20 */
+    const double *velocity;         /* DEVICE [3][cap]  Trajectory.velocity    modules/AirObject.py:19 */
+    const double *start_time;       /* DEVICE [cap]     Trajectory.start_time  modules/AirObject.py:21 */
+    uint8_t *alive;                 /* DEVICE [cap]     0 = tombstone          modules/AirEnv.py:39-40 */
+    const uint8_t *kind;            /* DEVICE [cap]     0 target, 1 missile */
+    double *pos[2];                 /* DEVICE [3][cap] x2  obj.pos, double-buffered: pos[cur] is this tick's,
+                                       pos[cur^1] holds what prev_pos aliases (modules/AirObject.py:41) */
+    uint32_t *vis_mask;             /* DEVICE [cap]     bit r = seen by radar r this tick */
+} zrk_entities;
+
+/* The fields SectorRadar.find_visible_objects reads (modules/Radar.py:44-73). */
+typedef struct {
+    double pos[3];
+    double max_distance;
+    double cur_azimuth, azimuth_range;
+    double cur_elevation, elevation_range;
+} zrk_radar;
+
+/* In-flight missiles, rows in the order they entered AirEnv (= slot order). */
+typedef struct {
+    int64_t capacity;
+    const int32_t *slot;            /* DEVICE [cap] entity slot of the missile */
+    const int32_t *target;          /* DEVICE [cap] entity slot of Missile.target */
+    const double *radius;           /* DEVICE [cap] detonate_radius */
+    double *period;                 /* DEVICE [cap] detonate_period, decremented in place */
+    uint8_t *status;                /* DEVICE [cap] 1 active, 2 detonated */
+    uint8_t *ev_code;               /* DEVICE [cap] scratch: 0 none, 1 hit, 2 timeout */
+    int32_t *ev_missile;            /* DEVICE [cap] out: missile slots that detonated, list order */
+    int32_t *ev_target;             /* DEVICE [cap] out: target slot, or -1 for self-detonation */
+    int32_t *ev_count;              /* DEVICE [1]   out: number of events */
+} zrk_missiles;
+
+/* One pending Missile._launch (modules/Missile.py:104-133). */
+typedef struct {
+    int32_t target_slot;
+    int32_t _pad;
+    double missile_pos[3];
+    double speed;                   /* velocity_module */
+    double period;                  /* detonate_period */
+} zrk_launch_req;
+
+typedef struct {
+    int32_t rc;                     /* 0 launched; 1..5 = which ValueError of modules/Missile.py:70-94 */
+    int32_t _pad;
+    double velocity[3];             /* V, modules/Missile.py:97-100 */
+    double t_hit;
+} zrk_launch_res;
+
+int zrk_abi_version(void);
+int zrk_ctx_create(int device, zrk_ctx **out);
+void zrk_ctx_destroy(zrk_ctx *ctx);
+const char *zrk_last_error(zrk_ctx *ctx);
+
+/* Bytes of DEVICE scratch the sweep + compaction need for up to n_max entities. */
+int64_t zrk_workspace_bytes(int64_t n_max);
+
+/*
+ * AirEnv.step()'s entity loop for non-missile work plus every SectorRadar's
+ * find_visible_objects in one pass over the table.
+ *   replaces: `for object in self.__objects: object.step()`   modules/AirEnv.py:45-48
+ *             -> AirObject.step / Trajectory.get_pos          modules/AirObject.py:39-42, :23-25
+ *             SectorRadar.find_visible_objects                modules/Radar.py:44-73
+ *             SectorRadar.smooth_objects (ZRK_F_PHILOX only)  modules/Radar.py:138-142
+ * For each live slot i < n: (ZRK_F_ADVANCE) pos[cur][i] = start_pos + velocity*(t - start_time)
+ * with t = time_ms/1000; then radars 0..R-1 in order test the current position and, with
+ * ZRK_F_PHILOX, perturb it by N(0, 5^2) per axis keyed (seed, tick, radar_base + r, gid0 + i)
+ * before the next radar looks.  vis_mask[i] gets bit r per detecting radar (0 for dead slots).
+ * Also leaves per-block detection counts in `workspace` for zrk_compact.
+ */
+int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *ents, int64_t n, int cur, int64_t time_ms,
+                   const zrk_radar *radars /* HOST */, int R, int radar_base, uint32_t flags,
+                   uint64_t seed, uint64_t tick, int64_t gid0, void *workspace, void *stream);
+
+/*
+ * Ordered detection lists: for each radar r the slots with bit r set, ascending, i.e. the
+ * order of FoundObjectsMessage.visible_objects (modules/Radar.py:48-73, :168-174).
+ * det_idx[det_off[r] .. det_off[r+1]) holds base_index + slot; det_off has R+1 entries.
+ * Must follow zrk_tick_sweep on the same stream with the same n, R and workspace.
+ * det_capacity bounds det_idx; on overflow det_off is still exact and entries past the
+ * capacity are dropped (det_off[R] > det_capacity tells the caller).
+ */
+int zrk_compact(zrk_ctx *ctx, const uint32_t *vis_mask /* DEVICE */, int64_t n, int R,
+                int32_t base_index, void *workspace, int32_t *det_idx /* DEVICE */,
+                int64_t det_capacity, int32_t *det_off /* DEVICE [R+1] */, void *stream);
+
+/* SectorRadar.smooth_objects with caller-supplied draws (modules/Radar.py:138-142):
+ * pos[idx[j]] += noise[j] for j < k, noise row-major k x 3. */
+int zrk_noise_apply(zrk_ctx *ctx, double *pos /* DEVICE [3][cap] */, int64_t capacity,
+                    const int32_t *idx /* DEVICE */, int32_t idx_base, const double *noise /* DEVICE */,
+                    int64_t k, void *stream);
+
+/*
+ * Missile.step(), 'active' branch, for every in-flight missile (modules/Missile.py:162-193):
+ * own position from its trajectory, distance to the target's position of this tick, proximity
+ * fuse, else life-timer decrement and timeout.  Emits MissileDetonateMessage contents
+ * (modules/Missile.py:138-146) as (missile slot, target slot | -1) rows in list order.
+ * `cur` is the buffer this tick's zrk_tick_sweep(ZRK_F_ADVANCE) writes; the kernel reads
+ * pos[cur^1] (last tick's final positions) for targets that have not been stepped yet or
+ * are no longer live, and recomputes from trajectories otherwise, so it may run before,
+ * after or beside the sweep of the same tick.
+ */
+int zrk_missile_step(zrk_ctx *ctx, const zrk_entities *ents, int cur, const zrk_missiles *mis,
+                     int64_t m, int64_t time_ms, int64_t dt_ms, void *stream);
+
+/* AirEnv.step()'s tombstoning (modules/AirEnv.py:33-40) for k slots: alive = 0 and the final
+ * position (in pos[src]) frozen into both buffers so later readers see it. */
+int zrk_kill_slots(zrk_ctx *ctx, const zrk_entities *ents, int src, const int32_t *slots /* DEVICE */,
+                   int64_t k, void *stream);
+
+/* Same, taking last tick's event rows straight from the missile table on the device
+ * (no host round trip), then clearing ev_count. */
+int zrk_apply_events(zrk_ctx *ctx, const zrk_entities *ents, int src, const zrk_missiles *mis,
+                     void *stream);
+
+/* Missile._calculate_trajectory_params for a batch (modules/Missile.py:35-102), reading the
+ * targets' current positions from pos[cur]. */
+int zrk_launch_solve(zrk_ctx *ctx, const zrk_entities *ents, int cur, const zrk_launch_req *req /* DEVICE */,
+                     zrk_launch_res *res /* DEVICE */, int64_t k, void *stream);
+
+/* Numerics self-test hooks used by tests/: y[i] = op(a[i], b[i]) in device binary64.
+ * op: 0 sqrt(a), 1 a/b, 2 atan2(a,b), 3 asin(a), 4 fma-chain norm of (a,b,0). */
+int zrk_selftest_math(zrk_ctx *ctx, int op, const double *a, const double *b, double *y /* DEVICE */,
+                      int64_t n, void *stream);
+/* out[i*3..] = the Philox noise triple of (seed, tick, radar, entity0 + i). */
+int zrk_selftest_noise(zrk_ctx *ctx, uint64_t seed, uint64_t tick, uint32_t radar, int64_t entity0,
+                       double *out /* DEVICE [n][3] */, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZRK_HOT_H */

@@ -1,0 +1,184 @@
+"""ctypes binding of libzrk_hot.so (include/zrk_hot.h).
+
+There is no fallback: if the shared library is missing or does not load, importing
+anything that computes raises `HotPathUnavailable`.  The library is built in-tree by
+`__graft_entry__.build()` / `make -C zrk_modulation_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB_PATH = CSRC / "libzrk_hot.so"
+
+ZRK_ABI_VERSION = 1
+ZRK_MAX_RADARS = 32
+ZRK_BLOCK = 256
+F_ADVANCE, F_PHILOX, F_EXACT_ONLY = 1, 2, 4
+
+
+class HotPathUnavailable(RuntimeError):
+    pass
+
+
+class ZrkEntities(C.Structure):
+    _fields_ = [
+        ("capacity", C.c_int64),
+        ("start_pos", C.c_void_p),
+        ("velocity", C.c_void_p),
+        ("start_time", C.c_void_p),
+        ("alive", C.c_void_p),
+        ("kind", C.c_void_p),
+        ("pos", C.c_void_p * 2),
+        ("vis_mask", C.c_void_p),
+    ]
+
+
+class ZrkRadar(C.Structure):
+    _fields_ = [
+        ("pos", C.c_double * 3),
+        ("max_distance", C.c_double),
+        ("cur_azimuth", C.c_double),
+        ("azimuth_range", C.c_double),
+        ("cur_elevation", C.c_double),
+        ("elevation_range", C.c_double),
+    ]
+
+
+class ZrkMissiles(C.Structure):
+    _fields_ = [
+        ("capacity", C.c_int64),
+        ("slot", C.c_void_p),
+        ("target", C.c_void_p),
+        ("radius", C.c_void_p),
+        ("period", C.c_void_p),
+        ("status", C.c_void_p),
+        ("ev_code", C.c_void_p),
+        ("ev_missile", C.c_void_p),
+        ("ev_target", C.c_void_p),
+        ("ev_count", C.c_void_p),
+    ]
+
+
+class ZrkLaunchReq(C.Structure):
+    _fields_ = [
+        ("target_slot", C.c_int32),
+        ("_pad", C.c_int32),
+        ("missile_pos", C.c_double * 3),
+        ("speed", C.c_double),
+        ("period", C.c_double),
+    ]
+
+
+class ZrkLaunchRes(C.Structure):
+    _fields_ = [
+        ("rc", C.c_int32),
+        ("_pad", C.c_int32),
+        ("velocity", C.c_double * 3),
+        ("t_hit", C.c_double),
+    ]
+
+
+# name -> (restype, argtypes); the exported surface of include/zrk_hot.h
+_PROTOTYPES = {
+    "zrk_abi_version": (C.c_int, []),
+    "zrk_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "zrk_ctx_destroy": (None, [C.c_void_p]),
+    "zrk_last_error": (C.c_char_p, [C.c_void_p]),
+    "zrk_workspace_bytes": (C.c_int64, [C.c_int64]),
+    "zrk_tick_sweep": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.c_int64, C.c_int, C.c_int64,
+                                 C.POINTER(ZrkRadar), C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64,
+                                 C.c_int64, C.c_void_p, C.c_void_p]),
+    "zrk_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int32, C.c_void_p, C.c_void_p,
+                              C.c_int64, C.c_void_p, C.c_void_p]),
+    "zrk_noise_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p,
+                                  C.c_int64, C.c_void_p]),
+    "zrk_missile_step": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.c_int, C.POINTER(ZrkMissiles),
+                                   C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "zrk_kill_slots": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.c_int, C.c_void_p, C.c_int64,
+                                 C.c_void_p]),
+    "zrk_apply_events": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.c_int, C.POINTER(ZrkMissiles),
+                                   C.c_void_p]),
+    "zrk_launch_solve": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_int64, C.c_void_p]),
+    "zrk_selftest_math": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.c_void_p]),
+    "zrk_selftest_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64, C.c_void_p,
+                                     C.c_int64, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+
+_lib = None
+
+
+def build(force: bool = False) -> Path:
+    """Compile csrc/zrk_hot.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    src = CSRC / "zrk_hot.hip"
+    hdr = CSRC.parent.parent / "include" / "zrk_hot.h"
+    stale = (not LIB_PATH.exists()
+             or LIB_PATH.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime))
+    if force or stale:
+        subprocess.check_call(["make", "-C", str(CSRC)] + (["-B"] if force else []) + ["libzrk_hot.so"])
+    return LIB_PATH
+
+
+def load():
+    """dlopen libzrk_hot.so and attach prototypes.  Raises HotPathUnavailable, never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise HotPathUnavailable(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C {CSRC}`; there is no CPU fallback for the hot path")
+    try:
+        lib = C.CDLL(str(LIB_PATH))
+    except OSError as e:
+        raise HotPathUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HotPathUnavailable(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.zrk_abi_version() != ZRK_ABI_VERSION:
+        raise HotPathUnavailable(f"ABI mismatch: library {lib.zrk_abi_version()}, binding {ZRK_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+class ZrkError(RuntimeError):
+    pass
+
+
+class Context:
+    """Owns one zrk_ctx on one device."""
+
+    def __init__(self, device_index: int):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.zrk_ctx_create(int(device_index), C.byref(h))
+        if rc != 0 or not h.value:
+            raise HotPathUnavailable(f"zrk_ctx_create(device={device_index}) failed with {rc}: no usable HIP device")
+        self.handle = h
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.zrk_last_error(self.handle)
+            raise ZrkError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.zrk_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

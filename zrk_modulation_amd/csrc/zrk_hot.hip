@@ -1,0 +1,718 @@
+// zrk_hot.hip -- HIP kernels (gfx950 / MI355X) and the C ABI of include/zrk_hot.h.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (see csrc/Makefile).
+// -ffp-contract=off is part of the numerics contract: the reference rounds
+// start_pos + velocity*(t - t0) three times (modules/AirObject.py:23-25) and the only fused
+// operations are the explicit fma() chains that reproduce OpenBLAS ddot for n = 3
+// (np.linalg.norm / np.dot).
+//
+// No MFMA anywhere: the path has no dense contraction.  The sweep is one pass over the
+// entity columns (85 algorithmic bytes per live entity) with the radar parameter block
+// passed by value in the kernel-argument segment, so every wave reads it through the scalar
+// cache into SGPRs; an LDS tile of radars would only add a copy.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "zrk_hot.h"
+
+#define ZRK_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+constexpr double kRad2Deg = 180.0 / 3.14159265358979323846;   // numpy.degrees factor
+constexpr float kGuard = 3e-5f;                               // relative half-width of the "ambiguous" band
+
+// Device-side radar record: the exact binary64 gate of modules/Radar.py:56-70 plus a float32
+// pre-classification that settles every pair farther than kGuard (relative) from an edge.
+struct RadarDev {
+    double px, py, pz;
+    double d2_max;              // largest d2 with sqrt(d2) <= max_distance  (== `dist > max` gate)
+    double az_lo, az_hi;        // current_azimuth, current_azimuth + azimuth_range
+    double el_lo, el_hi;
+    float elx, ely, ehx, ehy;   // unit vectors of the (clamped) azimuth edges
+    float s_lo_up, s_hi_up;     // sin(elevation) bounds for dz >= 0
+    float s_lo_dn, s_hi_dn;     // and for dz < 0 (elevation wraps to (90,180])
+    float seam_g;               // kGuard when elevation 0 / 180 must be told apart, else -1
+    uint32_t az_mode;           // 0 never, 1 both edges (width <= 180), 2 either edge, 3 always exact
+};
+
+struct RadarBlock {
+    RadarDev r[ZRK_MAX_RADARS];
+};
+
+struct SweepParams {
+    const double *sp, *vel, *t0;
+    const uint8_t *alive;
+    double *pos;
+    uint32_t *vis;
+    int32_t *block_counts;      // [R][nb]
+    int64_t n, cap;
+    double t;
+    uint64_t seed, tick;
+    int64_t gid0;
+    int32_t R, radar_base, nb;
+    uint32_t flags;
+    RadarBlock rb;
+};
+
+__device__ __forceinline__ double dot3(double ax, double ay, double az, double bx, double by, double bz)
+{
+    return __builtin_fma(az, bz, __builtin_fma(ay, by, ax * bx));
+}
+
+// a % b of numpy / CPython for |a| < b, b > 0:  fmod is the identity there.
+__device__ __forceinline__ double floormod_small(double a, double b)
+{
+    double m = a;
+    if (m != 0.0) {
+        if (m < 0.0) m += b;
+    } else {
+        m = 0.0;                // -0.0 % b == +0.0
+    }
+    return m;
+}
+
+// modules/Radar.py:61-70 for a pair already inside the range gate.
+__device__ __noinline__ bool visible_exact(double az_lo, double az_hi, double el_lo, double el_hi,
+                                           double dx, double dy, double dz, double d2)
+{
+    double dist = sqrt(d2);
+    double az = floormod_small(atan2(dy, dx) * kRad2Deg, 360.0);
+    double el = floormod_small(asin(dz / dist) * kRad2Deg, 180.0);
+    return (az_lo <= az) && (az <= az_hi) && (el_lo <= el) && (el <= el_hi);
+}
+
+// Philox4x32-10, counter (entity lo, entity hi, tick, radar), key = seed.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Three N(0, sigma^2) values in binary32 (Box-Muller on the hardware log2 / sin / cos), widened.
+__device__ __forceinline__ void philox_noise(uint64_t seed, uint64_t tick, uint32_t radar, uint64_t entity,
+                                             float sigma, double out[3])
+{
+    uint32_t x[4];
+    philox4x32_10((uint32_t)entity, (uint32_t)(entity >> 32), (uint32_t)tick, radar, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), x);
+    const float k24 = 5.9604644775390625e-8f;
+    float u0 = ((float)(x[0] >> 8) + 0.5f) * k24;
+    float u1 = (float)(x[1] >> 8) * k24;
+    float u2 = ((float)(x[2] >> 8) + 0.5f) * k24;
+    float u3 = (float)(x[3] >> 8) * k24;
+    float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
+    float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+    out[0] = (double)(sigma * (r0 * __builtin_amdgcn_cosf(u1)));      // v_cos/v_sin take revolutions
+    out[1] = (double)(sigma * (r0 * __builtin_amdgcn_sinf(u1)));
+    out[2] = (double)(sigma * (r1 * __builtin_amdgcn_cosf(u3)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused advance + radar sweep.  One thread per entity slot, ZRK_BLOCK slots per workgroup.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P)
+{
+    __shared__ int s_cnt[ZRK_MAX_RADARS];
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * ZRK_BLOCK + tid;
+    if (tid < ZRK_MAX_RADARS) s_cnt[tid] = 0;
+    __syncthreads();
+
+    uint32_t mask = 0;
+    const bool live = (i < P.n) && P.alive[i];
+    if (live) {
+        const int64_t cap = P.cap;
+        double x, y, z;
+        if (P.flags & ZRK_F_ADVANCE) {
+            // Trajectory.get_pos: three separate roundings per axis
+            const double d = P.t - P.t0[i];
+            double sx = P.vel[i] * d, sy = P.vel[cap + i] * d, sz = P.vel[2 * cap + i] * d;
+            x = P.sp[i] + sx; y = P.sp[cap + i] + sy; z = P.sp[2 * cap + i] + sz;
+        } else {
+            x = P.pos[i]; y = P.pos[cap + i]; z = P.pos[2 * cap + i];
+        }
+        const bool exact_only = (P.flags & ZRK_F_EXACT_ONLY) != 0;
+        for (int r = 0; r < P.R; ++r) {
+            const RadarDev &rd = P.rb.r[r];
+            if (rd.az_mode == 0u) continue;
+            const double dx = x - rd.px, dy = y - rd.py, dz = z - rd.pz;
+            const double d2 = dot3(dx, dy, dz, dx, dy, dz);
+            if (d2 > rd.d2_max) continue;                    // == `distance > max_distance`
+            bool vis, amb;
+            {
+                const float fx = (float)dx, fy = (float)dy, fz = (float)dz;
+                const float rho2 = fx * fx + fy * fy;
+                const float d2f = rho2 + fz * fz;
+                const float cl = rd.elx * fy - rd.ely * fx;  // cross(e_lo, p)
+                const float ch = fx * rd.ehy - fy * rd.ehx;  // cross(p, e_hi)
+                const float g2r = (kGuard * kGuard) * rho2;
+                const bool az_amb = (cl * cl <= g2r) | (ch * ch <= g2r);
+                const bool az_in = (rd.az_mode == 1u) ? ((cl > 0.f) & (ch > 0.f)) : ((cl > 0.f) | (ch > 0.f));
+                const float dist = __builtin_amdgcn_sqrtf(d2f);
+                const float gd = kGuard * dist;
+                const bool up = fz >= 0.f;
+                const float s_lo = up ? rd.s_lo_up : rd.s_lo_dn;
+                const float s_hi = up ? rd.s_hi_up : rd.s_hi_dn;
+                const float a = fz - s_lo * dist, b = s_hi * dist - fz;
+                const bool el_amb = (fabsf(a) <= gd) | (fabsf(b) <= gd) | (fabsf(fz) <= rd.seam_g * dist);
+                const bool el_in = (a > 0.f) & (b > 0.f);
+                const bool finite = d2f < 1e30f;             // false for inf / NaN
+                amb = exact_only | az_amb | el_amb | !finite | (rd.az_mode == 3u);
+                vis = az_in & el_in;
+            }
+            if (amb) vis = visible_exact(rd.az_lo, rd.az_hi, rd.el_lo, rd.el_hi, dx, dy, dz, d2);
+            if (vis) {
+                mask |= 1u << r;
+                if (P.flags & ZRK_F_PHILOX) {
+                    double nz[3];
+                    philox_noise(P.seed, P.tick, (uint32_t)(P.radar_base + r), (uint64_t)(P.gid0 + i), 5.0f, nz);
+                    x += nz[0]; y += nz[1]; z += nz[2];      // modules/Radar.py:142, before the next radar looks
+                }
+            }
+        }
+        if (P.flags & (ZRK_F_ADVANCE | ZRK_F_PHILOX)) {
+            P.pos[i] = x; P.pos[cap + i] = y; P.pos[2 * cap + i] = z;
+        }
+    }
+    if (i < P.n) P.vis[i] = mask;
+
+    // per-workgroup detection counts per radar, consumed by the compaction's scan
+    const int lane = tid & 63;
+    for (int r = 0; r < P.R; ++r) {
+        const unsigned long long b = __ballot((mask >> r) & 1u);
+        if (lane == 0 && b) atomicAdd(&s_cnt[r], (int)__popcll(b));
+    }
+    __syncthreads();
+    if (tid < P.R) P.block_counts[(int64_t)tid * P.nb + blockIdx.x] = s_cnt[tid];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Compaction, phase 2: exclusive scan of the per-workgroup counts, one workgroup per radar.
+// ---------------------------------------------------------------------------------------------
+constexpr int kScanThreads = 1024;
+constexpr int kScanItems = 4;
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_counts(const int32_t *__restrict__ counts,
+                                                              int32_t *__restrict__ offs,
+                                                              int32_t *__restrict__ totals, int nb)
+{
+    __shared__ int s_wave[kScanThreads / 64];
+    __shared__ int s_carry;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t *c = counts + (int64_t)r * nb;
+    int32_t *o = offs + (int64_t)r * nb;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += kScanThreads * kScanItems) {
+        int v[kScanItems], sum = 0;
+        const int j0 = base + tid * kScanItems;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            v[k] = (j0 + k < nb) ? c[j0 + k] : 0;
+            sum += v[k];
+        }
+        int incl = sum;                                    // inclusive scan of `sum` across the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int wave_off = 0, total = 0;
+        for (int w = 0; w < kScanThreads / 64; ++w) {
+            int t = s_wave[w];
+            if (w < wave) wave_off += t;
+            total += t;
+        }
+        int run = s_carry + wave_off + incl - sum;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            if (j0 + k < nb) o[j0 + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (tid == 0) s_carry += total;
+        __syncthreads();
+    }
+    if (tid == 0) totals[r] = s_carry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Compaction, phase 3: stable scatter.  Lane order == slot order inside a wave, so
+// popcount(ballot & lanes-below) is the rank; waves and workgroups are ordered by the scans.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ZRK_BLOCK) void k_scatter(const uint32_t *__restrict__ vis, int64_t n, int R,
+                                                       int nb, const int32_t *__restrict__ offs,
+                                                       const int32_t *__restrict__ totals, int32_t base_index,
+                                                       int32_t *__restrict__ det_idx, int64_t det_capacity,
+                                                       int32_t *__restrict__ det_off)
+{
+    __shared__ int s_wcnt[ZRK_BLOCK / 64][ZRK_MAX_RADARS];
+    __shared__ int s_rbase[ZRK_MAX_RADARS + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i = (int64_t)blockIdx.x * ZRK_BLOCK + tid;
+    const uint32_t m = (i < n) ? vis[i] : 0u;
+    if (tid == 0) {
+        int acc = 0;
+        for (int r = 0; r < R; ++r) { s_rbase[r] = acc; acc += totals[r]; }
+        s_rbase[R] = acc;
+    }
+    for (int r = 0; r < R; ++r) {
+        const unsigned long long b = __ballot((m >> r) & 1u);
+        if (lane == 0) s_wcnt[wave][r] = (int)__popcll(b);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid <= R) det_off[tid] = s_rbase[tid];
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int r = 0; r < R; ++r) {
+        const unsigned long long b = __ballot((m >> r) & 1u);
+        if ((m >> r) & 1u) {
+            int rank = (int)__popcll(b & below);
+            for (int w = 0; w < wave; ++w) rank += s_wcnt[w][r];
+            const int64_t dst = (int64_t)s_rbase[r] + offs[(int64_t)r * nb + blockIdx.x] + rank;
+            if (dst < det_capacity) det_idx[dst] = base_index + (int32_t)i;
+        }
+    }
+}
+
+// SectorRadar.smooth_objects with supplied draws: pos[idx[j]] += noise[j].
+__global__ void k_noise_apply(double *__restrict__ pos, int64_t cap, const int32_t *__restrict__ idx,
+                              int32_t idx_base, const double *__restrict__ noise, int64_t k)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    const int64_t i = (int64_t)idx[j] - idx_base;
+    pos[i] += noise[3 * j];
+    pos[cap + i] += noise[3 * j + 1];
+    pos[2 * cap + i] += noise[3 * j + 2];
+}
+
+// Missile.step 'active' branch, one thread per in-flight missile.
+__global__ void k_missile_step(const double *__restrict__ sp, const double *__restrict__ vel,
+                               const double *__restrict__ t0, const uint8_t *__restrict__ alive,
+                               const double *__restrict__ pos_prev, int64_t cap, const int32_t *__restrict__ m_slot,
+                               const int32_t *__restrict__ m_tgt, const double *__restrict__ m_radius,
+                               double *__restrict__ m_period, uint8_t *__restrict__ m_status,
+                               uint8_t *__restrict__ ev_code, int64_t m, double t, double dts)
+{
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= m) return;
+    uint8_t code = 0;
+    const int32_t s = m_slot[row];
+    if (m_status[row] == 1 && alive[s]) {
+        const double d = t - t0[s];
+        const double px = sp[s] + vel[s] * d, py = sp[cap + s] + vel[cap + s] * d,
+                     pz = sp[2 * cap + s] + vel[2 * cap + s] * d;
+        const int32_t j = m_tgt[row];
+        double tx, ty, tz;
+        if (alive[j] && j < s) {          // already stepped this tick (list order): fresh, noise-free
+            const double dj = t - t0[j];
+            tx = sp[j] + vel[j] * dj; ty = sp[cap + j] + vel[cap + j] * dj; tz = sp[2 * cap + j] + vel[2 * cap + j] * dj;
+        } else {                          // not stepped yet, or removed: what it held after last tick
+            tx = pos_prev[j]; ty = pos_prev[cap + j]; tz = pos_prev[2 * cap + j];
+        }
+        const double dx = tx - px, dy = ty - py, dz = tz - pz;
+        const double dist = sqrt(dot3(dx, dy, dz, dx, dy, dz));
+        if (dist <= m_radius[row]) {
+            code = 1; m_status[row] = 2;
+        } else {
+            const double p = m_period[row] - dts;
+            m_period[row] = p;
+            if (p <= 0.0) { code = 2; m_status[row] = 2; }
+        }
+    }
+    ev_code[row] = code;
+}
+
+// Ordered event list from ev_code: one workgroup walks the (short) missile table in row order.
+__global__ __launch_bounds__(1024) void k_missile_events(const uint8_t *__restrict__ ev_code,
+                                                         const int32_t *__restrict__ m_slot,
+                                                         const int32_t *__restrict__ m_tgt, int64_t m,
+                                                         int32_t *__restrict__ ev_missile,
+                                                         int32_t *__restrict__ ev_target, int32_t *__restrict__ ev_count)
+{
+    __shared__ int s_wave[16];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < m; base += 1024) {
+        const int64_t row = base + tid;
+        const uint8_t c = (row < m) ? ev_code[row] : 0;
+        const unsigned long long b = __ballot(c != 0);
+        if (lane == 0) s_wave[wave] = (int)__popcll(b);
+        __syncthreads();
+        int off = s_carry, total = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) off += s_wave[w]; total += s_wave[w]; }
+        if (c) {
+            const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            const int k = off + (int)__popcll(b & below);
+            ev_missile[k] = m_slot[row];
+            ev_target[k] = (c == 1) ? m_tgt[row] : -1;
+        }
+        __syncthreads();
+        if (tid == 0) s_carry += total;
+        __syncthreads();
+    }
+    if (tid == 0) *ev_count = s_carry;
+}
+
+__device__ __forceinline__ void kill_one(uint8_t *alive, const double *src, double *dst, int64_t cap, int32_t s)
+{
+    alive[s] = 0;
+    dst[s] = src[s]; dst[cap + s] = src[cap + s]; dst[2 * cap + s] = src[2 * cap + s];
+}
+
+__global__ void k_kill_slots(uint8_t *alive, const double *src, double *dst, int64_t cap,
+                             const int32_t *__restrict__ slots, int64_t k)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < k && slots[j] >= 0) kill_one(alive, src, dst, cap, slots[j]);
+}
+
+__global__ void k_apply_events(uint8_t *alive, const double *src, double *dst, int64_t cap,
+                               const int32_t *__restrict__ ev_missile, const int32_t *__restrict__ ev_target,
+                               int32_t *ev_count, int64_t mcap)
+{
+    const int n = *ev_count;
+    for (int64_t j = threadIdx.x; j < n && j < mcap; j += blockDim.x) {
+        kill_one(alive, src, dst, cap, ev_missile[j]);
+        if (ev_target[j] >= 0) kill_one(alive, src, dst, cap, ev_target[j]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *ev_count = 0;
+}
+
+// Missile._calculate_trajectory_params, one thread per request (modules/Missile.py:35-102).
+__global__ void k_launch_solve(const double *__restrict__ vel, const uint8_t *__restrict__ kind,
+                               const double *__restrict__ pos, int64_t cap, const zrk_launch_req *__restrict__ req,
+                               zrk_launch_res *__restrict__ res, int64_t k)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= k) return;
+    const zrk_launch_req rq = req[q];
+    const int32_t j = rq.target_slot;
+    zrk_launch_res out;
+    out.rc = 0; out._pad = 0; out.velocity[0] = out.velocity[1] = out.velocity[2] = 0.0; out.t_hit = 0.0;
+    // target.velocity (unit) * target.speed_mod, modules/AirObject.py:35-36, modules/Missile.py:58.
+    // A missile used as a target has velocity NaN forever (Missile.py:26-27).
+    double vt[3];
+    {
+        const double vx = vel[j], vy = vel[cap + j], vz = vel[2 * cap + j];
+        const double nrm = sqrt(dot3(vx, vy, vz, vx, vy, vz));
+        if (kind[j] == 1) {
+            const double qnan = __builtin_nan("");
+            vt[0] = vt[1] = vt[2] = qnan;
+        } else {
+            vt[0] = (vx / nrm) * nrm; vt[1] = (vy / nrm) * nrm; vt[2] = (vz / nrm) * nrm;
+        }
+    }
+    const double d0 = pos[j] - rq.missile_pos[0], d1 = pos[cap + j] - rq.missile_pos[1],
+                 d2 = pos[2 * cap + j] - rq.missile_pos[2];
+    const double v0 = rq.speed;
+    const double a = dot3(vt[0], vt[1], vt[2], vt[0], vt[1], vt[2]) - v0 * v0;
+    const double b = 2.0 * dot3(d0, d1, d2, vt[0], vt[1], vt[2]);
+    const double c = dot3(d0, d1, d2, d0, d1, d2);
+    double t = 0.0;
+    if (fabs(a) < 1e-6) {
+        if (fabs(b) < 1e-6) out.rc = 1;
+        else {
+            t = -c / b;
+            if (t <= 0.0) out.rc = 2;
+        }
+    } else {
+        const double disc = b * b - 4.0 * a * c;
+        if (disc < 0.0) out.rc = 3;
+        else {
+            const double sq = sqrt(disc);
+            const double t1 = (-b + sq) / (2.0 * a), t2 = (-b - sq) / (2.0 * a);
+            bool have = false;
+            if (t1 > 0.0) { t = t1; have = true; }
+            if (t2 > 0.0) { if (!have || t2 < t) t = t2; have = true; }
+            if (!have) out.rc = 4;
+        }
+    }
+    if (out.rc == 0 && t > rq.period) out.rc = 5;
+    if (out.rc == 0) {
+        const double w0 = d0 / t + vt[0], w1 = d1 / t + vt[1], w2 = d2 / t + vt[2];
+        const double nrm = sqrt(dot3(w0, w1, w2, w0, w1, w2));
+        out.velocity[0] = w0 / nrm * v0; out.velocity[1] = w1 / nrm * v0; out.velocity[2] = w2 / nrm * v0;
+        out.t_hit = t;
+    }
+    res[q] = out;
+}
+
+__global__ void k_selftest_math(int op, const double *a, const double *b, double *y, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r;
+    switch (op) {
+    case 0: r = sqrt(a[i]); break;
+    case 1: r = a[i] / b[i]; break;
+    case 2: r = atan2(a[i], b[i]); break;
+    case 3: r = asin(a[i]); break;
+    default: r = sqrt(dot3(a[i], b[i], 0.0, a[i], b[i], 0.0)); break;
+    }
+    y[i] = r;
+}
+
+__global__ void k_selftest_noise(uint64_t seed, uint64_t tick, uint32_t radar, int64_t entity0, double *out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double nz[3];
+    philox_noise(seed, tick, radar, (uint64_t)(entity0 + i), 5.0f, nz);
+    out[3 * i] = nz[0]; out[3 * i + 1] = nz[1]; out[3 * i + 2] = nz[2];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+double d2_threshold(double m)
+{
+    if (std::isnan(m)) return INFINITY;            // `dist > nan` is never true
+    if (m < 0.0) return -1.0;                      // every dist >= 0 > m
+    if (std::isinf(m)) return INFINITY;
+    double c = m * m;
+    if (std::isinf(c)) c = DBL_MAX;
+    while (std::sqrt(c) > m) c = std::nextafter(c, 0.0);
+    for (;;) {
+        double nx = std::nextafter(c, INFINITY);
+        if (std::isinf(nx) || std::sqrt(nx) > m) break;
+        c = nx;
+    }
+    return c;
+}
+
+void derive_radar(const zrk_radar &h, RadarDev &d)
+{
+    const double deg = 3.14159265358979323846 / 180.0;
+    d.px = h.pos[0]; d.py = h.pos[1]; d.pz = h.pos[2];
+    d.d2_max = d2_threshold(h.max_distance);
+    d.az_lo = h.cur_azimuth; d.az_hi = h.cur_azimuth + h.azimuth_range;
+    d.el_lo = h.cur_elevation; d.el_hi = h.cur_elevation + h.elevation_range;
+    d.elx = d.ely = d.ehx = d.ehy = 0.f;
+    d.s_lo_up = d.s_lo_dn = 2.f; d.s_hi_up = d.s_hi_dn = -2.f;
+    d.seam_g = kGuard;
+    if (!std::isfinite(d.az_lo) || !std::isfinite(d.az_hi) || !std::isfinite(d.el_lo) || !std::isfinite(d.el_hi)) {
+        d.az_mode = 3u;                            // decide every in-range pair in binary64
+        return;
+    }
+    // azimuth lives in [0, 360]; the comparison has no wrap-around (modules/Radar.py:67-68)
+    const double lo = std::fmax(d.az_lo, 0.0), hi = std::fmin(d.az_hi, 360.0);
+    if (!(lo <= hi)) { d.az_mode = 0u; return; }
+    d.az_mode = (hi - lo <= 180.0) ? 1u : 2u;
+    d.elx = (float)std::cos(lo * deg); d.ely = (float)std::sin(lo * deg);
+    d.ehx = (float)std::cos(hi * deg); d.ehy = (float)std::sin(hi * deg);
+    // elevation: dz >= 0 -> el = theta in [0,90];  dz < 0 -> el = 180 + theta in [90,180]
+    const double lo_u = std::fmax(d.el_lo, 0.0), hi_u = std::fmin(d.el_hi, 90.0);
+    if (lo_u <= hi_u) {
+        d.s_lo_up = (d.el_lo <= 0.0) ? -2.f : (float)std::sin(lo_u * deg);
+        d.s_hi_up = (d.el_hi >= 90.0) ? 2.f : (float)std::sin(hi_u * deg);
+    }
+    const double lo_d = std::fmax(d.el_lo - 180.0, -90.0), hi_d = std::fmin(d.el_hi - 180.0, 0.0);
+    if (lo_d <= hi_d) {
+        d.s_lo_dn = (d.el_lo - 180.0 <= -90.0) ? -2.f : (float)std::sin(lo_d * deg);
+        d.s_hi_dn = (d.el_hi >= 180.0) ? 2.f : (float)std::sin(hi_d * deg);
+    }
+    if (d.el_lo <= 0.0 && d.el_hi >= 180.0) d.seam_g = -1.f;
+}
+
+}  // namespace
+
+struct zrk_ctx {
+    int device;
+    std::string err;
+};
+
+namespace {
+
+int fail(zrk_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+int check_launch(zrk_ctx *ctx, const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, ZRK_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return 0;
+}
+
+inline int nblocks(int64_t n, int per) { return (int)((n + per - 1) / per); }
+
+struct Workspace {
+    int32_t *counts, *offs, *totals;
+};
+
+Workspace carve(void *ws, int nb)
+{
+    Workspace w;
+    w.totals = (int32_t *)ws;                       // [ZRK_MAX_RADARS] (+ pad to 64 ints)
+    w.counts = w.totals + 64;
+    w.offs = w.counts + (int64_t)ZRK_MAX_RADARS * nb;
+    return w;
+}
+
+}  // namespace
+
+ZRK_API int zrk_abi_version(void) { return ZRK_ABI_VERSION; }
+
+ZRK_API int zrk_ctx_create(int device, zrk_ctx **out)
+{
+    if (!out) return ZRK_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return ZRK_E_HIP;
+    if (hipSetDevice(device) != hipSuccess) return ZRK_E_HIP;
+    zrk_ctx *c = new zrk_ctx;
+    c->device = device;
+    *out = c;
+    return 0;
+}
+
+ZRK_API void zrk_ctx_destroy(zrk_ctx *ctx) { delete ctx; }
+
+ZRK_API const char *zrk_last_error(zrk_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+ZRK_API int64_t zrk_workspace_bytes(int64_t n_max)
+{
+    if (n_max < 0) return ZRK_E_INVALID;
+    const int64_t nb = (n_max + ZRK_BLOCK - 1) / ZRK_BLOCK + 1;
+    return (64 + 2 * (int64_t)ZRK_MAX_RADARS * nb) * (int64_t)sizeof(int32_t);
+}
+
+ZRK_API int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_t time_ms,
+                           const zrk_radar *radars, int R, int radar_base, uint32_t flags, uint64_t seed,
+                           uint64_t tick, int64_t gid0, void *workspace, void *stream)
+{
+    if (!ctx || !e || !workspace || (R > 0 && !radars)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
+    if (R < 0 || R > ZRK_MAX_RADARS || radar_base < 0 || radar_base + R > 0xFFFF)
+        return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: radar count out of range");
+    if (n < 0 || n > e->capacity || (cur != 0 && cur != 1)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: n/cur out of range");
+    if (n == 0) return 0;
+    SweepParams P;
+    P.sp = e->start_pos; P.vel = e->velocity; P.t0 = e->start_time; P.alive = e->alive;
+    P.pos = e->pos[cur]; P.vis = e->vis_mask;
+    P.n = n; P.cap = e->capacity;
+    P.t = (double)time_ms / 1000.0;                 // to_seconds, modules/AirObject.py:5-7
+    P.seed = seed; P.tick = tick; P.gid0 = gid0;
+    P.R = R; P.radar_base = radar_base; P.nb = nblocks(n, ZRK_BLOCK); P.flags = flags;
+    P.block_counts = carve(workspace, P.nb).counts;
+    std::memset(&P.rb, 0, sizeof(P.rb));
+    for (int r = 0; r < R; ++r) derive_radar(radars[r], P.rb.r[r]);
+    hipLaunchKernelGGL(k_tick_sweep, dim3(P.nb), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P);
+    return check_launch(ctx, "k_tick_sweep");
+}
+
+ZRK_API int zrk_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int32_t base_index,
+                        void *workspace, int32_t *det_idx, int64_t det_capacity, int32_t *det_off, void *stream)
+{
+    if (!ctx || !vis_mask || !workspace || !det_idx || !det_off) return fail(ctx, ZRK_E_INVALID, "zrk_compact: null argument");
+    if (R < 0 || R > ZRK_MAX_RADARS || n < 0 || det_capacity < 0) return fail(ctx, ZRK_E_INVALID, "zrk_compact: size out of range");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0 || R == 0) {
+        if (hipMemsetAsync(det_off, 0, sizeof(int32_t) * (R + 1), s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "memset det_off");
+        return 0;
+    }
+    const int nb = nblocks(n, ZRK_BLOCK);
+    Workspace w = carve(workspace, nb);
+    hipLaunchKernelGGL(k_scan_counts, dim3(R), dim3(kScanThreads), 0, s, w.counts, w.offs, w.totals, nb);
+    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(ZRK_BLOCK), 0, s, vis_mask, n, R, nb, w.offs, w.totals, base_index,
+                       det_idx, det_capacity, det_off);
+    return check_launch(ctx, "zrk_compact");
+}
+
+ZRK_API int zrk_noise_apply(zrk_ctx *ctx, double *pos, int64_t capacity, const int32_t *idx, int32_t idx_base,
+                            const double *noise, int64_t k, void *stream)
+{
+    if (!ctx || !pos || (k > 0 && (!idx || !noise))) return fail(ctx, ZRK_E_INVALID, "zrk_noise_apply: null argument");
+    if (k <= 0) return 0;
+    hipLaunchKernelGGL(k_noise_apply, dim3(nblocks(k, 256)), dim3(256), 0, (hipStream_t)stream, pos, capacity, idx,
+                       idx_base, noise, k);
+    return check_launch(ctx, "k_noise_apply");
+}
+
+ZRK_API int zrk_missile_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const zrk_missiles *mis, int64_t m,
+                             int64_t time_ms, int64_t dt_ms, void *stream)
+{
+    if (!ctx || !e || !mis) return fail(ctx, ZRK_E_INVALID, "zrk_missile_step: null argument");
+    if (m < 0 || m > mis->capacity || (cur != 0 && cur != 1)) return fail(ctx, ZRK_E_INVALID, "zrk_missile_step: m/cur out of range");
+    hipStream_t s = (hipStream_t)stream;
+    if (m == 0) {
+        if (hipMemsetAsync(mis->ev_count, 0, sizeof(int32_t), s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "memset ev_count");
+        return 0;
+    }
+    const double t = (double)time_ms / 1000.0, dts = (double)dt_ms / 1000.0;
+    hipLaunchKernelGGL(k_missile_step, dim3(nblocks(m, 256)), dim3(256), 0, s, e->start_pos, e->velocity, e->start_time,
+                       e->alive, e->pos[cur ^ 1], e->capacity, mis->slot, mis->target, mis->radius, mis->period,
+                       mis->status, mis->ev_code, m, t, dts);
+    hipLaunchKernelGGL(k_missile_events, dim3(1), dim3(1024), 0, s, mis->ev_code, mis->slot, mis->target, m,
+                       mis->ev_missile, mis->ev_target, mis->ev_count);
+    return check_launch(ctx, "zrk_missile_step");
+}
+
+ZRK_API int zrk_kill_slots(zrk_ctx *ctx, const zrk_entities *e, int src, const int32_t *slots, int64_t k, void *stream)
+{
+    if (!ctx || !e || (k > 0 && !slots)) return fail(ctx, ZRK_E_INVALID, "zrk_kill_slots: null argument");
+    if (src != 0 && src != 1) return fail(ctx, ZRK_E_INVALID, "zrk_kill_slots: src out of range");
+    if (k <= 0) return 0;
+    hipLaunchKernelGGL(k_kill_slots, dim3(nblocks(k, 256)), dim3(256), 0, (hipStream_t)stream, e->alive, e->pos[src],
+                       e->pos[src ^ 1], e->capacity, slots, k);
+    return check_launch(ctx, "k_kill_slots");
+}
+
+ZRK_API int zrk_apply_events(zrk_ctx *ctx, const zrk_entities *e, int src, const zrk_missiles *mis, void *stream)
+{
+    if (!ctx || !e || !mis) return fail(ctx, ZRK_E_INVALID, "zrk_apply_events: null argument");
+    if (src != 0 && src != 1) return fail(ctx, ZRK_E_INVALID, "zrk_apply_events: src out of range");
+    hipLaunchKernelGGL(k_apply_events, dim3(1), dim3(256), 0, (hipStream_t)stream, e->alive, e->pos[src], e->pos[src ^ 1],
+                       e->capacity, mis->ev_missile, mis->ev_target, mis->ev_count, mis->capacity);
+    return check_launch(ctx, "k_apply_events");
+}
+
+ZRK_API int zrk_launch_solve(zrk_ctx *ctx, const zrk_entities *e, int cur, const zrk_launch_req *req,
+                             zrk_launch_res *res, int64_t k, void *stream)
+{
+    if (!ctx || !e || (k > 0 && (!req || !res))) return fail(ctx, ZRK_E_INVALID, "zrk_launch_solve: null argument");
+    if (cur != 0 && cur != 1) return fail(ctx, ZRK_E_INVALID, "zrk_launch_solve: cur out of range");
+    if (k <= 0) return 0;
+    hipLaunchKernelGGL(k_launch_solve, dim3(nblocks(k, 64)), dim3(64), 0, (hipStream_t)stream, e->velocity, e->kind,
+                       e->pos[cur], e->capacity, req, res, k);
+    return check_launch(ctx, "k_launch_solve");
+}
+
+ZRK_API int zrk_selftest_math(zrk_ctx *ctx, int op, const double *a, const double *b, double *y, int64_t n, void *stream)
+{
+    if (!ctx || !a || !b || !y) return fail(ctx, ZRK_E_INVALID, "zrk_selftest_math: null argument");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_selftest_math, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, op, a, b, y, n);
+    return check_launch(ctx, "k_selftest_math");
+}
+
+ZRK_API int zrk_selftest_noise(zrk_ctx *ctx, uint64_t seed, uint64_t tick, uint32_t radar, int64_t entity0,
+                               double *out, int64_t n, void *stream)
+{
+    if (!ctx || !out) return fail(ctx, ZRK_E_INVALID, "zrk_selftest_noise: null argument");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_selftest_noise, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, seed, tick, radar,
+                       entity0, out, n);
+    return check_launch(ctx, "k_selftest_noise");
+}

@@ -1,0 +1,326 @@
+"""EntityStore: AirEnv's object list as structure-of-arrays float64 tensors in HBM, plus the
+thin calls into libzrk_hot.so that act on it.
+
+Layout (see DESIGN.md "Data layout in HBM"):
+    start_pos, velocity          float64 [3][cap]   Trajectory columns (reference modules/AirObject.py:19-21)
+    start_time                   float64 [cap]
+    alive, kind                  uint8   [cap]      tombstones (modules/AirEnv.py:39-40); 0 target / 1 missile
+    pos                          float64 [2][3][cap] double buffer: pos[cur] is this tick's obj.pos,
+                                                     pos[cur^1] what obj.prev_pos aliases (AirObject.py:41)
+    vis_mask                     uint32  [cap]      bit r = detected by radar r
+    missile table                rows in the order missiles entered the air (= slot order)
+Slots are never reused, so slot order == the order of the reference's `self.__objects`.
+
+PyTorch is only the allocator / stream owner here; every computation is a HIP kernel behind the
+C ABI.  Constructing a store without a usable GPU + libzrk_hot.so raises HotPathUnavailable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (F_ADVANCE, F_EXACT_ONLY, F_PHILOX, HotPathUnavailable, ZrkEntities, ZrkLaunchReq,
+                   ZrkLaunchRes, ZrkMissiles, ZrkRadar)
+
+LAUNCH_ERRORS = {
+    1: "No interception possible: target and interceptor are stationary relative or parallel.",
+    2: "Interception impossible in the future: computed time t <= 0.",
+    3: "No real interception time: target is too fast or out of range.",
+    4: "Interception times are not positive; interception not possible in future.",
+    5: "Target is too far for this rocket (detonation_period over limited)",
+}
+
+
+def _round_up(n, q):
+    return ((int(n) + q - 1) // q) * q
+
+
+def radar_struct_array(params):
+    """params: iterable of (px,py,pz,max_distance,cur_az,az_range,cur_el,el_range) -> ZrkRadar[]"""
+    params = list(params)
+    arr = (ZrkRadar * max(len(params), 1))()
+    for k, p in enumerate(params):
+        arr[k].pos[0], arr[k].pos[1], arr[k].pos[2] = float(p[0]), float(p[1]), float(p[2])
+        arr[k].max_distance = float(p[3])
+        arr[k].cur_azimuth, arr[k].azimuth_range = float(p[4]), float(p[5])
+        arr[k].cur_elevation, arr[k].elevation_range = float(p[6]), float(p[7])
+    return arr
+
+
+class EntityStore:
+    def __init__(self, device=None, capacity: int = 1024, missile_capacity: int = 64):
+        if not torch.cuda.is_available():
+            raise HotPathUnavailable("no HIP device visible: the hot path has no CPU fallback")
+        self.device = torch.device(device if device is not None else "cuda:0")
+        if self.device.type != "cuda":
+            raise HotPathUnavailable(f"EntityStore needs a HIP device, got {self.device}")
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        self.ctx = _lib.Context(idx)
+        self.lib = self.ctx.lib
+        self.cap = 0
+        self.mcap = 0
+        self.n = 0                 # slots in use
+        self.n_uploaded = 0
+        self.n_stepped = 0         # slots that existed at the last advance
+        self.m = 0                 # in-flight missile rows
+        self.cur = 0
+        self.time_ms = None        # time of the last advance
+        self.version = 0           # bumped whenever device positions change
+        self._snap = {}
+        # host mirrors of the immutable columns (what the handles expose as .trajectory etc.)
+        self.h_ids = np.zeros(0, np.int64)
+        self.h_kind = np.zeros(0, np.uint8)
+        self.h_sp = np.zeros((0, 3)); self.h_vel = np.zeros((0, 3)); self.h_t0 = np.zeros(0)
+        self.h_pos0 = np.zeros((0, 3))
+        self.h_alive = np.zeros(0, np.uint8)
+        self.slots_of_id = {}
+        # host mirror of the missile table's static columns
+        self.hm_slot = np.zeros(0, np.int32); self.hm_tgt = np.zeros(0, np.int32)
+        self._alloc_entities(max(int(capacity), 256))
+        self._alloc_missiles(max(int(missile_capacity), 64))
+        self._ws = None
+        self._det_idx = None
+        self._det_off = torch.zeros(_lib.ZRK_MAX_RADARS + 1, dtype=torch.int32, device=self.device)
+
+    # -- allocation -------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _alloc_entities(self, cap):
+        cap = _round_up(cap, 256)
+        dev, f64 = self.device, torch.float64
+        new = dict(sp=torch.zeros(3, cap, dtype=f64, device=dev), vel=torch.zeros(3, cap, dtype=f64, device=dev),
+                   t0=torch.zeros(cap, dtype=f64, device=dev), alive=torch.zeros(cap, dtype=torch.uint8, device=dev),
+                   kind=torch.zeros(cap, dtype=torch.uint8, device=dev),
+                   pos=torch.zeros(2, 3, cap, dtype=f64, device=dev),
+                   vis=torch.zeros(cap, dtype=torch.int32, device=dev))
+        if self.cap:
+            k = self.n_uploaded
+            for name, t in new.items():
+                old = getattr(self, "d_" + name)
+                t[..., :k] = old[..., :k]
+        for name, t in new.items():
+            setattr(self, "d_" + name, t)
+        self.cap = cap
+        e = ZrkEntities()
+        e.capacity = cap
+        e.start_pos, e.velocity, e.start_time = self.d_sp.data_ptr(), self.d_vel.data_ptr(), self.d_t0.data_ptr()
+        e.alive, e.kind = self.d_alive.data_ptr(), self.d_kind.data_ptr()
+        e.pos[0], e.pos[1] = self.d_pos[0].data_ptr(), self.d_pos[1].data_ptr()
+        e.vis_mask = self.d_vis.data_ptr()
+        self.ents = e
+        self._ws = None
+        self._det_idx = None
+
+    def _alloc_missiles(self, mcap):
+        mcap = _round_up(mcap, 64)
+        dev = self.device
+        new = dict(slot=torch.zeros(mcap, dtype=torch.int32, device=dev),
+                   tgt=torch.zeros(mcap, dtype=torch.int32, device=dev),
+                   radius=torch.zeros(mcap, dtype=torch.float64, device=dev),
+                   period=torch.zeros(mcap, dtype=torch.float64, device=dev),
+                   status=torch.zeros(mcap, dtype=torch.uint8, device=dev),
+                   evcode=torch.zeros(mcap, dtype=torch.uint8, device=dev),
+                   evm=torch.zeros(mcap, dtype=torch.int32, device=dev),
+                   evt=torch.zeros(mcap, dtype=torch.int32, device=dev),
+                   evn=torch.zeros(1, dtype=torch.int32, device=dev))
+        if self.mcap:
+            for name, t in new.items():
+                if name != "evn":
+                    t[:self.m] = getattr(self, "dm_" + name)[:self.m]
+        for name, t in new.items():
+            setattr(self, "dm_" + name, t)
+        self.mcap = mcap
+        ms = ZrkMissiles()
+        ms.capacity = mcap
+        ms.slot, ms.target = self.dm_slot.data_ptr(), self.dm_tgt.data_ptr()
+        ms.radius, ms.period, ms.status = self.dm_radius.data_ptr(), self.dm_period.data_ptr(), self.dm_status.data_ptr()
+        ms.ev_code, ms.ev_missile, ms.ev_target = self.dm_evcode.data_ptr(), self.dm_evm.data_ptr(), self.dm_evt.data_ptr()
+        ms.ev_count = self.dm_evn.data_ptr()
+        self.mis = ms
+
+    def workspace(self):
+        need = int(self.lib.zrk_workspace_bytes(self.cap))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def det_buffer(self, entries):
+        if self._det_idx is None or self._det_idx.numel() < entries:
+            self._det_idx = torch.zeros(max(int(entries), 256), dtype=torch.int32, device=self.device)
+        return self._det_idx
+
+    # -- population -------------------------------------------------------------------------
+    def add_entities(self, ids, start_pos, velocity, start_time, kind=0, pos0=None):
+        """Append rows (host side); they reach the device at the next flush()."""
+        sp = np.asarray(start_pos, np.float64).reshape(-1, 3)
+        k = sp.shape[0]
+        vel = np.asarray(velocity, np.float64).reshape(k, 3)
+        t0 = np.broadcast_to(np.asarray(start_time, np.float64), (k,))
+        ids = np.broadcast_to(np.asarray(ids, np.int64), (k,))
+        p0 = sp if pos0 is None else np.asarray(pos0, np.float64).reshape(k, 3)
+        first = self.n
+        self.h_ids = np.concatenate([self.h_ids, ids])
+        self.h_kind = np.concatenate([self.h_kind, np.full(k, kind, np.uint8)])
+        self.h_sp = np.concatenate([self.h_sp, sp]); self.h_vel = np.concatenate([self.h_vel, vel])
+        self.h_t0 = np.concatenate([self.h_t0, t0]); self.h_pos0 = np.concatenate([self.h_pos0, p0])
+        self.h_alive = np.concatenate([self.h_alive, np.ones(k, np.uint8)])
+        if k <= 4096:
+            for j in range(k):
+                self.slots_of_id.setdefault(int(ids[j]), []).append(first + j)
+        else:
+            self.slots_of_id = None        # bulk load: id lookups go through np.nonzero(h_ids == id)
+        self.n += k
+        return first
+
+    def slots_for_id(self, id):
+        if self.slots_of_id is not None:
+            return self.slots_of_id.get(int(id), [])
+        return np.nonzero(self.h_ids[:self.n] == id)[0].tolist()
+
+    def flush(self):
+        """Upload rows added since the last flush."""
+        a, b = self.n_uploaded, self.n
+        if a == b:
+            return
+        if b > self.cap:
+            self._alloc_entities(max(b, 2 * self.cap))
+        dev = self.device
+        self.d_sp[:, a:b] = torch.from_numpy(np.ascontiguousarray(self.h_sp[a:b].T)).to(dev)
+        self.d_vel[:, a:b] = torch.from_numpy(np.ascontiguousarray(self.h_vel[a:b].T)).to(dev)
+        self.d_t0[a:b] = torch.from_numpy(np.ascontiguousarray(self.h_t0[a:b])).to(dev)
+        self.d_kind[a:b] = torch.from_numpy(np.ascontiguousarray(self.h_kind[a:b])).to(dev)
+        self.d_alive[a:b] = 1
+        p0 = torch.from_numpy(np.ascontiguousarray(self.h_pos0[a:b].T)).to(dev)
+        self.d_pos[0][:, a:b] = p0
+        self.d_pos[1][:, a:b] = p0          # both buffers: whichever is "previous" at its first step
+        self.n_uploaded = b
+        self._bump()
+
+    def add_missile_row(self, slot, target_slot, radius, period):
+        if self.m + 1 > self.mcap:
+            self._alloc_missiles(2 * self.mcap)
+        r = self.m
+        self.dm_slot[r] = int(slot); self.dm_tgt[r] = int(target_slot)
+        self.dm_radius[r] = float(radius); self.dm_period[r] = float(period)
+        self.dm_status[r] = 1
+        self.hm_slot = np.append(self.hm_slot, np.int32(slot)); self.hm_tgt = np.append(self.hm_tgt, np.int32(target_slot))
+        self.m += 1
+        return r
+
+    def add_missile_rows(self, slots, target_slots, radius, period):
+        """Bulk form of add_missile_row (synthetic scenarios)."""
+        k = len(slots)
+        if self.m + k > self.mcap:
+            self._alloc_missiles(max(2 * self.mcap, self.m + k))
+        a, b = self.m, self.m + k
+        dev = self.device
+        self.dm_slot[a:b] = torch.as_tensor(np.asarray(slots, np.int32), device=dev)
+        self.dm_tgt[a:b] = torch.as_tensor(np.asarray(target_slots, np.int32), device=dev)
+        self.dm_radius[a:b] = torch.as_tensor(np.broadcast_to(np.asarray(radius, np.float64), (k,)).copy(), device=dev)
+        self.dm_period[a:b] = torch.as_tensor(np.broadcast_to(np.asarray(period, np.float64), (k,)).copy(), device=dev)
+        self.dm_status[a:b] = 1
+        self.hm_slot = np.concatenate([self.hm_slot, np.asarray(slots, np.int32)])
+        self.hm_tgt = np.concatenate([self.hm_tgt, np.asarray(target_slots, np.int32)])
+        self.m = b
+
+    # -- snapshots for host-side readers ----------------------------------------------------------
+    def _bump(self):
+        self.version += 1
+        self._snap.clear()
+
+    def host_pos(self, which="cur"):
+        """(n,3) float64 copy of pos[cur] ('cur') or pos[cur^1] ('prev'); cached until the next kernel."""
+        key = which
+        if key not in self._snap:
+            buf = self.cur if which == "cur" else self.cur ^ 1
+            self._snap[key] = self.d_pos[buf][:, :self.n_uploaded].T.contiguous().cpu().numpy()
+        return self._snap[key]
+
+    def write_pos(self, slot, value):
+        v = torch.as_tensor(np.asarray(value, np.float64).reshape(3), device=self.device)
+        self.d_pos[self.cur][:, int(slot)] = v
+        self._bump()
+
+    # -- kernels ------------------------------------------------------------------------------
+    def kill(self, slots):
+        """AirEnv tombstoning; `slots` are frozen at their current (pos[cur]) values."""
+        slots = [int(s) for s in slots if self.h_alive[int(s)]]
+        if not slots:
+            return
+        for s in slots:
+            self.h_alive[s] = 0
+        d = torch.as_tensor(np.asarray(slots, np.int32), device=self.device)
+        self.ctx.check(self.lib.zrk_kill_slots(self.ctx.handle, C.byref(self.ents), self.cur, d.data_ptr(), len(slots),
+                                               self._stream()), "zrk_kill_slots")
+        self._bump()
+
+    def begin_tick(self, time_ms):
+        """Flip the position double buffer: last tick's final positions become 'previous'."""
+        self.flush()
+        self.cur ^= 1
+        self.time_ms = int(time_ms)
+        self._bump()
+
+    def missile_step(self, dt_ms):
+        """Missile.step for all in-flight rows.  Returns [(missile slot, target slot | -1)] in list order."""
+        self.ctx.check(self.lib.zrk_missile_step(self.ctx.handle, C.byref(self.ents), self.cur, C.byref(self.mis), self.m,
+                                                 self.time_ms, int(dt_ms), self._stream()), "zrk_missile_step")
+        if self.m == 0:
+            return []
+        k = int(self.dm_evn.item())
+        if k == 0:
+            return []
+        em = self.dm_evm[:k].cpu().numpy(); et = self.dm_evt[:k].cpu().numpy()
+        return [(int(a), int(b)) for a, b in zip(em, et)]
+
+    def sweep(self, radars, flags, radar_base=0, seed=0, tick=0, gid0=0, n=None):
+        """zrk_tick_sweep over slots [0, n) for the given radar parameter tuples."""
+        n = self.n_uploaded if n is None else n
+        arr = radars if isinstance(radars, C.Array) else radar_struct_array(radars)
+        R = len(radars)
+        self.ctx.check(self.lib.zrk_tick_sweep(self.ctx.handle, C.byref(self.ents), n, self.cur, self.time_ms, arr, R,
+                                               radar_base, flags, seed, tick, gid0, self.workspace().data_ptr(),
+                                               self._stream()), "zrk_tick_sweep")
+        if flags & F_ADVANCE:
+            self.n_stepped = n
+        if flags & (F_ADVANCE | F_PHILOX):
+            self._bump()
+        return R
+
+    def compact(self, R, base_index=0, n=None, det_capacity=None):
+        """zrk_compact after sweep(); returns (det_idx tensor, det_off tensor[R+1]) on the device."""
+        n = self.n_uploaded if n is None else n
+        capn = n * max(R, 1) if det_capacity is None else det_capacity
+        det = self.det_buffer(capn)
+        self.ctx.check(self.lib.zrk_compact(self.ctx.handle, self.d_vis.data_ptr(), n, R, base_index,
+                                            self.workspace().data_ptr(), det.data_ptr(), det.numel(),
+                                            self._det_off.data_ptr(), self._stream()), "zrk_compact")
+        return det, self._det_off
+
+    def noise_apply(self, det_idx, k, noise, idx_base=0):
+        nz = torch.as_tensor(np.ascontiguousarray(noise, np.float64).reshape(k, 3), device=self.device)
+        self.ctx.check(self.lib.zrk_noise_apply(self.ctx.handle, self.d_pos[self.cur].data_ptr(), self.cap,
+                                                det_idx.data_ptr(), idx_base, nz.data_ptr(), k, self._stream()),
+                       "zrk_noise_apply")
+        self._bump()
+
+    def launch_solve(self, target_slot, missile_pos, speed, period):
+        """Missile._calculate_trajectory_params on the device.  Returns (rc, V[3], t_hit)."""
+        req = np.zeros(1, dtype=np.dtype([("target_slot", "<i4"), ("_pad", "<i4"), ("missile_pos", "<f8", 3),
+                                          ("speed", "<f8"), ("period", "<f8")]))
+        assert req.dtype.itemsize == C.sizeof(ZrkLaunchReq)
+        req["target_slot"] = int(target_slot); req["missile_pos"] = np.asarray(missile_pos, np.float64)
+        req["speed"] = float(speed); req["period"] = float(period)
+        d_req = torch.from_numpy(req.view(np.uint8)).to(self.device)
+        d_res = torch.zeros(C.sizeof(ZrkLaunchRes), dtype=torch.uint8, device=self.device)
+        self.flush()
+        self.ctx.check(self.lib.zrk_launch_solve(self.ctx.handle, C.byref(self.ents), self.cur, d_req.data_ptr(),
+                                                 d_res.data_ptr(), 1, self._stream()), "zrk_launch_solve")
+        res = d_res.cpu().numpy().view(np.dtype([("rc", "<i4"), ("_pad", "<i4"), ("velocity", "<f8", 3),
+                                                 ("t_hit", "<f8")]))[0]
+        return int(res["rc"]), np.array(res["velocity"], np.float64), float(res["t_hit"])
