@@ -128,10 +128,15 @@ int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *ents, int64_t n, int cur, i
  * Must follow zrk_tick_sweep on the same stream with the same n, R and workspace.
  * det_capacity bounds det_idx; on overflow det_off is still exact and entries past the
  * capacity are dropped (det_off[R] > det_capacity tells the caller).
+ * `packed` (optional) receives the union list used by the multi-GPU exchange: packed[0] = number
+ * of slots seen by at least one radar, then for each such slot, ascending,
+ * ((gid0 + slot) << 32) | vis_mask -- per-radar lists are stable filters of it.
  */
 int zrk_compact(zrk_ctx *ctx, const uint32_t *vis_mask /* DEVICE */, int64_t n, int R,
-                int32_t base_index, void *workspace, int32_t *det_idx /* DEVICE */,
-                int64_t det_capacity, int32_t *det_off /* DEVICE [R+1] */, void *stream);
+                int32_t base_index, void *workspace, int32_t *det_idx /* DEVICE, may be NULL */,
+                int64_t det_capacity, int32_t *det_off /* DEVICE [R+1] */,
+                int64_t *packed /* DEVICE, may be NULL */, int64_t packed_capacity, int64_t gid0,
+                void *stream);
 
 /* SectorRadar.smooth_objects with caller-supplied draws (modules/Radar.py:138-142):
  * pos[idx[j]] += noise[j] for j < k, noise row-major k x 3. */
@@ -166,6 +171,46 @@ int zrk_apply_events(zrk_ctx *ctx, const zrk_entities *ents, int src, const zrk_
  * targets' current positions from pos[cur]. */
 int zrk_launch_solve(zrk_ctx *ctx, const zrk_entities *ents, int cur, const zrk_launch_req *req /* DEVICE */,
                      zrk_launch_res *res /* DEVICE */, int64_t k, void *stream);
+
+/* Static scan parameters of one radar (modules/Radar.py:13-42): what
+ * move_to_next_sector_circular reads besides the current angles. */
+typedef struct {
+    double azimuth_speed, elevation_speed, elevation_start;
+    int32_t mode;                   /* 0 "horizontal", 1 "vertical", anything else: never moves */
+    int32_t _pad;
+} zrk_scan;
+
+/* SectorRadar.move_to_next_sector_circular (modules/Radar.py:96-117) for R radars, on the host
+ * (a7 in SURVEY.md section 8: scalar per-radar state, uploaded with the next sweep). */
+int zrk_scan_advance(zrk_radar *radars /* HOST, in/out */, const zrk_scan *scan /* HOST */, int R);
+
+/* Loop state of zrk_run_ticks (in/out). */
+typedef struct {
+    int64_t n;                      /* slots in use */
+    int64_t time_ms, dt_ms;         /* Timer.get_time / get_dt (modules/Timer.py:20-30) */
+    int64_t gid0;                   /* global index of slot 0 (multi-GPU shard offset) */
+    uint64_t seed, tick;            /* Philox key / tick counter */
+    int32_t cur;                    /* position buffer holding the LAST completed tick */
+    int32_t base_index;             /* added to slots in det_idx */
+    uint32_t flags;                 /* ZRK_F_PHILOX etc.; ZRK_F_ADVANCE is implied */
+    uint32_t _pad;
+} zrk_loop;
+
+/*
+ * K ticks of the L1 path, enqueued back to back on `stream` without returning to the caller:
+ * per tick  zrk_apply_events (last tick's detonations) -> flip buffer -> zrk_missile_step ->
+ * zrk_tick_sweep(ADVANCE) -> zrk_compact -> zrk_scan_advance -> time += dt.
+ *   replaces the per-tick `module.step()` calls of Manager.run_simulation for AirEnv and every
+ *   SectorRadar (modules/Manager.py:123-131, :140).
+ * Detection outputs hold the last tick's lists.  If sweep_ms != NULL the sweep kernel of every
+ * prof_stride-th tick is bracketed by HIP events on `stream`, the stream is synchronised at the
+ * end and sweep_ms[k / prof_stride] receives the kernel's duration in milliseconds.
+ */
+int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *ents, const zrk_missiles *mis, int64_t m, zrk_loop *st,
+                  zrk_radar *radars /* HOST, in/out */, const zrk_scan *scan /* HOST */, int R, void *workspace,
+                  int32_t *det_idx, int64_t det_capacity, int32_t *det_off, int64_t *packed,
+                  int64_t packed_capacity, int K, float *sweep_ms /* HOST, may be NULL */, int prof_stride,
+                  void *stream);
 
 /* Numerics self-test hooks used by tests/: y[i] = op(a[i], b[i]) in device binary64.
  * op: 0 sqrt(a), 1 a/b, 2 atan2(a,b), 3 asin(a), 4 fma-chain norm of (a,b,0). */

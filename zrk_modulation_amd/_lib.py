@@ -82,6 +82,31 @@ class ZrkLaunchRes(C.Structure):
     ]
 
 
+class ZrkScan(C.Structure):
+    _fields_ = [
+        ("azimuth_speed", C.c_double),
+        ("elevation_speed", C.c_double),
+        ("elevation_start", C.c_double),
+        ("mode", C.c_int32),
+        ("_pad", C.c_int32),
+    ]
+
+
+class ZrkLoop(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("time_ms", C.c_int64),
+        ("dt_ms", C.c_int64),
+        ("gid0", C.c_int64),
+        ("seed", C.c_uint64),
+        ("tick", C.c_uint64),
+        ("cur", C.c_int32),
+        ("base_index", C.c_int32),
+        ("flags", C.c_uint32),
+        ("_pad", C.c_uint32),
+    ]
+
+
 # name -> (restype, argtypes); the exported surface of include/zrk_hot.h
 _PROTOTYPES = {
     "zrk_abi_version": (C.c_int, []),
@@ -93,7 +118,12 @@ _PROTOTYPES = {
                                  C.POINTER(ZrkRadar), C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64,
                                  C.c_int64, C.c_void_p, C.c_void_p]),
     "zrk_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int32, C.c_void_p, C.c_void_p,
-                              C.c_int64, C.c_void_p, C.c_void_p]),
+                              C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "zrk_scan_advance": (C.c_int, [C.POINTER(ZrkRadar), C.POINTER(ZrkScan), C.c_int]),
+    "zrk_run_ticks": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.POINTER(ZrkMissiles), C.c_int64,
+                                C.POINTER(ZrkLoop), C.POINTER(ZrkRadar), C.POINTER(ZrkScan), C.c_int, C.c_void_p,
+                                C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                C.POINTER(C.c_float), C.c_int, C.c_void_p]),
     "zrk_noise_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p,
                                   C.c_int64, C.c_void_p]),
     "zrk_missile_step": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.c_int, C.POINTER(ZrkMissiles),

@@ -126,10 +126,10 @@ __device__ __forceinline__ void philox_noise(uint64_t seed, uint64_t tick, uint3
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P)
 {
-    __shared__ int s_cnt[ZRK_MAX_RADARS];
+    __shared__ int s_cnt[ZRK_MAX_RADARS + 1];
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * ZRK_BLOCK + tid;
-    if (tid < ZRK_MAX_RADARS) s_cnt[tid] = 0;
+    if (tid <= ZRK_MAX_RADARS) s_cnt[tid] = 0;
     __syncthreads();
 
     uint32_t mask = 0;
@@ -190,14 +190,18 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P)
     }
     if (i < P.n) P.vis[i] = mask;
 
-    // per-workgroup detection counts per radar, consumed by the compaction's scan
+    // per-workgroup detection counts per radar (row R: seen by any radar), consumed by the scan
     const int lane = tid & 63;
     for (int r = 0; r < P.R; ++r) {
         const unsigned long long b = __ballot((mask >> r) & 1u);
         if (lane == 0 && b) atomicAdd(&s_cnt[r], (int)__popcll(b));
     }
+    {
+        const unsigned long long b = __ballot(mask != 0u);
+        if (lane == 0 && b) atomicAdd(&s_cnt[P.R], (int)__popcll(b));
+    }
     __syncthreads();
-    if (tid < P.R) P.block_counts[(int64_t)tid * P.nb + blockIdx.x] = s_cnt[tid];
+    if (tid <= P.R) P.block_counts[(int64_t)tid * P.nb + blockIdx.x] = s_cnt[tid];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -260,9 +264,10 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_scatter(const uint32_t *__restric
                                                        int nb, const int32_t *__restrict__ offs,
                                                        const int32_t *__restrict__ totals, int32_t base_index,
                                                        int32_t *__restrict__ det_idx, int64_t det_capacity,
-                                                       int32_t *__restrict__ det_off)
+                                                       int32_t *__restrict__ det_off, int64_t *__restrict__ packed,
+                                                       int64_t packed_capacity, int64_t gid0)
 {
-    __shared__ int s_wcnt[ZRK_BLOCK / 64][ZRK_MAX_RADARS];
+    __shared__ int s_wcnt[ZRK_BLOCK / 64][ZRK_MAX_RADARS + 1];
     __shared__ int s_rbase[ZRK_MAX_RADARS + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t i = (int64_t)blockIdx.x * ZRK_BLOCK + tid;
@@ -276,16 +281,30 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_scatter(const uint32_t *__restric
         const unsigned long long b = __ballot((m >> r) & 1u);
         if (lane == 0) s_wcnt[wave][r] = (int)__popcll(b);
     }
+    const unsigned long long bu = __ballot(m != 0u);
+    if (lane == 0) s_wcnt[wave][R] = (int)__popcll(bu);
     __syncthreads();
-    if (blockIdx.x == 0 && tid <= R) det_off[tid] = s_rbase[tid];
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int r = 0; r < R; ++r) {
-        const unsigned long long b = __ballot((m >> r) & 1u);
-        if ((m >> r) & 1u) {
-            int rank = (int)__popcll(b & below);
-            for (int w = 0; w < wave; ++w) rank += s_wcnt[w][r];
-            const int64_t dst = (int64_t)s_rbase[r] + offs[(int64_t)r * nb + blockIdx.x] + rank;
-            if (dst < det_capacity) det_idx[dst] = base_index + (int32_t)i;
+    if (det_idx) {
+        if (blockIdx.x == 0 && tid <= R) det_off[tid] = s_rbase[tid];
+        for (int r = 0; r < R; ++r) {
+            const unsigned long long b = __ballot((m >> r) & 1u);
+            if ((m >> r) & 1u) {
+                int rank = (int)__popcll(b & below);
+                for (int w = 0; w < wave; ++w) rank += s_wcnt[w][r];
+                const int64_t dst = (int64_t)s_rbase[r] + offs[(int64_t)r * nb + blockIdx.x] + rank;
+                if (dst < det_capacity) det_idx[dst] = base_index + (int32_t)i;
+            }
+        }
+    }
+    if (packed) {
+        // union list for the multi-GPU exchange: packed[0] = count, then (global index << 32 | mask)
+        if (blockIdx.x == 0 && tid == 0) packed[0] = totals[R];
+        if (m != 0u) {
+            int rank = (int)__popcll(bu & below);
+            for (int w = 0; w < wave; ++w) rank += s_wcnt[w][R];
+            const int64_t dst = (int64_t)offs[(int64_t)R * nb + blockIdx.x] + rank;
+            if (dst + 1 < packed_capacity) packed[dst + 1] = ((gid0 + i) << 32) | (int64_t)m;
         }
     }
 }
@@ -567,7 +586,7 @@ Workspace carve(void *ws, int nb)
     Workspace w;
     w.totals = (int32_t *)ws;                       // [ZRK_MAX_RADARS] (+ pad to 64 ints)
     w.counts = w.totals + 64;
-    w.offs = w.counts + (int64_t)ZRK_MAX_RADARS * nb;
+    w.offs = w.counts + (int64_t)(ZRK_MAX_RADARS + 1) * nb;
     return w;
 }
 
@@ -596,7 +615,7 @@ ZRK_API int64_t zrk_workspace_bytes(int64_t n_max)
 {
     if (n_max < 0) return ZRK_E_INVALID;
     const int64_t nb = (n_max + ZRK_BLOCK - 1) / ZRK_BLOCK + 1;
-    return (64 + 2 * (int64_t)ZRK_MAX_RADARS * nb) * (int64_t)sizeof(int32_t);
+    return (64 + 2 * (int64_t)(ZRK_MAX_RADARS + 1) * nb) * (int64_t)sizeof(int32_t);
 }
 
 ZRK_API int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_t time_ms,
@@ -623,20 +642,24 @@ ZRK_API int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int c
 }
 
 ZRK_API int zrk_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int32_t base_index,
-                        void *workspace, int32_t *det_idx, int64_t det_capacity, int32_t *det_off, void *stream)
+                        void *workspace, int32_t *det_idx, int64_t det_capacity, int32_t *det_off, int64_t *packed,
+                        int64_t packed_capacity, int64_t gid0, void *stream)
 {
-    if (!ctx || !vis_mask || !workspace || !det_idx || !det_off) return fail(ctx, ZRK_E_INVALID, "zrk_compact: null argument");
-    if (R < 0 || R > ZRK_MAX_RADARS || n < 0 || det_capacity < 0) return fail(ctx, ZRK_E_INVALID, "zrk_compact: size out of range");
+    if (!ctx || !vis_mask || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_compact: null argument");
+    if ((det_idx && !det_off) || (!det_idx && !packed)) return fail(ctx, ZRK_E_INVALID, "zrk_compact: no output requested");
+    if (R < 0 || R > ZRK_MAX_RADARS || n < 0 || det_capacity < 0 || (packed && packed_capacity < 1))
+        return fail(ctx, ZRK_E_INVALID, "zrk_compact: size out of range");
     hipStream_t s = (hipStream_t)stream;
-    if (n == 0 || R == 0) {
-        if (hipMemsetAsync(det_off, 0, sizeof(int32_t) * (R + 1), s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "memset det_off");
+    if (n == 0) {
+        if (det_idx && hipMemsetAsync(det_off, 0, sizeof(int32_t) * (R + 1), s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "memset det_off");
+        if (packed && hipMemsetAsync(packed, 0, sizeof(int64_t), s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "memset packed");
         return 0;
     }
     const int nb = nblocks(n, ZRK_BLOCK);
     Workspace w = carve(workspace, nb);
-    hipLaunchKernelGGL(k_scan_counts, dim3(R), dim3(kScanThreads), 0, s, w.counts, w.offs, w.totals, nb);
+    hipLaunchKernelGGL(k_scan_counts, dim3(R + 1), dim3(kScanThreads), 0, s, w.counts, w.offs, w.totals, nb);
     hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(ZRK_BLOCK), 0, s, vis_mask, n, R, nb, w.offs, w.totals, base_index,
-                       det_idx, det_capacity, det_off);
+                       det_idx, det_capacity, det_off, packed, packed_capacity, gid0);
     return check_launch(ctx, "zrk_compact");
 }
 
@@ -715,4 +738,92 @@ ZRK_API int zrk_selftest_noise(zrk_ctx *ctx, uint64_t seed, uint64_t tick, uint3
     hipLaunchKernelGGL(k_selftest_noise, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, seed, tick, radar,
                        entity0, out, n);
     return check_launch(ctx, "k_selftest_noise");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host loop: K ticks of the L1 path without returning to the caller (the headless counterpart of
+// Manager.run_simulation's per-tick module calls, reference modules/Manager.py:111-140).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// CPython / numpy float floor-mod (modules/Radar.py:103, :109, :114, :117).
+double floormod_host(double a, double b)
+{
+    double m = std::fmod(a, b);
+    if (m != 0.0) {
+        if ((b < 0.0) != (m < 0.0)) m += b;
+    } else {
+        m = std::copysign(0.0, b);
+    }
+    return m;
+}
+
+}  // namespace
+
+ZRK_API int zrk_scan_advance(zrk_radar *radars, const zrk_scan *scan, int R)
+{
+    if (R < 0 || (R > 0 && (!radars || !scan))) return ZRK_E_INVALID;
+    for (int r = 0; r < R; ++r) {
+        zrk_radar &rd = radars[r];
+        const zrk_scan &sc = scan[r];
+        if (sc.mode == 0) {            // "horizontal"
+            if (rd.cur_azimuth + rd.azimuth_range < 360.0) rd.cur_azimuth = floormod_host(rd.cur_azimuth + sc.azimuth_speed, 360.0);
+            else rd.cur_azimuth = sc.elevation_start;           // sic, modules/Radar.py:105
+            if (rd.cur_azimuth < sc.azimuth_speed) {
+                if (rd.cur_elevation + sc.elevation_speed < 90.0) rd.cur_elevation = floormod_host(rd.cur_elevation + sc.elevation_speed, 90.0);
+                else rd.cur_elevation = sc.elevation_start;
+            }
+        } else if (sc.mode == 1) {     // "vertical"
+            rd.cur_elevation = floormod_host(rd.cur_elevation + sc.elevation_speed, 90.0);
+            if (rd.cur_elevation < sc.elevation_speed) rd.cur_azimuth = floormod_host(rd.cur_azimuth + sc.azimuth_speed, 360.0);
+        }                               // any other mode string: the reference does nothing
+    }
+    return 0;
+}
+
+ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int64_t m, zrk_loop *st,
+                          zrk_radar *radars, const zrk_scan *scan, int R, void *workspace, int32_t *det_idx,
+                          int64_t det_capacity, int32_t *det_off, int64_t *packed, int64_t packed_capacity, int K,
+                          float *sweep_ms, int prof_stride, void *stream)
+{
+    if (!ctx || !e || !st || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: null argument");
+    if (m > 0 && !mis) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: missiles without a table");
+    if (K < 0 || (st->cur != 0 && st->cur != 1)) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: K/cur out of range");
+    hipStream_t s = (hipStream_t)stream;
+    const int stride = prof_stride > 0 ? prof_stride : 1;
+    const int n_prof = sweep_ms ? (K + stride - 1) / stride : 0;
+    hipEvent_t *ev = nullptr;
+    if (n_prof) {
+        ev = new hipEvent_t[2 * n_prof];
+        for (int k = 0; k < 2 * n_prof; ++k)
+            if (hipEventCreate(&ev[k]) != hipSuccess) { delete[] ev; return fail(ctx, ZRK_E_HIP, "hipEventCreate"); }
+    }
+    int rc = 0;
+    for (int k = 0; k < K && rc == 0; ++k) {
+        if (m > 0) rc = zrk_apply_events(ctx, e, st->cur, mis, stream);      // AirEnv.py:33-40, last tick's detonations
+        st->cur ^= 1;
+        if (rc == 0 && m > 0) rc = zrk_missile_step(ctx, e, st->cur, mis, m, st->time_ms, st->dt_ms, stream);
+        const bool prof = sweep_ms && (k % stride == 0);
+        if (prof) (void)hipEventRecord(ev[2 * (k / stride)], s);
+        if (rc == 0) rc = zrk_tick_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, 0, st->flags | ZRK_F_ADVANCE,
+                                         st->seed, st->tick, st->gid0, workspace, stream);
+        if (prof) (void)hipEventRecord(ev[2 * (k / stride) + 1], s);
+        if (rc == 0 && (det_idx || packed))
+            rc = zrk_compact(ctx, e->vis_mask, st->n, R, st->base_index, workspace, det_idx, det_capacity, det_off, packed,
+                             packed_capacity, st->gid0, stream);
+        zrk_scan_advance(radars, scan, R);                                   // Radar.py:205
+        st->time_ms += st->dt_ms;                                            // Manager.py:140
+        st->tick += 1;
+    }
+    if (n_prof) {
+        if (hipStreamSynchronize(s) != hipSuccess && rc == 0) rc = fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
+        for (int k = 0; k < n_prof; ++k) {
+            float ms = 0.f;
+            if (rc == 0 && hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]) != hipSuccess) ms = -1.f;
+            sweep_ms[k] = ms;
+        }
+        for (int k = 0; k < 2 * n_prof; ++k) (void)hipEventDestroy(ev[k]);
+        delete[] ev;
+    }
+    return rc;
 }

@@ -142,3 +142,131 @@ class DeviceSim:
 
     def end_tick(self):
         self.time_ms += self.dt_ms
+
+
+class HotPathEngine:
+    """Headless L1 loop for large scenes: the whole tick stays on the device (events, tombstones,
+    compaction) and `run(K)` enqueues K ticks through one C call (zrk_run_ticks).
+
+    noise: "philox" = counter-based measurement noise inside the sweep (throughput mode; same
+    distribution as the reference's np.random.normal(0, 5, 3), not the same stream), "off" = none.
+    """
+
+    def __init__(self, device=None, dt_ms=10, seed=0, noise="philox", gid0=0):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib = C, _lib
+        self.store = None
+        self.device = device
+        self.dt_ms = int(dt_ms)
+        self.seed = int(seed)
+        self.noise = noise
+        self.gid0 = int(gid0)
+        self.loop = None
+        self.R = 0
+
+    def load(self, ids, start_pos, velocity, start_time, radars, missile_capacity=0, det_capacity=None,
+             union_capacity=None):
+        """ids/start_pos/velocity/start_time: target columns; radars: list of dicts with the
+        SectorRadar constructor fields (reference modules/Radar.py:13-42)."""
+        C, _lib = self._C, self._lib
+        n = len(ids)
+        st = self.store = EntityStore(self.device, n + missile_capacity, max(missile_capacity, 64))
+        st.add_entities(ids, start_pos, velocity, start_time, kind=0)
+        st.flush()
+        self.R = R = len(radars)
+        self.c_radars = (_lib.ZrkRadar * max(R, 1))()
+        self.c_scan = (_lib.ZrkScan * max(R, 1))()
+        for k, rd in enumerate(radars):
+            cr, cs = self.c_radars[k], self.c_scan[k]
+            cr.pos[0], cr.pos[1], cr.pos[2] = (float(v) for v in rd["position"])
+            cr.max_distance = float(rd["max_distance"])
+            cr.cur_azimuth, cr.azimuth_range = float(rd["azimuth_start"]), float(rd["azimuth_range"])
+            cr.cur_elevation, cr.elevation_range = float(rd["elevation_start"]), float(rd["elevation_range"])
+            cs.azimuth_speed, cs.elevation_speed = float(rd["azimuth_speed"]), float(rd["elevation_speed"])
+            cs.elevation_start = float(rd["elevation_start"])
+            cs.mode = scan_mode_code(rd.get("scan_mode", "horizontal"))
+        self.loop = _lib.ZrkLoop()
+        self.loop.n = st.n_uploaded
+        self.loop.time_ms, self.loop.dt_ms = 0, self.dt_ms
+        self.loop.gid0, self.loop.seed, self.loop.tick = self.gid0, self.seed, 0
+        self.loop.cur, self.loop.base_index = st.cur, 0
+        self.loop.flags = F_PHILOX if self.noise == "philox" else 0
+        self.det_capacity = det_capacity
+        self.det_idx = None
+        self.det_off = torch.zeros(_lib.ZRK_MAX_RADARS + 1, dtype=torch.int32, device=st.device)
+        self.packed = None
+        if union_capacity:
+            self.packed = torch.zeros(int(union_capacity) + 1, dtype=torch.int64, device=st.device)
+        return self
+
+    def enable_lists(self, det_capacity=None):
+        st = self.store
+        cap = det_capacity or self.det_capacity or st.cap * max(self.R, 1)
+        self.det_idx = torch.zeros(int(cap), dtype=torch.int32, device=st.device)
+        return self
+
+    def launch_missiles(self, target_slots, launcher_pos=(0.0, 0.0, 0.0), speed=1000.0, radius=150.0, period=60.0,
+                        id0=10_000_000):
+        """Batched Missile._launch at the current time against the given target slots; the ones whose
+        solve succeeds enter the table as active missiles (in request order).  Returns their count."""
+        C, _lib = self._C, self._lib
+        st = self.store
+        k = len(target_slots)
+        if k == 0:
+            return 0
+        req = np.zeros(k, dtype=np.dtype([("target_slot", "<i4"), ("_pad", "<i4"), ("missile_pos", "<f8", 3),
+                                          ("speed", "<f8"), ("period", "<f8")]))
+        req["target_slot"] = np.asarray(target_slots, np.int32)
+        req["missile_pos"] = np.asarray(launcher_pos, np.float64)
+        req["speed"], req["period"] = speed, period
+        d_req = torch.from_numpy(req.view(np.uint8).reshape(-1)).to(st.device)
+        d_res = torch.zeros(k * C.sizeof(_lib.ZrkLaunchRes), dtype=torch.uint8, device=st.device)
+        st.ctx.check(st.lib.zrk_launch_solve(st.ctx.handle, C.byref(st.ents), st.cur, d_req.data_ptr(),
+                                             d_res.data_ptr(), k, st._stream()), "zrk_launch_solve")
+        res = d_res.cpu().numpy().view(np.dtype([("rc", "<i4"), ("_pad", "<i4"), ("velocity", "<f8", 3),
+                                                 ("t_hit", "<f8")]))
+        ok = np.nonzero(res["rc"] == 0)[0]
+        if len(ok) == 0:
+            return 0
+        t0 = self.loop.time_ms / 1000
+        first = st.add_entities(id0 + ok, np.broadcast_to(np.asarray(launcher_pos, np.float64), (len(ok), 3)),
+                                res["velocity"][ok], t0, kind=1)
+        st.flush()
+        st.add_missile_rows(np.arange(first, first + len(ok), dtype=np.int32),
+                            np.asarray(target_slots, np.int32)[ok], radius, period)
+        self.loop.n = st.n_uploaded
+        self.launch_results = res
+        return len(ok)
+
+    def run(self, K, sweep_ms=None, prof_stride=1):
+        """Enqueue K ticks.  With `sweep_ms` (a float32 numpy array of ceil(K/prof_stride)) the call
+        also times the sweep kernel with HIP events and synchronises the stream."""
+        C = self._C
+        st = self.store
+        self.loop.cur = st.cur
+        ms_ptr = sweep_ms.ctypes.data_as(C.POINTER(C.c_float)) if sweep_ms is not None else None
+        st.ctx.check(st.lib.zrk_run_ticks(
+            st.ctx.handle, C.byref(st.ents), C.byref(st.mis), st.m, C.byref(self.loop), self.c_radars, self.c_scan,
+            self.R, st.workspace().data_ptr(),
+            self.det_idx.data_ptr() if self.det_idx is not None else None,
+            self.det_idx.numel() if self.det_idx is not None else 0, self.det_off.data_ptr(),
+            self.packed.data_ptr() if self.packed is not None else None,
+            self.packed.numel() if self.packed is not None else 0, int(K), ms_ptr, int(prof_stride), st._stream()),
+            "zrk_run_ticks")
+        st.cur = int(self.loop.cur)
+        st.time_ms = int(self.loop.time_ms) - self.dt_ms
+        st.n_stepped = st.n_uploaded
+        st._bump()
+
+    # results (each synchronises) ---------------------------------------------------------------
+    def alive_count(self):
+        return int(self.store.d_alive[:self.store.n_uploaded].sum().item())
+
+    def detections(self):
+        off = self.det_off[:self.R + 1].cpu().numpy()
+        idx = self.det_idx[:off[-1]].cpu().numpy()
+        return [idx[off[r]:off[r + 1]] for r in range(self.R)]
+
+    def radar_state(self):
+        return [(self.c_radars[r].cur_azimuth, self.c_radars[r].cur_elevation) for r in range(self.R)]

@@ -1,0 +1,38 @@
+"""Synthetic scenarios of the benchmark configurations as plain arrays.
+
+Seeded with numpy.random.Generator(PCG64(seed)); nothing here computes on the hot path."""
+from __future__ import annotations
+
+import numpy as np
+
+WORKLOADS = {
+    # name: (targets, radars, missiles)       BASELINE.json configs[1], configs[2]
+    "C2": (100_000, 4, 1_000),
+    "C3": (1_000_000, 16, 10_000),
+    "tiny": (4_096, 4, 64),
+}
+SEEDS = {"C2": 1236, "C3": 1237, "tiny": 1234}
+
+
+def synthetic_targets(n, seed, first_id=1000):
+    g = np.random.Generator(np.random.PCG64(seed))
+    sp = np.empty((n, 3))
+    sp[:, 0] = g.uniform(-60e3, 60e3, n)
+    sp[:, 1] = g.uniform(-60e3, 60e3, n)
+    sp[:, 2] = g.uniform(100.0, 12e3, n)
+    vel = g.normal(0.0, 150.0, (n, 3))
+    ids = first_id + np.arange(n, dtype=np.int64)
+    return ids, sp, vel, np.zeros(n)
+
+
+def synthetic_radars(R):
+    return [dict(id=10_000 + r, position=[1000.0 * r, 0.0, 0.0], max_distance=50e3, azimuth_start=0.0,
+                 elevation_start=0.0, azimuth_range=90.0, elevation_range=45.0, azimuth_speed=10.0,
+                 elevation_speed=0.0, scan_mode="horizontal") for r in range(R)]
+
+
+def missile_targets(n, m):
+    """Missile k is launched against target k * floor(n / m)."""
+    if m <= 0:
+        return np.zeros(0, np.int32)
+    return (np.arange(m, dtype=np.int64) * (n // m)).astype(np.int32)

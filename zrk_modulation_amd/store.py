@@ -169,7 +169,7 @@ class EntityStore:
         self.h_sp = np.concatenate([self.h_sp, sp]); self.h_vel = np.concatenate([self.h_vel, vel])
         self.h_t0 = np.concatenate([self.h_t0, t0]); self.h_pos0 = np.concatenate([self.h_pos0, p0])
         self.h_alive = np.concatenate([self.h_alive, np.ones(k, np.uint8)])
-        if k <= 4096:
+        if self.slots_of_id is not None and k <= 4096:
             for j in range(k):
                 self.slots_of_id.setdefault(int(ids[j]), []).append(first + j)
         else:
@@ -299,7 +299,7 @@ class EntityStore:
         det = self.det_buffer(capn)
         self.ctx.check(self.lib.zrk_compact(self.ctx.handle, self.d_vis.data_ptr(), n, R, base_index,
                                             self.workspace().data_ptr(), det.data_ptr(), det.numel(),
-                                            self._det_off.data_ptr(), self._stream()), "zrk_compact")
+                                            self._det_off.data_ptr(), None, 0, 0, self._stream()), "zrk_compact")
         return det, self._det_off
 
     def noise_apply(self, det_idx, k, noise, idx_base=0):
