@@ -113,12 +113,13 @@ int64_t zrk_workspace_bytes(int64_t n_max);
  *             SectorRadar.smooth_objects (ZRK_F_PHILOX only)  modules/Radar.py:138-142
  * For each live slot i < n: (ZRK_F_ADVANCE) pos[cur][i] = start_pos + velocity*(t - start_time)
  * with t = time_ms/1000; then radars 0..R-1 in order test the current position and, with
- * ZRK_F_PHILOX, perturb it by N(0, 5^2) per axis keyed (seed, tick, radar_base + r, gid0 + i)
- * before the next radar looks.  vis_mask[i] gets bit r per detecting radar (0 for dead slots).
+ * ZRK_F_PHILOX, every detection perturbs it by N(0, 5^2) per axis (a stream keyed by
+ * (seed, tick, gid0 + i)) before the next radar looks.  vis_mask[i] gets bit r per detecting
+ * radar (0 for dead slots).
  * Also leaves per-block detection counts in `workspace` for zrk_compact.
  */
 int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *ents, int64_t n, int cur, int64_t time_ms,
-                   const zrk_radar *radars /* HOST */, int R, int radar_base, uint32_t flags,
+                   const zrk_radar *radars /* HOST */, int R, uint32_t flags,
                    uint64_t seed, uint64_t tick, int64_t gid0, void *workspace, void *stream);
 
 /*
@@ -152,18 +153,20 @@ int zrk_noise_apply(zrk_ctx *ctx, double *pos /* DEVICE [3][cap] */, int64_t cap
  * `cur` is the buffer this tick's zrk_tick_sweep(ZRK_F_ADVANCE) writes; the kernel reads
  * pos[cur^1] (last tick's final positions) for targets that have not been stepped yet or
  * are no longer live, and recomputes from trajectories otherwise, so it may run before,
- * after or beside the sweep of the same tick.
+ * after or beside the sweep of the same tick.  With apply_kills != 0 the detonated missiles and
+ * their targets are tombstoned at the end of the call (positions frozen from pos[cur], so the
+ * sweep of this tick must already be enqueued): AirEnv.step()'s removal (modules/AirEnv.py:33-40)
+ * without a host round trip.  With apply_kills == 0 the caller removes them (zrk_kill_slots).
  */
 int zrk_missile_step(zrk_ctx *ctx, const zrk_entities *ents, int cur, const zrk_missiles *mis,
-                     int64_t m, int64_t time_ms, int64_t dt_ms, void *stream);
+                     int64_t m, int64_t time_ms, int64_t dt_ms, int apply_kills, void *stream);
 
 /* AirEnv.step()'s tombstoning (modules/AirEnv.py:33-40) for k slots: alive = 0 and the final
  * position (in pos[src]) frozen into both buffers so later readers see it. */
 int zrk_kill_slots(zrk_ctx *ctx, const zrk_entities *ents, int src, const int32_t *slots /* DEVICE */,
                    int64_t k, void *stream);
 
-/* Same, taking last tick's event rows straight from the missile table on the device
- * (no host round trip), then clearing ev_count. */
+/* Same, taking the event rows straight from the missile table on the device. */
 int zrk_apply_events(zrk_ctx *ctx, const zrk_entities *ents, int src, const zrk_missiles *mis,
                      void *stream);
 
@@ -198,8 +201,8 @@ typedef struct {
 
 /*
  * K ticks of the L1 path, enqueued back to back on `stream` without returning to the caller:
- * per tick  zrk_apply_events (last tick's detonations) -> flip buffer -> zrk_missile_step ->
- * zrk_tick_sweep(ADVANCE) -> zrk_compact -> zrk_scan_advance -> time += dt.
+ * per tick  flip buffer -> zrk_tick_sweep(ADVANCE) -> zrk_compact -> zrk_missile_step(apply_kills)
+ * -> zrk_scan_advance -> time += dt.
  *   replaces the per-tick `module.step()` calls of Manager.run_simulation for AirEnv and every
  *   SectorRadar (modules/Manager.py:123-131, :140).
  * Detection outputs hold the last tick's lists.  If sweep_ms != NULL the sweep kernel of every
@@ -216,8 +219,9 @@ int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *ents, const zrk_missiles *mi
  * op: 0 sqrt(a), 1 a/b, 2 atan2(a,b), 3 asin(a), 4 fma-chain norm of (a,b,0). */
 int zrk_selftest_math(zrk_ctx *ctx, int op, const double *a, const double *b, double *y /* DEVICE */,
                       int64_t n, void *stream);
-/* out[i*3..] = the Philox noise triple of (seed, tick, radar, entity0 + i). */
-int zrk_selftest_noise(zrk_ctx *ctx, uint64_t seed, uint64_t tick, uint32_t radar, int64_t entity0,
+/* out[i*3..] = the noise triple the `ordinal`-th detection (0-based) of entity entity0 + i draws
+ * in tick `tick` under ZRK_F_PHILOX. */
+int zrk_selftest_noise(zrk_ctx *ctx, uint64_t seed, uint64_t tick, uint32_t ordinal, int64_t entity0,
                        double *out /* DEVICE [n][3] */, int64_t n, void *stream);
 
 #ifdef __cplusplus

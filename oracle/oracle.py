@@ -68,10 +68,8 @@ def lib():
     L.zo_scan_next.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp]
     L.zo_launch_solve.restype = C.c_int
     L.zo_launch_solve.argtypes = [dp, dp, dp, C.c_double, C.c_double, C.c_double, dp, dp]
-    L.zo_philox_raw.restype = None
-    L.zo_philox_raw.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, u32p]
     L.zo_philox_noise.restype = None
-    L.zo_philox_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_double, dp]
+    L.zo_philox_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, dp]
     L.zo_radar_phase_fused.restype = None
     L.zo_radar_phase_fused.argtypes = [i64, i64, dp, u8p, C.c_int, C.POINTER(ZoRadar), C.c_int, dp,
                                        C.c_uint64, C.c_uint64, i64, u32p, C.c_int]
@@ -137,9 +135,10 @@ def launch_solve(tp, mp, tvu, tsm, v0, period):
     return rc, V, t.value
 
 
-def philox_noise(seed, tick, radar, entity, sigma=5.0):
+def philox_noise(seed, tick, ordinal, entity):
+    """Noise triple of the `ordinal`-th detection of `entity` in `tick` (throughput mode)."""
     out = np.zeros(3)
-    lib().zo_philox_noise(seed, tick, radar, entity, sigma, dptr(out))
+    lib().zo_philox_noise(seed, tick, ordinal, entity, dptr(out))
     return out
 
 

@@ -238,9 +238,9 @@ ZO_API int zo_launch_solve(const double tp[3], const double mp[3], const double 
 /* ------------------------------------------------------------------------- *
  * Counter-based noise of the throughput mode (no counterpart in the reference,
  * which draws from numpy's global MT19937 stream).
- * Philox4x32-10 (Salmon et al., SC'11) keyed by seed, counter (entity, tick, radar),
- * then two Box-Muller pairs in binary32.  The device computes the same integers;
- * its log/sin/cos are hardware approximations, so values agree to ~1e-6 absolute,
+ * Philox4x32-10 (Salmon et al., SC'11) keyed by seed, counter (entity, tick), seeds a
+ * xoshiro128++ stream per entity and tick.  The device computes the same integers;
+ * its log/sin/cos are hardware approximations, so values agree to ~1e-5 absolute,
  * not bitwise (tests feed the device's own values back through noise tables).
  * ------------------------------------------------------------------------- */
 static inline void zo_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -259,37 +259,59 @@ static inline void zo_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint3
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-ZO_API void zo_philox_raw(uint64_t seed, uint64_t tick, uint32_t radar, uint64_t entity, uint32_t out[4])
+/* Noise stream of one (entity, tick): Philox block -> xoshiro128++ state; each detection draws two
+ * words = four 16-bit uniforms = two Box-Muller pairs in binary32, three values used. */
+typedef struct { uint32_t s[4]; } zo_noise_state;
+
+static inline zo_noise_state zo_noise_init(uint64_t seed, uint64_t tick, uint64_t entity)
 {
-    /* counter = (entity lo, entity hi, tick mod 2^32, radar); key = seed */
-    zo_philox4x32_10((uint32_t)entity, (uint32_t)(entity >> 32), (uint32_t)tick, radar,
-                     (uint32_t)seed, (uint32_t)(seed >> 32), out);
+    zo_noise_state st;
+    zo_philox4x32_10((uint32_t)entity, (uint32_t)(entity >> 32), (uint32_t)tick, (uint32_t)(tick >> 32),
+                     (uint32_t)seed, (uint32_t)(seed >> 32), st.s);
+    return st;
 }
 
-ZO_API void zo_philox_noise(uint64_t seed, uint64_t tick, uint32_t radar, uint64_t entity,
-                            double sigma, double out[3])
+static inline uint32_t zo_rotl(uint32_t v, int k) { return (v << k) | (v >> (32 - k)); }
+
+static inline uint32_t zo_noise_next(zo_noise_state *st)     /* xoshiro128++ */
 {
-    uint32_t x[4];
-    zo_philox_raw(seed, tick, radar, entity, x);
-    /* uniforms in (0,1): 24 high bits, centred */
-    float u0 = ((float)(x[0] >> 8) + 0.5f) * 5.9604644775390625e-8f;
-    float u1 = (float)(x[1] >> 8) * 5.9604644775390625e-8f;      /* [0,1): angle in revolutions */
-    float u2 = ((float)(x[2] >> 8) + 0.5f) * 5.9604644775390625e-8f;
-    float u3 = (float)(x[3] >> 8) * 5.9604644775390625e-8f;
-    float r0 = sqrtf(-1.3862943611198906f * log2f(u0));           /* sqrt(-2 ln u) */
-    float r1 = sqrtf(-1.3862943611198906f * log2f(u2));
+    uint32_t *s = st->s;
+    uint32_t result = zo_rotl(s[0] + s[3], 7) + s[0];
+    uint32_t t = s[1] << 9;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = zo_rotl(s[3], 11);
+    return result;
+}
+
+static inline void zo_noise_draw3(zo_noise_state *st, float sigma, double out[3])
+{
+    uint32_t a = zo_noise_next(st), b = zo_noise_next(st);
+    const float k16 = 1.52587890625e-5f;
+    float u0 = ((float)(a >> 16) + 0.5f) * k16, u1 = (float)(a & 0xFFFFu) * k16;
+    float u2 = ((float)(b >> 16) + 0.5f) * k16, u3 = (float)(b & 0xFFFFu) * k16;
+    float r0 = sigma * sqrtf(-1.3862943611198906f * log2f(u0));
+    float r1 = sigma * sqrtf(-1.3862943611198906f * log2f(u2));
     const float two_pi = 6.283185307179586f;
-    out[0] = sigma * (double)(r0 * cosf(two_pi * u1));
-    out[1] = sigma * (double)(r0 * sinf(two_pi * u1));
-    out[2] = sigma * (double)(r1 * cosf(two_pi * u3));
+    out[0] = (double)(r0 * cosf(two_pi * u1));
+    out[1] = (double)(r0 * sinf(two_pi * u1));
+    out[2] = (double)(r1 * cosf(two_pi * u3));
+}
+
+/* The triple the `ordinal`-th detection (0-based) of `entity` draws in `tick`. */
+ZO_API void zo_philox_noise(uint64_t seed, uint64_t tick, uint32_t ordinal, uint64_t entity, double out[3])
+{
+    zo_noise_state st = zo_noise_init(seed, tick, entity);
+    out[0] = out[1] = out[2] = 0.0;
+    for (uint32_t k = 0; k <= ordinal; ++k) zo_noise_draw3(&st, 5.0f, out);
 }
 
 /*
  * Full L1 radar phase of one tick, entity-major ("fused") form, for noise modes in
  * which entities are independent (hard part 3):
  *   mode 0  no noise
- *   mode 1  Philox noise (zo_philox_noise), sigma = 5
- *   mode 2  noise table: table[(r*n + i)*3 + c], values supplied by the caller
+ *   mode 1  counter-based noise (zo_noise_*), sigma = 5
+ *   mode 2  noise table: table[(k*n + i)*3 + c] = what the k-th detection of slot i adds
  * Per live entity, radars in order: zo_visible on the current (already perturbed)
  * position, then pos += noise (modules/Radar.py:163-164 applied radar after radar).
  * vis_mask bit r = seen by radar r.  gid0 = global index of slot 0 (multi-GPU shards).
@@ -308,17 +330,21 @@ ZO_API void zo_radar_phase_fused(int64_t n, int64_t cap, double *pos, const uint
         if (!alive[i]) { vis_mask[i] = 0; continue; }
         double x = pos[i], y = pos[cap + i], z = pos[2 * cap + i];
         uint32_t m = 0;
+        int ordinal = 0;
+        zo_noise_state ns;
+        if (mode == 1) ns = zo_noise_init(seed, tick, (uint64_t)(gid0 + i));
         for (int r = 0; r < R; ++r) {
             if (!zo_visible(&radars[r], x, y, z)) continue;
             m |= 1u << r;
             if (mode == 1) {
                 double nz[3];
-                zo_philox_noise(seed, tick, (uint32_t)r, (uint64_t)(gid0 + i), 5.0, nz);
+                zo_noise_draw3(&ns, 5.0f, nz);
                 x += nz[0]; y += nz[1]; z += nz[2];
             } else if (mode == 2) {
-                const double *nz = table + ((int64_t)r * n + i) * 3;
+                const double *nz = table + ((int64_t)ordinal * n + i) * 3;
                 x += nz[0]; y += nz[1]; z += nz[2];
             }
+            ++ordinal;
         }
         pos[i] = x; pos[cap + i] = y; pos[2 * cap + i] = z;
         vis_mask[i] = m;

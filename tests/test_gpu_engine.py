@@ -86,7 +86,8 @@ class OracleMirror:
 
 
 def _device_noise_table(eng, tick, R, n):
-    """The Philox triples the device will use this tick, dumped by the device itself."""
+    """The noise triples the device will draw this tick (k-th detection of each slot), dumped by the
+    device itself."""
     import torch
     st = eng.store
     tab = torch.zeros(R, n, 3, dtype=torch.float64, device=st.device)

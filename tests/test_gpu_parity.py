@@ -95,14 +95,33 @@ def test_device_angles_within_2ulp(op, name, fn):
 
 
 def test_philox_noise_matches_oracle_stream():
-    """Same Philox integers on both sides; the float32 Box-Muller differs only by the hardware
-    log2/sin/cos approximations."""
+    """Same Philox / xoshiro integers on both sides; the float32 Box-Muller differs only by the
+    hardware log2/sin/cos approximations."""
     from oracle import oracle as O
     ctx, torch = _ctx_and_buffers(0)
     n = 4096
-    out = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
-    ctx.check(ctx.lib.zrk_selftest_noise(ctx.handle, 1234, 77, 3, 1000, out.data_ptr(), n, None), "noise")
-    got = out.cpu().numpy()
-    want = np.array([O.philox_noise(1234, 77, 3, 1000 + i) for i in range(n)])
-    assert np.abs(got - want).max() < 5e-4
-    assert abs(got.std() - 5.0) < 0.15 and abs(got.mean()) < 0.15
+    for ordinal in (0, 3):
+        out = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+        ctx.check(ctx.lib.zrk_selftest_noise(ctx.handle, 1234, 77, ordinal, 1000, out.data_ptr(), n, None), "noise")
+        got = out.cpu().numpy()
+        want = np.array([O.philox_noise(1234, 77, ordinal, 1000 + i) for i in range(n)])
+        assert np.abs(got - want).max() < 5e-4
+        assert abs(got.std() - 5.0) < 0.15 and abs(got.mean()) < 0.15
+
+
+def test_throughput_noise_is_gaussian():
+    """Distribution of the device noise: N(0, 5^2) per axis, axes and detections uncorrelated
+    (what the reference's np.random.normal(0, 5, 3) provides, modules/Radar.py:138-142)."""
+    from scipy import stats
+    ctx, torch = _ctx_and_buffers(0)
+    n = 1 << 18
+    outs = []
+    for ordinal in (0, 1):
+        out = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+        ctx.check(ctx.lib.zrk_selftest_noise(ctx.handle, 99, 5, ordinal, 0, out.data_ptr(), n, None), "noise")
+        outs.append(out.cpu().numpy())
+    z = np.concatenate(outs, axis=1)                       # [n, 6]
+    for c in range(6):
+        assert stats.kstest(z[:, c] / 5.0, "norm").pvalue > 1e-4
+    corr = np.corrcoef(z.T)
+    assert np.abs(corr - np.eye(6)).max() < 0.01

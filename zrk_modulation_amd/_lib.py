@@ -115,7 +115,7 @@ _PROTOTYPES = {
     "zrk_last_error": (C.c_char_p, [C.c_void_p]),
     "zrk_workspace_bytes": (C.c_int64, [C.c_int64]),
     "zrk_tick_sweep": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.c_int64, C.c_int, C.c_int64,
-                                 C.POINTER(ZrkRadar), C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64,
+                                 C.POINTER(ZrkRadar), C.c_int, C.c_uint32, C.c_uint64, C.c_uint64,
                                  C.c_int64, C.c_void_p, C.c_void_p]),
     "zrk_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int32, C.c_void_p, C.c_void_p,
                               C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
@@ -127,7 +127,7 @@ _PROTOTYPES = {
     "zrk_noise_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p,
                                   C.c_int64, C.c_void_p]),
     "zrk_missile_step": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.c_int, C.POINTER(ZrkMissiles),
-                                   C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+                                   C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "zrk_kill_slots": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.c_int, C.c_void_p, C.c_int64,
                                  C.c_void_p]),
     "zrk_apply_events": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.c_int, C.POINTER(ZrkMissiles),

@@ -27,22 +27,36 @@ namespace {
 constexpr double kRad2Deg = 180.0 / 3.14159265358979323846;   // numpy.degrees factor
 constexpr float kGuard = 3e-5f;                               // relative half-width of the "ambiguous" band
 
-// Device-side radar record: the exact binary64 gate of modules/Radar.py:56-70 plus a float32
-// pre-classification that settles every pair farther than kGuard (relative) from an edge.
-struct RadarDev {
+// Device-side radar records.  Hot: what every (radar, entity) pair touches -- the float32
+// pre-classification that settles every pair farther than kGuard (relative) from a sector edge or
+// the range sphere; 20 dwords, fetched with one scalar load burst per radar.  Cold: the exact
+// binary64 gate of modules/Radar.py:56-70, read only by the rare pairs inside a guard band.
+struct RadarHot {
     double px, py, pz;
-    double d2_max;              // largest d2 with sqrt(d2) <= max_distance  (== `dist > max` gate)
-    double az_lo, az_hi;        // current_azimuth, current_azimuth + azimuth_range
-    double el_lo, el_hi;
+    float d2f_in, d2f_out;      // float32 d2 below / above which the range gate is already decided
     float elx, ely, ehx, ehy;   // unit vectors of the (clamped) azimuth edges
     float s_lo_up, s_hi_up;     // sin(elevation) bounds for dz >= 0
     float s_lo_dn, s_hi_dn;     // and for dz < 0 (elevation wraps to (90,180])
     float seam_g;               // kGuard when elevation 0 / 180 must be told apart, else -1
-    uint32_t az_mode;           // 0 never, 1 both edges (width <= 180), 2 either edge, 3 always exact
+    float az_sgn;               // +1: inside = both edge tests (width <= 180); -1: either (edges stored negated)
+    uint32_t pad[2];
+};
+static_assert(sizeof(RadarHot) == 80, "RadarHot must be 20 dwords");
+
+struct RadarCold {
+    double d2_max;              // largest d2 with sqrt(d2) <= max_distance  (== `dist > max` gate)
+    double az_lo, az_hi;        // current_azimuth, current_azimuth + azimuth_range
+    double el_lo, el_hi;
 };
 
-struct RadarBlock {
-    RadarDev r[ZRK_MAX_RADARS];
+struct RadarDev {               // host-side scratch while deriving
+    RadarHot h;
+    RadarCold c;
+};
+
+struct RadarBlock {                                 // lives in the kernel-argument segment (by value)
+    uint32_t hotw[ZRK_MAX_RADARS][20];              // RadarHot records as dwords (indexed, never addressed)
+    RadarCold cold[ZRK_MAX_RADARS];
 };
 
 struct SweepParams {
@@ -55,7 +69,7 @@ struct SweepParams {
     double t;
     uint64_t seed, tick;
     int64_t gid0;
-    int32_t R, radar_base, nb;
+    int32_t R, nb;
     uint32_t flags;
     RadarBlock rb;
 };
@@ -77,14 +91,15 @@ __device__ __forceinline__ double floormod_small(double a, double b)
     return m;
 }
 
-// modules/Radar.py:61-70 for a pair already inside the range gate.
-__device__ __noinline__ bool visible_exact(double az_lo, double az_hi, double el_lo, double el_hi,
-                                           double dx, double dy, double dz, double d2)
+// modules/Radar.py:56-70 in binary64: the decision every guard-band pair falls back to.
+__device__ __noinline__ bool visible_exact(const RadarCold c, double dx, double dy, double dz)
 {
-    double dist = sqrt(d2);
-    double az = floormod_small(atan2(dy, dx) * kRad2Deg, 360.0);
-    double el = floormod_small(asin(dz / dist) * kRad2Deg, 180.0);
-    return (az_lo <= az) && (az <= az_hi) && (el_lo <= el) && (el <= el_hi);
+    const double d2 = dot3(dx, dy, dz, dx, dy, dz);
+    if (d2 > c.d2_max) return false;                           // == `distance > max_distance`
+    const double dist = sqrt(d2);
+    const double az = floormod_small(atan2(dy, dx) * kRad2Deg, 360.0);
+    const double el = floormod_small(asin(dz / dist) * kRad2Deg, 180.0);
+    return (c.az_lo <= az) && (az <= c.az_hi) && (c.el_lo <= el) && (el <= c.el_hi);
 }
 
 // Philox4x32-10, counter (entity lo, entity hi, tick, radar), key = seed.
@@ -102,28 +117,55 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Three N(0, sigma^2) values in binary32 (Box-Muller on the hardware log2 / sin / cos), widened.
-__device__ __forceinline__ void philox_noise(uint64_t seed, uint64_t tick, uint32_t radar, uint64_t entity,
-                                             float sigma, double out[3])
+// Measurement-noise stream of the throughput mode.  One Philox4x32-10 block per (entity, tick)
+// seeds a xoshiro128++ state; every detection of that entity in that tick (radar after radar) draws
+// two words from it = four 16-bit uniforms = two Box-Muller pairs in binary32 on the hardware
+// log2 / sqrt / sin / cos (v_sin/v_cos take revolutions), of which three values are used.
+struct NoiseState {
+    uint32_t s0, s1, s2, s3;
+};
+
+__device__ __forceinline__ NoiseState noise_init(uint64_t seed, uint64_t tick, uint64_t entity)
 {
     uint32_t x[4];
-    philox4x32_10((uint32_t)entity, (uint32_t)(entity >> 32), (uint32_t)tick, radar, (uint32_t)seed,
+    philox4x32_10((uint32_t)entity, (uint32_t)(entity >> 32), (uint32_t)tick, (uint32_t)(tick >> 32), (uint32_t)seed,
                   (uint32_t)(seed >> 32), x);
-    const float k24 = 5.9604644775390625e-8f;
-    float u0 = ((float)(x[0] >> 8) + 0.5f) * k24;
-    float u1 = (float)(x[1] >> 8) * k24;
-    float u2 = ((float)(x[2] >> 8) + 0.5f) * k24;
-    float u3 = (float)(x[3] >> 8) * k24;
-    float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
-    float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
-    out[0] = (double)(sigma * (r0 * __builtin_amdgcn_cosf(u1)));      // v_cos/v_sin take revolutions
-    out[1] = (double)(sigma * (r0 * __builtin_amdgcn_sinf(u1)));
-    out[2] = (double)(sigma * (r1 * __builtin_amdgcn_cosf(u3)));
+    return NoiseState{x[0], x[1], x[2], x[3]};
+}
+
+__device__ __forceinline__ uint32_t rotl32(uint32_t v, int k) { return (v << k) | (v >> (32 - k)); }
+
+__device__ __forceinline__ uint32_t noise_next(NoiseState &st)       // xoshiro128++ (Blackman & Vigna)
+{
+    const uint32_t result = rotl32(st.s0 + st.s3, 7) + st.s0;
+    const uint32_t t = st.s1 << 9;
+    st.s2 ^= st.s0; st.s3 ^= st.s1; st.s1 ^= st.s2; st.s0 ^= st.s3;
+    st.s2 ^= t;
+    st.s3 = rotl32(st.s3, 11);
+    return result;
+}
+
+__device__ __forceinline__ void noise_draw3(NoiseState &st, float sigma, float out[3])
+{
+    const uint32_t a = noise_next(st), b = noise_next(st);
+    const float k16 = 1.52587890625e-5f;                              // 2^-16
+    const float u0 = ((float)(a >> 16) + 0.5f) * k16, u1 = (float)(a & 0xFFFFu) * k16;
+    const float u2 = ((float)(b >> 16) + 0.5f) * k16, u3 = (float)(b & 0xFFFFu) * k16;
+    const float r0 = sigma * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
+    const float r1 = sigma * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+    out[0] = r0 * __builtin_amdgcn_cosf(u1);
+    out[1] = r0 * __builtin_amdgcn_sinf(u1);
+    out[2] = r1 * __builtin_amdgcn_cosf(u3);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Fused advance + radar sweep.  One thread per entity slot, ZRK_BLOCK slots per workgroup.
 // ---------------------------------------------------------------------------------------------
+// The CU has ONE scalar unit for its four SIMDs, so the loop body keeps scalar work minimal: one
+// scalar-load burst per radar, no uniform branches (degenerate radars are encoded in the thresholds
+// by the host), predicates folded into two float minima, and only two divergent regions -- the
+// binary64 fallback for guard-band pairs and the noise draw for detections.
+template <bool PHILOX>
 __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P)
 {
     __shared__ int s_cnt[ZRK_MAX_RADARS + 1];
@@ -145,61 +187,78 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P)
         } else {
             x = P.pos[i]; y = P.pos[cap + i]; z = P.pos[2 * cap + i];
         }
-        const bool exact_only = (P.flags & ZRK_F_EXACT_ONLY) != 0;
+        NoiseState ns{0u, 0u, 0u, 0u};
+        if (PHILOX) ns = noise_init(P.seed, P.tick, (uint64_t)(P.gid0 + i));
         for (int r = 0; r < P.R; ++r) {
-            const RadarDev &rd = P.rb.r[r];
-            if (rd.az_mode == 0u) continue;
-            const double dx = x - rd.px, dy = y - rd.py, dz = z - rd.pz;
-            const double d2 = dot3(dx, dy, dz, dx, dy, dz);
-            if (d2 > rd.d2_max) continue;                    // == `distance > max_distance`
-            bool vis, amb;
-            {
-                const float fx = (float)dx, fy = (float)dy, fz = (float)dz;
-                const float rho2 = fx * fx + fy * fy;
-                const float d2f = rho2 + fz * fz;
-                const float cl = rd.elx * fy - rd.ely * fx;  // cross(e_lo, p)
-                const float ch = fx * rd.ehy - fy * rd.ehx;  // cross(p, e_hi)
-                const float g2r = (kGuard * kGuard) * rho2;
-                const bool az_amb = (cl * cl <= g2r) | (ch * ch <= g2r);
-                const bool az_in = (rd.az_mode == 1u) ? ((cl > 0.f) & (ch > 0.f)) : ((cl > 0.f) | (ch > 0.f));
-                const float dist = __builtin_amdgcn_sqrtf(d2f);
-                const float gd = kGuard * dist;
-                const bool up = fz >= 0.f;
-                const float s_lo = up ? rd.s_lo_up : rd.s_lo_dn;
-                const float s_hi = up ? rd.s_hi_up : rd.s_hi_dn;
-                const float a = fz - s_lo * dist, b = s_hi * dist - fz;
-                const bool el_amb = (fabsf(a) <= gd) | (fabsf(b) <= gd) | (fabsf(fz) <= rd.seam_g * dist);
-                const bool el_in = (a > 0.f) & (b > 0.f);
-                const bool finite = d2f < 1e30f;             // false for inf / NaN
-                amb = exact_only | az_amb | el_amb | !finite | (rd.az_mode == 3u);
-                vis = az_in & el_in;
-            }
-            if (amb) vis = visible_exact(rd.az_lo, rd.az_hi, rd.el_lo, rd.el_hi, dx, dy, dz, d2);
+            // one scalar-load burst for the whole hot record, resident in SGPRs before any use
+            uint32_t w[18];
+#pragma unroll
+            for (int k = 0; k < 18; ++k) w[k] = P.rb.hotw[r][k];
+            asm volatile("" ::"s"(w[0]), "s"(w[1]), "s"(w[2]), "s"(w[3]), "s"(w[4]), "s"(w[5]), "s"(w[6]), "s"(w[7]),
+                         "s"(w[8]), "s"(w[9]), "s"(w[10]), "s"(w[11]), "s"(w[12]), "s"(w[13]), "s"(w[14]), "s"(w[15]),
+                         "s"(w[16]), "s"(w[17]));
+            const double rpx = __builtin_bit_cast(double, ((uint64_t)w[1] << 32) | w[0]);
+            const double rpy = __builtin_bit_cast(double, ((uint64_t)w[3] << 32) | w[2]);
+            const double rpz = __builtin_bit_cast(double, ((uint64_t)w[5] << 32) | w[4]);
+            const float d2f_in = __builtin_bit_cast(float, w[6]), d2f_out = __builtin_bit_cast(float, w[7]);
+            const float elx = __builtin_bit_cast(float, w[8]), ely = __builtin_bit_cast(float, w[9]);
+            const float ehx = __builtin_bit_cast(float, w[10]), ehy = __builtin_bit_cast(float, w[11]);
+            const float s_lo_up = __builtin_bit_cast(float, w[12]), s_hi_up = __builtin_bit_cast(float, w[13]);
+            const float s_lo_dn = __builtin_bit_cast(float, w[14]), s_hi_dn = __builtin_bit_cast(float, w[15]);
+            const float seam_g = __builtin_bit_cast(float, w[16]), az_sgn = __builtin_bit_cast(float, w[17]);
+
+            const double dx = x - rpx, dy = y - rpy, dz = z - rpz;
+            const float fx = (float)dx, fy = (float)dy, fz = (float)dz;
+            const float rho2 = __builtin_fmaf(fy, fy, fx * fx);
+            const float d2f = __builtin_fmaf(fz, fz, rho2);
+            const float cl = __builtin_fmaf(elx, fy, -(ely * fx));     // az_sgn * cross(e_lo, p)
+            const float ch = __builtin_fmaf(fx, ehy, -(fy * ehx));     // az_sgn * cross(p, e_hi)
+            const float m_az = az_sgn * fminf(cl, ch);                 // > 0 inside the azimuth sector
+            const float dist = __builtin_amdgcn_sqrtf(d2f);
+            const bool up = fz >= 0.f;
+            const float s_lo = up ? s_lo_up : s_lo_dn;
+            const float s_hi = up ? s_hi_up : s_hi_dn;
+            const float a = __builtin_fmaf(-s_lo, dist, fz), b = __builtin_fmaf(s_hi, dist, -fz);
+            const float inside = fminf(fminf(m_az, a), b);             // > 0: inside azimuth and elevation
+            // q <= 0: within the guard band of an azimuth edge line, an elevation edge or the 0/180 seam
+            const float q_az = __builtin_fmaf(-(kGuard * kGuard), rho2, fminf(cl * cl, ch * ch));
+            const float q_el = __builtin_fmaf(-kGuard, dist, fminf(fabsf(a), fabsf(b)));
+            const float q_sm = __builtin_fmaf(-seam_g, dist, fabsf(fz));
+            const float q = fminf(fminf(q_az, q_el), q_sm);
+            // float32 range gate; d2f in [d2f_in, d2f_out] is the thin shell that needs binary64.
+            // NaN / overflowed d2f: not in range (degenerate ranges have d2f_out = inf, d2f_in = -1).
+            const bool in_range = d2f <= d2f_out;
+            bool vis = in_range & (inside > 0.f);
+            const bool amb = in_range & ((q <= 0.f) | !(d2f < d2f_in));
+            if (amb) vis = visible_exact(P.rb.cold[r], dx, dy, dz);
             if (vis) {
                 mask |= 1u << r;
-                if (P.flags & ZRK_F_PHILOX) {
-                    double nz[3];
-                    philox_noise(P.seed, P.tick, (uint32_t)(P.radar_base + r), (uint64_t)(P.gid0 + i), 5.0f, nz);
-                    x += nz[0]; y += nz[1]; z += nz[2];      // modules/Radar.py:142, before the next radar looks
+                if (PHILOX) {
+                    float nz[3];
+                    noise_draw3(ns, 5.0f, nz);
+                    x += (double)nz[0]; y += (double)nz[1]; z += (double)nz[2];   // modules/Radar.py:142
                 }
             }
         }
-        if (P.flags & (ZRK_F_ADVANCE | ZRK_F_PHILOX)) {
+        if (PHILOX || (P.flags & ZRK_F_ADVANCE)) {
             P.pos[i] = x; P.pos[cap + i] = y; P.pos[2 * cap + i] = z;
         }
     }
     if (i < P.n) P.vis[i] = mask;
 
-    // per-workgroup detection counts per radar (row R: seen by any radar), consumed by the scan
+    // per-workgroup detection counts per radar (row R: seen by any radar), consumed by the scan:
+    // lane r of each wave collects the wave's count for radar r, then one LDS add per lane
     const int lane = tid & 63;
+    int cnt_lane = 0;
     for (int r = 0; r < P.R; ++r) {
         const unsigned long long b = __ballot((mask >> r) & 1u);
-        if (lane == 0 && b) atomicAdd(&s_cnt[r], (int)__popcll(b));
+        cnt_lane = (lane == r) ? (int)__popcll(b) : cnt_lane;
     }
     {
         const unsigned long long b = __ballot(mask != 0u);
-        if (lane == 0 && b) atomicAdd(&s_cnt[P.R], (int)__popcll(b));
+        cnt_lane = (lane == P.R) ? (int)__popcll(b) : cnt_lane;
     }
+    if (lane <= P.R && cnt_lane) atomicAdd(&s_cnt[lane], cnt_lane);
     __syncthreads();
     if (tid <= P.R) P.block_counts[(int64_t)tid * P.nb + blockIdx.x] = s_cnt[tid];
 }
@@ -268,31 +327,50 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_scatter(const uint32_t *__restric
                                                        int64_t packed_capacity, int64_t gid0)
 {
     __shared__ int s_wcnt[ZRK_BLOCK / 64][ZRK_MAX_RADARS + 1];
-    __shared__ int s_rbase[ZRK_MAX_RADARS + 1];
+    __shared__ int s_base[ZRK_MAX_RADARS + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t i = (int64_t)blockIdx.x * ZRK_BLOCK + tid;
     const uint32_t m = (i < n) ? vis[i] : 0u;
-    if (tid == 0) {
-        int acc = 0;
-        for (int r = 0; r < R; ++r) { s_rbase[r] = acc; acc += totals[r]; }
-        s_rbase[R] = acc;
+    if (wave == 0) {
+        // exclusive scan of the R per-radar totals across the first wave; s_base[r] = where this
+        // workgroup's detections of radar r start in det_idx (row R: in the packed union list)
+        const int tot = (lane < R) ? totals[lane] : 0;
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        const int grand = __shfl(incl, R > 0 ? R - 1 : 0);
+        if (lane <= R) {
+            const int rbase = (lane < R) ? incl - tot : 0;      // the union row is a list of its own
+            if (det_idx && blockIdx.x == 0) det_off[lane] = (lane < R) ? rbase : (R > 0 ? grand : 0);
+            s_base[lane] = rbase + offs[(int64_t)lane * nb + blockIdx.x];
+        }
     }
+    // lane r of each wave holds the wave's count for radar r (lane R: union)
+    int cnt_lane = 0;
     for (int r = 0; r < R; ++r) {
         const unsigned long long b = __ballot((m >> r) & 1u);
-        if (lane == 0) s_wcnt[wave][r] = (int)__popcll(b);
+        cnt_lane = (lane == r) ? (int)__popcll(b) : cnt_lane;
     }
     const unsigned long long bu = __ballot(m != 0u);
-    if (lane == 0) s_wcnt[wave][R] = (int)__popcll(bu);
+    cnt_lane = (lane == R) ? (int)__popcll(bu) : cnt_lane;
+    if (lane <= R) s_wcnt[wave][lane] = cnt_lane;
     __syncthreads();
-    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // lane r: where this wave's detections of radar r start
+    int wbase_lane = 0;
+    if (lane <= R) {
+        wbase_lane = s_base[lane];
+        for (int w = 0; w < wave; ++w) wbase_lane += s_wcnt[w][lane];
+    }
     if (det_idx) {
-        if (blockIdx.x == 0 && tid <= R) det_off[tid] = s_rbase[tid];
         for (int r = 0; r < R; ++r) {
             const unsigned long long b = __ballot((m >> r) & 1u);
+            const int wbase = __builtin_amdgcn_readlane(wbase_lane, r);
             if ((m >> r) & 1u) {
-                int rank = (int)__popcll(b & below);
-                for (int w = 0; w < wave; ++w) rank += s_wcnt[w][r];
-                const int64_t dst = (int64_t)s_rbase[r] + offs[(int64_t)r * nb + blockIdx.x] + rank;
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                const int64_t dst = (int64_t)wbase + rank;
                 if (dst < det_capacity) det_idx[dst] = base_index + (int32_t)i;
             }
         }
@@ -300,10 +378,10 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_scatter(const uint32_t *__restric
     if (packed) {
         // union list for the multi-GPU exchange: packed[0] = count, then (global index << 32 | mask)
         if (blockIdx.x == 0 && tid == 0) packed[0] = totals[R];
+        const int wbase = __builtin_amdgcn_readlane(wbase_lane, R);
         if (m != 0u) {
-            int rank = (int)__popcll(bu & below);
-            for (int w = 0; w < wave; ++w) rank += s_wcnt[w][R];
-            const int64_t dst = (int64_t)offs[(int64_t)R * nb + blockIdx.x] + rank;
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bu >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bu, 0u));
+            const int64_t dst = (int64_t)wbase + rank;
             if (dst + 1 < packed_capacity) packed[dst + 1] = ((gid0 + i) << 32) | (int64_t)m;
         }
     }
@@ -321,16 +399,14 @@ __global__ void k_noise_apply(double *__restrict__ pos, int64_t cap, const int32
     pos[2 * cap + i] += noise[3 * j + 2];
 }
 
-// Missile.step 'active' branch, one thread per in-flight missile.
-__global__ void k_missile_step(const double *__restrict__ sp, const double *__restrict__ vel,
-                               const double *__restrict__ t0, const uint8_t *__restrict__ alive,
-                               const double *__restrict__ pos_prev, int64_t cap, const int32_t *__restrict__ m_slot,
-                               const int32_t *__restrict__ m_tgt, const double *__restrict__ m_radius,
-                               double *__restrict__ m_period, uint8_t *__restrict__ m_status,
-                               uint8_t *__restrict__ ev_code, int64_t m, double t, double dts)
+// Missile.step 'active' branch for one row (modules/Missile.py:162-193).  Returns 0 none, 1 hit, 2 timeout.
+__device__ __forceinline__ uint8_t missile_step_row(const double *__restrict__ sp, const double *__restrict__ vel,
+                                                    const double *__restrict__ t0, const uint8_t *alive,
+                                                    const double *pos_prev, int64_t cap,
+                                                    const int32_t *__restrict__ m_slot, const int32_t *__restrict__ m_tgt,
+                                                    const double *__restrict__ m_radius, double *__restrict__ m_period,
+                                                    uint8_t *__restrict__ m_status, int64_t row, double t, double dts)
 {
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= m) return;
     uint8_t code = 0;
     const int32_t s = m_slot[row];
     if (m_status[row] == 1 && alive[s]) {
@@ -355,7 +431,78 @@ __global__ void k_missile_step(const double *__restrict__ sp, const double *__re
             if (p <= 0.0) { code = 2; m_status[row] = 2; }
         }
     }
-    ev_code[row] = code;
+    return code;
+}
+
+// One thread per in-flight missile (any table size); events are ordered by k_missile_events.
+__global__ void k_missile_step(const double *__restrict__ sp, const double *__restrict__ vel,
+                               const double *__restrict__ t0, const uint8_t *__restrict__ alive,
+                               const double *__restrict__ pos_prev, int64_t cap, const int32_t *__restrict__ m_slot,
+                               const int32_t *__restrict__ m_tgt, const double *__restrict__ m_radius,
+                               double *__restrict__ m_period, uint8_t *__restrict__ m_status,
+                               uint8_t *__restrict__ ev_code, int64_t m, double t, double dts)
+{
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= m) return;
+    ev_code[row] = missile_step_row(sp, vel, t0, alive, pos_prev, cap, m_slot, m_tgt, m_radius, m_period, m_status, row, t, dts);
+}
+
+__device__ __forceinline__ void kill_one(uint8_t *alive, const double *src, double *dst, int64_t cap, int32_t s)
+{
+    alive[s] = 0;
+    dst[s] = src[s]; dst[cap + s] = src[cap + s]; dst[2 * cap + s] = src[2 * cap + s];
+}
+
+// Second half of the missile phase in ONE workgroup: the ordered event list out of ev_code (each
+// thread owns a run of consecutive rows) and, with apply != 0, the tombstones of the detonated
+// missiles and their targets.  Runs after k_missile_step has finished (kernel boundary), so no row
+// of this tick sees a half-applied removal.
+constexpr int kMissileItems = 16;
+
+__global__ __launch_bounds__(1024) void k_missile_finish(const uint8_t *__restrict__ ev_code,
+                                                         const int32_t *__restrict__ m_slot,
+                                                         const int32_t *__restrict__ m_tgt, int64_t m,
+                                                         int32_t *__restrict__ ev_missile,
+                                                         int32_t *__restrict__ ev_target,
+                                                         int32_t *__restrict__ ev_count, int apply, uint8_t *alive,
+                                                         const double *pos_cur, double *pos_prev, int64_t cap)
+{
+    __shared__ int s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (int)((m + 1023) / 1024);                 // consecutive rows per thread (<= kMissileItems)
+    const int64_t row0 = (int64_t)tid * per;
+    uint8_t codes[kMissileItems];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kMissileItems; ++k) {
+        const int64_t row = row0 + k;
+        codes[k] = (k < per && row < m) ? ev_code[row] : 0;
+        cnt += codes[k] != 0;
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int base = incl - cnt, total = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wave) base += s_wave[w]; total += s_wave[w]; }
+    if (tid == 0) *ev_count = total;
+    if (cnt == 0) return;
+#pragma unroll
+    for (int k = 0; k < kMissileItems; ++k) {
+        if (codes[k]) {
+            const int64_t row = row0 + k;
+            const int32_t ms = m_slot[row], ts = (codes[k] == 1) ? m_tgt[row] : -1;
+            ev_missile[base] = ms; ev_target[base] = ts; ++base;
+            if (apply) {                                      // AirEnv.py:33-40, effective from the next tick
+                kill_one(alive, pos_cur, pos_prev, cap, ms);
+                if (ts >= 0) kill_one(alive, pos_cur, pos_prev, cap, ts);
+            }
+        }
+    }
 }
 
 // Ordered event list from ev_code: one workgroup walks the (short) missile table in row order.
@@ -391,12 +538,6 @@ __global__ __launch_bounds__(1024) void k_missile_events(const uint8_t *__restri
     if (tid == 0) *ev_count = s_carry;
 }
 
-__device__ __forceinline__ void kill_one(uint8_t *alive, const double *src, double *dst, int64_t cap, int32_t s)
-{
-    alive[s] = 0;
-    dst[s] = src[s]; dst[cap + s] = src[cap + s]; dst[2 * cap + s] = src[2 * cap + s];
-}
-
 __global__ void k_kill_slots(uint8_t *alive, const double *src, double *dst, int64_t cap,
                              const int32_t *__restrict__ slots, int64_t k)
 {
@@ -406,15 +547,13 @@ __global__ void k_kill_slots(uint8_t *alive, const double *src, double *dst, int
 
 __global__ void k_apply_events(uint8_t *alive, const double *src, double *dst, int64_t cap,
                                const int32_t *__restrict__ ev_missile, const int32_t *__restrict__ ev_target,
-                               int32_t *ev_count, int64_t mcap)
+                               const int32_t *ev_count, int64_t mcap)
 {
     const int n = *ev_count;
     for (int64_t j = threadIdx.x; j < n && j < mcap; j += blockDim.x) {
         kill_one(alive, src, dst, cap, ev_missile[j]);
         if (ev_target[j] >= 0) kill_one(alive, src, dst, cap, ev_target[j]);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) *ev_count = 0;
 }
 
 // Missile._calculate_trajectory_params, one thread per request (modules/Missile.py:35-102).
@@ -491,13 +630,14 @@ __global__ void k_selftest_math(int op, const double *a, const double *b, double
     y[i] = r;
 }
 
-__global__ void k_selftest_noise(uint64_t seed, uint64_t tick, uint32_t radar, int64_t entity0, double *out, int64_t n)
+__global__ void k_selftest_noise(uint64_t seed, uint64_t tick, uint32_t ordinal, int64_t entity0, double *out, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    double nz[3];
-    philox_noise(seed, tick, radar, (uint64_t)(entity0 + i), 5.0f, nz);
-    out[3 * i] = nz[0]; out[3 * i + 1] = nz[1]; out[3 * i + 2] = nz[2];
+    NoiseState ns = noise_init(seed, tick, (uint64_t)(entity0 + i));
+    float nz[3] = {0.f, 0.f, 0.f};
+    for (uint32_t k = 0; k <= ordinal; ++k) noise_draw3(ns, 5.0f, nz);
+    out[3 * i] = (double)nz[0]; out[3 * i + 1] = (double)nz[1]; out[3 * i + 2] = (double)nz[2];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -519,38 +659,46 @@ double d2_threshold(double m)
     return c;
 }
 
-void derive_radar(const zrk_radar &h, RadarDev &d)
+void derive_radar(const zrk_radar &hr, bool exact_only, RadarHot &h, RadarCold &c)
 {
     const double deg = 3.14159265358979323846 / 180.0;
-    d.px = h.pos[0]; d.py = h.pos[1]; d.pz = h.pos[2];
-    d.d2_max = d2_threshold(h.max_distance);
-    d.az_lo = h.cur_azimuth; d.az_hi = h.cur_azimuth + h.azimuth_range;
-    d.el_lo = h.cur_elevation; d.el_hi = h.cur_elevation + h.elevation_range;
-    d.elx = d.ely = d.ehx = d.ehy = 0.f;
-    d.s_lo_up = d.s_lo_dn = 2.f; d.s_hi_up = d.s_hi_dn = -2.f;
-    d.seam_g = kGuard;
-    if (!std::isfinite(d.az_lo) || !std::isfinite(d.az_hi) || !std::isfinite(d.el_lo) || !std::isfinite(d.el_hi)) {
-        d.az_mode = 3u;                            // decide every in-range pair in binary64
-        return;
-    }
+    std::memset(&h, 0, sizeof(h));
+    h.px = hr.pos[0]; h.py = hr.pos[1]; h.pz = hr.pos[2];
+    c.d2_max = d2_threshold(hr.max_distance);
+    c.az_lo = hr.cur_azimuth; c.az_hi = hr.cur_azimuth + hr.azimuth_range;
+    c.el_lo = hr.cur_elevation; c.el_hi = hr.cur_elevation + hr.elevation_range;
+    // float32 pre-gate: d2 computed in binary32 from rounded differences is within ~1e-6 relative.
+    // "always binary64" is encoded as d2f_in = -1 (every in-range pair counts as shell),
+    // "never visible" as d2f_out = -1 (nothing is in range).
+    const bool plain_range = std::isfinite(c.d2_max) && c.d2_max > 0.0 && c.d2_max < 1e30;
+    h.d2f_in = plain_range ? (float)(c.d2_max * (1.0 - 1e-5)) : -1.f;
+    h.d2f_out = plain_range ? (float)(c.d2_max * (1.0 + 1e-5)) : INFINITY;
+    h.s_lo_up = h.s_lo_dn = 2.f; h.s_hi_up = h.s_hi_dn = -2.f;
+    h.seam_g = kGuard;
+    h.az_sgn = 1.f;
+    const bool finite = std::isfinite(c.az_lo) && std::isfinite(c.az_hi) && std::isfinite(c.el_lo) && std::isfinite(c.el_hi);
+    if (!finite || exact_only) h.d2f_in = -1.f;   // decide every in-range pair in binary64
+    if (!finite) return;
     // azimuth lives in [0, 360]; the comparison has no wrap-around (modules/Radar.py:67-68)
-    const double lo = std::fmax(d.az_lo, 0.0), hi = std::fmin(d.az_hi, 360.0);
-    if (!(lo <= hi)) { d.az_mode = 0u; return; }
-    d.az_mode = (hi - lo <= 180.0) ? 1u : 2u;
-    d.elx = (float)std::cos(lo * deg); d.ely = (float)std::sin(lo * deg);
-    d.ehx = (float)std::cos(hi * deg); d.ehy = (float)std::sin(hi * deg);
+    const double lo = std::fmax(c.az_lo, 0.0), hi = std::fmin(c.az_hi, 360.0);
+    if (!(lo <= hi) || c.d2_max < 0.0) { h.d2f_out = -1.f; return; }
+    // width <= 180: inside <=> cross(e_lo,p) > 0 and cross(p,e_hi) > 0; wider: either one, which is
+    // min(-c1,-c2) < 0, so the edges are stored negated and az_sgn = -1 flips the minimum back
+    h.az_sgn = (hi - lo <= 180.0) ? 1.f : -1.f;
+    h.elx = h.az_sgn * (float)std::cos(lo * deg); h.ely = h.az_sgn * (float)std::sin(lo * deg);
+    h.ehx = h.az_sgn * (float)std::cos(hi * deg); h.ehy = h.az_sgn * (float)std::sin(hi * deg);
     // elevation: dz >= 0 -> el = theta in [0,90];  dz < 0 -> el = 180 + theta in [90,180]
-    const double lo_u = std::fmax(d.el_lo, 0.0), hi_u = std::fmin(d.el_hi, 90.0);
+    const double lo_u = std::fmax(c.el_lo, 0.0), hi_u = std::fmin(c.el_hi, 90.0);
     if (lo_u <= hi_u) {
-        d.s_lo_up = (d.el_lo <= 0.0) ? -2.f : (float)std::sin(lo_u * deg);
-        d.s_hi_up = (d.el_hi >= 90.0) ? 2.f : (float)std::sin(hi_u * deg);
+        h.s_lo_up = (c.el_lo <= 0.0) ? -2.f : (float)std::sin(lo_u * deg);
+        h.s_hi_up = (c.el_hi >= 90.0) ? 2.f : (float)std::sin(hi_u * deg);
     }
-    const double lo_d = std::fmax(d.el_lo - 180.0, -90.0), hi_d = std::fmin(d.el_hi - 180.0, 0.0);
+    const double lo_d = std::fmax(c.el_lo - 180.0, -90.0), hi_d = std::fmin(c.el_hi - 180.0, 0.0);
     if (lo_d <= hi_d) {
-        d.s_lo_dn = (d.el_lo - 180.0 <= -90.0) ? -2.f : (float)std::sin(lo_d * deg);
-        d.s_hi_dn = (d.el_hi >= 180.0) ? 2.f : (float)std::sin(hi_d * deg);
+        h.s_lo_dn = (c.el_lo - 180.0 <= -90.0) ? -2.f : (float)std::sin(lo_d * deg);
+        h.s_hi_dn = (c.el_hi >= 180.0) ? 2.f : (float)std::sin(hi_d * deg);
     }
-    if (d.el_lo <= 0.0 && d.el_hi >= 180.0) d.seam_g = -1.f;
+    if (c.el_lo <= 0.0 && c.el_hi >= 180.0) h.seam_g = -1.f;
 }
 
 }  // namespace
@@ -619,11 +767,11 @@ ZRK_API int64_t zrk_workspace_bytes(int64_t n_max)
 }
 
 ZRK_API int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_t time_ms,
-                           const zrk_radar *radars, int R, int radar_base, uint32_t flags, uint64_t seed,
-                           uint64_t tick, int64_t gid0, void *workspace, void *stream)
+                           const zrk_radar *radars, int R, uint32_t flags, uint64_t seed, uint64_t tick,
+                           int64_t gid0, void *workspace, void *stream)
 {
     if (!ctx || !e || !workspace || (R > 0 && !radars)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
-    if (R < 0 || R > ZRK_MAX_RADARS || radar_base < 0 || radar_base + R > 0xFFFF)
+    if (R < 0 || R > ZRK_MAX_RADARS)
         return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: radar count out of range");
     if (n < 0 || n > e->capacity || (cur != 0 && cur != 1)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: n/cur out of range");
     if (n == 0) return 0;
@@ -633,11 +781,18 @@ ZRK_API int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int c
     P.n = n; P.cap = e->capacity;
     P.t = (double)time_ms / 1000.0;                 // to_seconds, modules/AirObject.py:5-7
     P.seed = seed; P.tick = tick; P.gid0 = gid0;
-    P.R = R; P.radar_base = radar_base; P.nb = nblocks(n, ZRK_BLOCK); P.flags = flags;
+    P.R = R; P.nb = nblocks(n, ZRK_BLOCK); P.flags = flags;
     P.block_counts = carve(workspace, P.nb).counts;
     std::memset(&P.rb, 0, sizeof(P.rb));
-    for (int r = 0; r < R; ++r) derive_radar(radars[r], P.rb.r[r]);
-    hipLaunchKernelGGL(k_tick_sweep, dim3(P.nb), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P);
+    for (int r = 0; r < R; ++r) {
+        RadarHot hot;
+        derive_radar(radars[r], (flags & ZRK_F_EXACT_ONLY) != 0, hot, P.rb.cold[r]);
+        std::memcpy(P.rb.hotw[r], &hot, sizeof(hot));
+    }
+    if (flags & ZRK_F_PHILOX)
+        hipLaunchKernelGGL(k_tick_sweep<true>, dim3(P.nb), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P);
+    else
+        hipLaunchKernelGGL(k_tick_sweep<false>, dim3(P.nb), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P);
     return check_launch(ctx, "k_tick_sweep");
 }
 
@@ -674,7 +829,7 @@ ZRK_API int zrk_noise_apply(zrk_ctx *ctx, double *pos, int64_t capacity, const i
 }
 
 ZRK_API int zrk_missile_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const zrk_missiles *mis, int64_t m,
-                             int64_t time_ms, int64_t dt_ms, void *stream)
+                             int64_t time_ms, int64_t dt_ms, int apply_kills, void *stream)
 {
     if (!ctx || !e || !mis) return fail(ctx, ZRK_E_INVALID, "zrk_missile_step: null argument");
     if (m < 0 || m > mis->capacity || (cur != 0 && cur != 1)) return fail(ctx, ZRK_E_INVALID, "zrk_missile_step: m/cur out of range");
@@ -687,8 +842,17 @@ ZRK_API int zrk_missile_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const
     hipLaunchKernelGGL(k_missile_step, dim3(nblocks(m, 256)), dim3(256), 0, s, e->start_pos, e->velocity, e->start_time,
                        e->alive, e->pos[cur ^ 1], e->capacity, mis->slot, mis->target, mis->radius, mis->period,
                        mis->status, mis->ev_code, m, t, dts);
+    if (m <= 1024 * (int64_t)kMissileItems) {
+        hipLaunchKernelGGL(k_missile_finish, dim3(1), dim3(1024), 0, s, mis->ev_code, mis->slot, mis->target, m,
+                           mis->ev_missile, mis->ev_target, mis->ev_count, apply_kills, e->alive, e->pos[cur],
+                           e->pos[cur ^ 1], e->capacity);
+        return check_launch(ctx, "k_missile_finish");
+    }
     hipLaunchKernelGGL(k_missile_events, dim3(1), dim3(1024), 0, s, mis->ev_code, mis->slot, mis->target, m,
                        mis->ev_missile, mis->ev_target, mis->ev_count);
+    if (apply_kills)
+        hipLaunchKernelGGL(k_apply_events, dim3(1), dim3(256), 0, s, e->alive, e->pos[cur], e->pos[cur ^ 1], e->capacity,
+                           mis->ev_missile, mis->ev_target, mis->ev_count, mis->capacity);
     return check_launch(ctx, "zrk_missile_step");
 }
 
@@ -730,12 +894,12 @@ ZRK_API int zrk_selftest_math(zrk_ctx *ctx, int op, const double *a, const doubl
     return check_launch(ctx, "k_selftest_math");
 }
 
-ZRK_API int zrk_selftest_noise(zrk_ctx *ctx, uint64_t seed, uint64_t tick, uint32_t radar, int64_t entity0,
+ZRK_API int zrk_selftest_noise(zrk_ctx *ctx, uint64_t seed, uint64_t tick, uint32_t ordinal, int64_t entity0,
                                double *out, int64_t n, void *stream)
 {
     if (!ctx || !out) return fail(ctx, ZRK_E_INVALID, "zrk_selftest_noise: null argument");
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_selftest_noise, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, seed, tick, radar,
+    hipLaunchKernelGGL(k_selftest_noise, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, seed, tick, ordinal,
                        entity0, out, n);
     return check_launch(ctx, "k_selftest_noise");
 }
@@ -800,17 +964,18 @@ ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missile
     }
     int rc = 0;
     for (int k = 0; k < K && rc == 0; ++k) {
-        if (m > 0) rc = zrk_apply_events(ctx, e, st->cur, mis, stream);      // AirEnv.py:33-40, last tick's detonations
         st->cur ^= 1;
-        if (rc == 0 && m > 0) rc = zrk_missile_step(ctx, e, st->cur, mis, m, st->time_ms, st->dt_ms, stream);
         const bool prof = sweep_ms && (k % stride == 0);
         if (prof) (void)hipEventRecord(ev[2 * (k / stride)], s);
-        if (rc == 0) rc = zrk_tick_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, 0, st->flags | ZRK_F_ADVANCE,
-                                         st->seed, st->tick, st->gid0, workspace, stream);
+        rc = zrk_tick_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE, st->seed, st->tick,
+                            st->gid0, workspace, stream);
         if (prof) (void)hipEventRecord(ev[2 * (k / stride) + 1], s);
         if (rc == 0 && (det_idx || packed))
             rc = zrk_compact(ctx, e->vis_mask, st->n, R, st->base_index, workspace, det_idx, det_capacity, det_off, packed,
                              packed_capacity, st->gid0, stream);
+        // missiles read last tick's positions (pos[cur^1]) and trajectories only, so their phase may follow the
+        // sweep; detonations tombstone behind it, i.e. effective from the next tick (AirEnv.py:33-40)
+        if (rc == 0 && m > 0) rc = zrk_missile_step(ctx, e, st->cur, mis, m, st->time_ms, st->dt_ms, 1, stream);
         zrk_scan_advance(radars, scan, R);                                   // Radar.py:205
         st->time_ms += st->dt_ms;                                            // Manager.py:140
         st->tick += 1;

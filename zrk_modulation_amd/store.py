@@ -269,7 +269,7 @@ class EntityStore:
     def missile_step(self, dt_ms):
         """Missile.step for all in-flight rows.  Returns [(missile slot, target slot | -1)] in list order."""
         self.ctx.check(self.lib.zrk_missile_step(self.ctx.handle, C.byref(self.ents), self.cur, C.byref(self.mis), self.m,
-                                                 self.time_ms, int(dt_ms), self._stream()), "zrk_missile_step")
+                                                 self.time_ms, int(dt_ms), 0, self._stream()), "zrk_missile_step")
         if self.m == 0:
             return []
         k = int(self.dm_evn.item())
@@ -278,13 +278,13 @@ class EntityStore:
         em = self.dm_evm[:k].cpu().numpy(); et = self.dm_evt[:k].cpu().numpy()
         return [(int(a), int(b)) for a, b in zip(em, et)]
 
-    def sweep(self, radars, flags, radar_base=0, seed=0, tick=0, gid0=0, n=None):
+    def sweep(self, radars, flags, seed=0, tick=0, gid0=0, n=None):
         """zrk_tick_sweep over slots [0, n) for the given radar parameter tuples."""
         n = self.n_uploaded if n is None else n
         arr = radars if isinstance(radars, C.Array) else radar_struct_array(radars)
         R = len(radars)
         self.ctx.check(self.lib.zrk_tick_sweep(self.ctx.handle, C.byref(self.ents), n, self.cur, self.time_ms, arr, R,
-                                               radar_base, flags, seed, tick, gid0, self.workspace().data_ptr(),
+                                               flags, seed, tick, gid0, self.workspace().data_ptr(),
                                                self._stream()), "zrk_tick_sweep")
         if flags & F_ADVANCE:
             self.n_stepped = n
