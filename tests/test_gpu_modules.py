@@ -1,0 +1,138 @@
+"""The drop-in module stack (Manager + AirEnv + SectorRadar + Missile on the device, MissileLauncher
+and CombatControlPoint on the host) run exactly as the reference's main.py runs a scenario, compared
+tick by tick with what the reference produced (tests/golden, captured by gen_golden.py)."""
+import json
+
+import numpy as np
+import pytest
+
+from tests.helpers import ALL_FIXTURES, Fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _scripted_commander(mod):
+    """Test stand-in for the command post in scripted scenes; the class NAME gives it the CCP's slot in
+    the schedule (same trick as tests/golden/gen_golden.py uses against the reference)."""
+    from zrk_modulation_amd.modules.BaseModel import BaseModel
+    from zrk_modulation_amd.modules.constants import MessageType
+    from zrk_modulation_amd.modules.Messages import CPPLaunchMissileRequestMessage
+
+    class CombatControlPoint(BaseModel):
+        def __init__(self, manager, id, script):
+            super().__init__(manager, id, np.zeros(3))
+            self.script = script
+            self.known = {}
+
+        def step(self):
+            now = self._manager.time.get_time()
+            for msg in self._manager.give_messages_by_type(MessageType.ACTIVE_OBJECTS):
+                for obj in msg.active_objects:
+                    self.known.setdefault(obj.id, obj)
+            for t_ms, launcher_id, target_id in self.script:
+                if t_ms == now and target_id in self.known:
+                    obj = self.known[target_id]
+                    self._manager.add_message(CPPLaunchMissileRequestMessage(
+                        time=now, sender_id=self.id, receiver_id=launcher_id, target=obj, target_position=obj.pos,
+                        radar_id=0))
+    return CombatControlPoint
+
+
+def build(fx):
+    import zrk_modulation_amd.main as M
+    from zrk_modulation_amd.modules.Radar import SectorRadar
+    cfg = fx.cfg
+    if fx.scene.get("script") is None:
+        manager, objs = M.create_objects_from_config(cfg)
+        return manager, [o for o in objs.values() if isinstance(o, SectorRadar)]
+    cfg2 = dict(cfg)
+    cfg2["combat_control_point"] = {}
+    # same order as the reference builder: AirEnv, radars, launchers, commander, targets
+    targets = cfg2["air_environment"].get("targets", [])
+    cfg2["air_environment"] = dict(cfg2["air_environment"], targets=[])
+    manager, objs = M.create_objects_from_config(cfg2)
+    manager.add_module(_scripted_commander(M)(manager, 0, [tuple(s) for s in fx.scene["script"]]))
+    from zrk_modulation_amd.modules.AirObject import Trajectory
+    from zrk_modulation_amd.modules.utils import Target, TargetType
+    ae = objs[cfg["air_environment"]["id"]]
+    for tc in targets:
+        pos, vel = np.array(tc["position"]), np.array(tc["velocity"])
+        ae.add_target(Target(manager, tc["id"], pos, Trajectory(vel, pos, 0.0), getattr(TargetType, tc["type"])))
+    return manager, [o for o in objs.values() if isinstance(o, SectorRadar)]
+
+
+@pytest.mark.parametrize("name", ALL_FIXTURES)
+def test_module_stack_reproduces_reference_run(name):
+    from zrk_modulation_amd.modules.constants import MessageType
+    fx = Fixture(name)
+    np.random.seed(fx.scene["seed"])
+    real_normal = np.random.normal
+    if fx.scene.get("zero_noise"):
+        np.random.normal = lambda loc, scale, size=None: np.zeros(size)
+    try:
+        manager, radars = build(fx)
+        hist = {}
+        for T in range(fx.n_ticks):
+            t = int(fx.tick_ms[T])
+            manager.run_simulation(t + fx.dt)
+            msgs = manager.messages.get(t, [])
+            act = [m for m in msgs if m.type == MessageType.ACTIVE_OBJECTS][0].active_objects
+            assert [o.id for o in act] == fx.active_ids(T).tolist(), f"live ids differ at t={t}"
+            P = np.array([o.pos for o in act]).reshape(len(act), 3)
+            dig = int(np.bitwise_xor.reduce(np.ascontiguousarray(P).view(np.uint64).ravel())) if len(act) else 0
+            assert dig == int(fx.pos_digest[T]), f"position bits differ at t={t}"
+            found = [m for m in msgs if m.type == MessageType.FOUND_OBJECTS]
+            assert [m.sender_id for m in found] == [r.id for r in radars]
+            for r, m in enumerate(found):
+                assert [o.id for o in m.visible_objects] == fx.found(T, r).tolist(), f"radar {r} at t={t}"
+            state = np.array([[r.current_azimuth, r.current_elevation] for r in radars], np.float64).reshape(-1, 2)
+            assert np.array_equal(state, fx.radar_state[T])
+            if T in fx.samp_index:
+                k = fx.samp_index[T]
+                lo, hi = fx.samp_off[k], fx.samp_off[k + 1]
+                assert np.array_equal(P, fx.pos[lo:hi])
+                pv = np.array([o.prev_pos is not None for o in act], dtype=bool)
+                assert np.array_equal(pv, fx.prev_valid[lo:hi].astype(bool)), f"prev_pos None-ness at t={t}"
+                PP = np.array([o.prev_pos if o.prev_pos is not None else np.zeros(3) for o in act]).reshape(len(act), 3)
+                assert np.array_equal(PP[pv], fx.prev[lo:hi][pv]), f"prev_pos differs at t={t}"
+            det = [[t, m.missile_id, -1 if m.target_id is None else m.target_id, int(m.self_detonation)]
+                   for m in msgs if m.type == MessageType.MISSILE_DETONATE]
+            assert det == fx.rows_at(fx.detonations, t).tolist(), f"detonations differ at t={t}"
+            for m in msgs:
+                hist[m.type.name] = hist.get(m.type.name, 0) + 1
+                if m.type == MessageType.LAUNCH_SUCCESSFUL:
+                    row = [k for k, r in enumerate(fx.launch_ok) if r[0] == t and r[1] == m.missile.id]
+                    assert row, f"unexpected launch of {m.missile.id} at t={t}"
+                    tr = m.missile.trajectory
+                    want = fx.launch_traj[row[0]]
+                    assert np.array_equal(np.concatenate([tr.velocity, tr.start_pos, [tr.start_time]]), want)
+                elif m.type == MessageType.LAUNCH_CANCELLED:
+                    row = [k for k, r in enumerate(fx.launch_cancel) if r[0] == t and r[1] == m.missile.id]
+                    assert row and fx.reasons[row[0]] == m.reason
+        assert hist == fx.histogram, "message-type histogram of the whole run differs from the reference's"
+    finally:
+        np.random.normal = real_normal
+
+
+def test_handles_keep_identity_and_freeze_after_removal():
+    """CCP-style consumers keep references across ticks: a removed object's pos / prev_pos stay at
+    their last values, and missiles chasing it see the same frozen position on the device."""
+    from zrk_modulation_amd.modules.constants import MessageType
+    fx = Fixture("missiles")
+    np.random.seed(fx.scene["seed"])
+    manager, _ = build(fx)
+    seen = {}
+    frozen = {}
+    for T in range(fx.n_ticks):
+        t = int(fx.tick_ms[T])
+        manager.run_simulation(t + fx.dt)
+        act = [m for m in manager.messages[t] if m.type == MessageType.ACTIVE_OBJECTS][0].active_objects
+        live = {o.id for o in act}
+        for o in act:
+            assert seen.setdefault(o.id, o) is o          # same Python object every tick
+        for oid, o in seen.items():
+            if oid not in live:
+                if oid not in frozen:
+                    frozen[oid] = (o.pos.copy(), None if o.prev_pos is None else o.prev_pos.copy())
+                assert np.array_equal(o.pos, frozen[oid][0])
+    assert frozen, "scene should remove at least one object"

@@ -205,31 +205,30 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P)
             const float ehx = __builtin_bit_cast(float, w[10]), ehy = __builtin_bit_cast(float, w[11]);
             const float s_lo_up = __builtin_bit_cast(float, w[12]), s_hi_up = __builtin_bit_cast(float, w[13]);
             const float s_lo_dn = __builtin_bit_cast(float, w[14]), s_hi_dn = __builtin_bit_cast(float, w[15]);
-            const float seam_g = __builtin_bit_cast(float, w[16]), az_sgn = __builtin_bit_cast(float, w[17]);
+            const float az_sgn = __builtin_bit_cast(float, w[17]);
 
             const double dx = x - rpx, dy = y - rpy, dz = z - rpz;
             const float fx = (float)dx, fy = (float)dy, fz = (float)dz;
-            const float rho2 = __builtin_fmaf(fy, fy, fx * fx);
-            const float d2f = __builtin_fmaf(fz, fz, rho2);
+            const float d2f = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
             const float cl = __builtin_fmaf(elx, fy, -(ely * fx));     // az_sgn * cross(e_lo, p)
             const float ch = __builtin_fmaf(fx, ehy, -(fy * ehx));     // az_sgn * cross(p, e_hi)
-            const float m_az = az_sgn * fminf(cl, ch);                 // > 0 inside the azimuth sector
+            const float m_az = az_sgn * fminf(cl, ch);                 // > 0 inside the azimuth sector [m]
             const float dist = __builtin_amdgcn_sqrtf(d2f);
-            const bool up = fz >= 0.f;
-            const float s_lo = up ? s_lo_up : s_lo_dn;
-            const float s_hi = up ? s_hi_up : s_hi_dn;
-            const float a = __builtin_fmaf(-s_lo, dist, fz), b = __builtin_fmaf(s_hi, dist, -fz);
-            const float inside = fminf(fminf(m_az, a), b);             // > 0: inside azimuth and elevation
-            // q <= 0: within the guard band of an azimuth edge line, an elevation edge or the 0/180 seam
-            const float q_az = __builtin_fmaf(-(kGuard * kGuard), rho2, fminf(cl * cl, ch * ch));
-            const float q_el = __builtin_fmaf(-kGuard, dist, fminf(fabsf(a), fabsf(b)));
-            const float q_sm = __builtin_fmaf(-seam_g, dist, fabsf(fz));
-            const float q = fminf(fminf(q_az, q_el), q_sm);
-            // float32 range gate; d2f in [d2f_in, d2f_out] is the thin shell that needs binary64.
-            // NaN / overflowed d2f: not in range (degenerate ranges have d2f_out = inf, d2f_in = -1).
+            // elevation: el = theta for dz >= 0, 180 + theta for dz < 0 (sign taken in binary64, so a
+            // tiny negative dz that rounds to -0.0f still selects the lower-hemisphere bounds)
+            const float a_up = __builtin_fmaf(-s_lo_up, dist, fz), b_up = __builtin_fmaf(s_hi_up, dist, -fz);
+            const float a_dn = __builtin_fmaf(-s_lo_dn, dist, fz), b_dn = __builtin_fmaf(s_hi_dn, dist, -fz);
+            const bool up = dz >= 0.0;
+            const float a = up ? a_up : a_dn, b = up ? b_up : b_dn;
+            // t: signed distance [m] to the nearest sector face (> 0 inside).  Pairs with |t| within
+            // kGuard * dist of a face, and pairs in the thin shell around the range sphere, are decided
+            // in binary64; everything else is settled here.  NaN / overflow fall out as "not in range"
+            // (degenerate ranges are encoded by the host as d2f_out = inf, d2f_in = -1 -> always exact).
+            const float t = fminf(fminf(m_az, a), b);
+            const float gd = kGuard * dist;
             const bool in_range = d2f <= d2f_out;
-            bool vis = in_range & (inside > 0.f);
-            const bool amb = in_range & ((q <= 0.f) | !(d2f < d2f_in));
+            bool vis = in_range & (t > gd);
+            const bool amb = in_range & ((fabsf(t) <= gd) | !(d2f < d2f_in));
             if (amb) vis = visible_exact(P.rb.cold[r], dx, dy, dz);
             if (vis) {
                 mask |= 1u << r;
