@@ -49,6 +49,22 @@ def build_engine(workload, rank, world, device, seed_off=0):
     return eng, dict(n=n, R=R, m=m, launched=launched, scene=(ids, sp, vel, t0, radars))
 
 
+def usable_cores():
+    """Threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
 def cpu_baseline(info, eng, budget_s=15.0):
     """Time the oracle's L1 tick on the same scene (test infrastructure used as the reported CPU
     baseline only).  Single-threaded advance/missile loop + OpenMP radar phase on all host cores."""
@@ -73,11 +89,7 @@ def cpu_baseline(info, eng, budget_s=15.0):
     vis = np.zeros(n, np.uint32)
     from zrk_modulation_amd.engine import scan_next, scan_mode_code
     rs = [dict(r, caz=r["azimuth_start"], cel=r["elevation_start"]) for r in radars]
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = usable_cores()
 
     def tick(k, threads):
         nev = L.zo_airenv_step(n, cap, 10 * k, 10, O.dptr(hsp), O.dptr(hvel), O.dptr(ht0), O.u8ptr(alive),

@@ -1,0 +1,159 @@
+"""CPU-only checks: host-side logic of the drop-in modules, the C-ABI surface, fail-loud behaviour
+without a GPU.  No compute kernels run here."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_symbol_the_header_declares():
+    from zrk_modulation_amd import _lib
+    _lib.build()
+    header = (ROOT / "include" / "zrk_hot.h").read_text()
+    declared = set(re.findall(r"\b(zrk_[a-z_0-9]+)\s*\(", header))
+    lib = C.CDLL(str(_lib.LIB_PATH))
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/zrk_hot.h but not exported"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), "ctypes binding and header disagree on the surface"
+    assert lib.zrk_abi_version() == _lib.ZRK_ABI_VERSION
+
+
+def test_ctypes_structs_match_the_header_layout():
+    from zrk_modulation_amd import _lib
+    assert C.sizeof(_lib.ZrkRadar) == 8 * 8
+    assert C.sizeof(_lib.ZrkEntities) == 8 * 9
+    assert C.sizeof(_lib.ZrkMissiles) == 8 * 10
+    assert C.sizeof(_lib.ZrkLaunchReq) == 48 and C.sizeof(_lib.ZrkLaunchRes) == 40
+    assert C.sizeof(_lib.ZrkScan) == 32 and C.sizeof(_lib.ZrkLoop) == 64
+
+
+def test_no_gpu_means_loud_failure_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from zrk_modulation_amd import HotPathUnavailable
+    from zrk_modulation_amd.store import EntityStore
+    with pytest.raises(HotPathUnavailable):
+        EntityStore()
+    from zrk_modulation_amd.modules.AirEnv import AirEnv
+    from zrk_modulation_amd.modules.Manager import Manager
+    from zrk_modulation_amd.modules.AirObject import Trajectory
+    from zrk_modulation_amd.modules.utils import Target
+    m = Manager()
+    ae = AirEnv(m, 1, np.zeros(3))           # constructing is GPU-free ...
+    with pytest.raises(HotPathUnavailable):   # ... touching the table is not
+        ae.add_target(Target(m, 7, np.zeros(3), Trajectory((1, 0, 0), (0, 0, 0), 0.0)))
+
+
+def test_product_package_never_imports_the_oracle():
+    for path in (ROOT / "zrk_modulation_amd").rglob("*.py"):
+        text = path.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f"{path} imports the oracle"
+        assert "libzrk_oracle" not in text and "zrk_oracle" not in text, f"{path} loads the oracle library"
+    for path in (ROOT / "zrk_modulation_amd").rglob("*.hip"):
+        assert "zrk_oracle" not in path.read_text()
+
+
+def test_manager_schedules_by_class_name_and_sorts_by_relevance():
+    """SURVEY.md 5.9-1 and 5.9-12 (reference modules/Manager.py:58, :123-127)."""
+    from zrk_modulation_amd.modules.BaseMessage import BaseMessage
+    from zrk_modulation_amd.modules.constants import MessageType
+    from zrk_modulation_amd.modules.Manager import Manager
+    order = []
+
+    def make(name):
+        return type(name, (), {"id": name, "step": lambda self: order.append(type(self).__name__)})()
+
+    m = Manager()
+    for n in ("Zeta", "CombatControlPoint", "SectorRadar", "MissileLauncher", "AirEnv", "Alpha"):
+        m.add_module(make(n))
+    second_radar = make("SectorRadar")
+    m.add_module(second_radar)
+    m.time.set_dt(10)
+    m.run_simulation(10)
+    assert order == ["AirEnv", "SectorRadar", "SectorRadar", "MissileLauncher", "CombatControlPoint", "Zeta", "Alpha"]
+    assert m.time.get_time() == 10
+    a = BaseMessage(MessageType.MISSILE_POS, 1)
+    b = BaseMessage(MessageType.MISSILE_COUNT_REQUEST, 2, relevance=3)
+    c = BaseMessage(MessageType.MISSILE_POS, 3)
+    for x in (a, b, c):
+        m.add_message(x, step_time=50)
+    assert m.give_messages(50) == [b, a, c] and a.send_time == 50
+    assert m.give_messages_by_type(MessageType.MISSILE_POS, step_time=50) == [a, c]
+    assert m.give_messages_by_id(None, step_time=50) == [b, a, c]
+
+
+def test_message_shapes_and_quirks():
+    from zrk_modulation_amd.modules import Messages as M
+    from zrk_modulation_amd.modules.constants import MessageType
+    d = M.DestroyedMissileId(sender_id=5, missile_id=3005, receiver_id=0, self_detonation=True)
+    assert d.missile_id == (3005,) and d.type == MessageType.DESTROYED_MISSILE
+    det = M.MissileDetonateMessage(sender_id=9, target_id=None, self_detonation=True)
+    assert (det.missile_id, det.target_id, det.receiver_id) == (9, None, None)
+    assert M.MissileCountRequestMessage(sender_id=0).relevance == 3
+    assert len(list(MessageType)) == 18
+
+
+def test_scan_state_machine_matches_the_oracle_and_keeps_the_quirks():
+    """reference modules/Radar.py:96-117: azimuth wraps to elevation_start, unknown modes never move."""
+    from oracle import oracle as O
+    from zrk_modulation_amd.engine import scan_mode_code, scan_next
+    L = O.lib()
+    g = np.random.Generator(np.random.PCG64(3))
+    for _ in range(300):
+        mode = ["horizontal", "vertical", "spiral"][g.integers(3)]
+        azr, azs, els, el0 = g.uniform(10, 360), g.uniform(0.5, 200), g.uniform(0, 40), g.uniform(0, 30)
+        caz, cel = g.uniform(0, 360), g.uniform(0, 90)
+        a, e = caz, cel
+        ca, ce = C.c_double(caz), C.c_double(cel)
+        for _ in range(50):
+            a, e = scan_next(scan_mode_code(mode), azr, azs, els, el0, a, e)
+            L.zo_scan_next(O.SCAN_MODES.get(mode, 2), azr, azs, els, el0, C.byref(ca), C.byref(ce))
+            assert (a, e) == (ca.value, ce.value)
+    # the stock radar flips 0 <-> 180
+    a, e = 0.0, 0.0
+    seq = []
+    for _ in range(4):
+        a, e = scan_next(0, 180.0, 180.0, 0.0, 0.0, a, e)
+        seq.append(a)
+    assert seq == [180.0, 0.0, 180.0, 0.0]
+
+
+def test_c_scan_advance_matches_python(tmp_path):
+    """zrk_scan_advance (host function of the library) against the Python state machine."""
+    from zrk_modulation_amd import _lib
+    from zrk_modulation_amd.engine import scan_next
+    lib = _lib.load()
+    g = np.random.Generator(np.random.PCG64(11))
+    R = 8
+    rad = (_lib.ZrkRadar * R)()
+    sc = (_lib.ZrkScan * R)()
+    py = []
+    for r in range(R):
+        rad[r].cur_azimuth, rad[r].azimuth_range = g.uniform(0, 360), g.uniform(10, 360)
+        rad[r].cur_elevation, rad[r].elevation_range = g.uniform(0, 90), g.uniform(5, 180)
+        sc[r].azimuth_speed, sc[r].elevation_speed, sc[r].elevation_start = g.uniform(1, 200), g.uniform(0, 30), g.uniform(0, 20)
+        sc[r].mode = r % 3
+        py.append([rad[r].cur_azimuth, rad[r].cur_elevation])
+    for _ in range(100):
+        assert lib.zrk_scan_advance(rad, sc, R) == 0
+        for r in range(R):
+            py[r] = list(scan_next(sc[r].mode, rad[r].azimuth_range, sc[r].azimuth_speed, sc[r].elevation_speed,
+                                   sc[r].elevation_start, py[r][0], py[r][1]))
+            assert py[r] == [rad[r].cur_azimuth, rad[r].cur_elevation]
+
+
+def test_synthetic_scenario_is_seeded_and_matches_the_survey_definition():
+    from zrk_modulation_amd import scenario as S
+    ids, sp, vel, t0 = S.synthetic_targets(1000, 1236)
+    ids2, sp2, _, _ = S.synthetic_targets(1000, 1236)
+    assert np.array_equal(sp, sp2) and ids[0] == 1000 and (t0 == 0).all()
+    assert (np.abs(sp[:, :2]) <= 60e3).all() and (sp[:, 2] >= 100).all() and (sp[:, 2] <= 12e3).all()
+    rs = S.synthetic_radars(4)
+    assert rs[2]["position"] == [2000.0, 0.0, 0.0] and rs[0]["azimuth_range"] == 90.0
+    assert S.missile_targets(100000, 1000)[:3].tolist() == [0, 100, 200]
+    assert S.WORKLOADS["C2"] == (100_000, 4, 1_000) and S.WORKLOADS["C3"] == (1_000_000, 16, 10_000)

@@ -37,7 +37,7 @@ def scan_next(mode, az_range, az_speed, el_speed, el_start, caz, cel):
 
 
 class DeviceSim:
-    """Replay surface shared with oracle.OracleSim (tests/helpers.replay_l1)."""
+    """L1 boundary as the reference's modules use it; the surface tests/helpers.replay_l1 drives."""
 
     def __init__(self, dt_ms, device=None, capacity=1024, missile_capacity=64, exact_only=False):
         self.store = EntityStore(device, capacity, missile_capacity)
