@@ -43,6 +43,7 @@ def build_engine(workload, rank, world, device, seed_off=0):
     stride = n + m                                   # global index space: shard g starts at g * stride
     eng = HotPathEngine(device=device, dt_ms=10, seed=S.SEEDS[workload], noise="philox", gid0=rank * stride)
     eng.load(ids, sp, vel, t0, radars, missile_capacity=m, union_capacity=(n + m) if world > 1 else None)
+    # (the exchange buffers are re-sized to the observed detection count after warm-up, see main)
     if world == 1:
         eng.enable_lists()
     launched = eng.launch_missiles(S.missile_targets(n, m))
@@ -142,32 +143,56 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # ZRK_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks
+    backend = os.environ.get("ZRK_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
     eng, info = build_engine(args.workload, rank, world, device)
-    ex = None
-    if world > 1:
+    # N > 1: two packed buffers / exchanges in flight, so the all-gather of tick t (RCCL's own stream)
+    # overlaps the sweep of tick t+1; a buffer is reused only after its collective has been waited for
+    xchg = {"ex": [], "buf": [], "work": [None, None], "tick": 0}
+
+    def size_exchange(capacity):
         from zrk_modulation_amd.exchange import DetectionExchange
-        ex = DetectionExchange(eng.packed.numel() - 1, device)
+        xchg["ex"] = [DetectionExchange(capacity, device) for _ in range(2)]
+        xchg["buf"] = [torch.zeros(capacity + 1, dtype=torch.int64, device=device) for _ in range(2)]
+        xchg["work"] = [None, None]
+
+    def drain_exchange():
+        for k, w in enumerate(xchg["work"]):
+            if w is not None:
+                w.wait()
+                xchg["work"][k] = None
 
     def run_ticks(k, sweep_ms=None):
         if world == 1:
             eng.run(k, sweep_ms=sweep_ms, prof_stride=PROF_STRIDE)
-        else:
-            for j in range(k):
-                one = None
-                if sweep_ms is not None and j % PROF_STRIDE == 0:
-                    one = np.zeros(1, np.float32)
-                eng.run(1, sweep_ms=one, prof_stride=1)
-                ex.all_gather(eng.packed)
-                if one is not None:
-                    sweep_ms[j // PROF_STRIDE] = one[0]
+            return
+        for j in range(k):
+            b = xchg["tick"] & 1
+            if xchg["work"][b] is not None:
+                xchg["work"][b].wait()
+            eng.packed = xchg["buf"][b]
+            one = np.zeros(1, np.float32) if (sweep_ms is not None and j % PROF_STRIDE == 0) else None
+            eng.run(1, sweep_ms=one, prof_stride=1)
+            xchg["work"][b] = xchg["ex"][b].all_gather(eng.packed, async_op=True)
+            xchg["tick"] += 1
+            if one is not None:
+                sweep_ms[j // PROF_STRIDE] = one[0]
+
+    if world > 1:
+        size_exchange(eng.packed.numel() - 1)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -176,15 +201,26 @@ def main():
             torch.cuda.synchronize(device)
 
     run_ticks(args.warmup)
+    overflow = False
+    if world > 1:
+        # size the fixed exchange buffers from what the warm-up saw (1.5x the largest per-rank count)
+        drain_exchange()
+        seen = torch.tensor([max(max(e.counts()) for e in xchg["ex"])], dtype=torch.int64, device=device)
+        dist.all_reduce(seen, op=dist.ReduceOp.MAX)
+        size_exchange(int(seen.item() * 1.5) + 1024)
     barrier()
     live0 = eng.alive_count()
     sweep_ms = np.zeros((args.steps + PROF_STRIDE - 1) // PROF_STRIDE, np.float32)
     barrier()
     t0 = time.perf_counter()
     run_ticks(args.steps, sweep_ms)
+    if world > 1:
+        drain_exchange()
     barrier()
     elapsed = time.perf_counter() - t0
     live1 = eng.alive_count()
+    if world > 1:
+        overflow = any(e.overflowed() for e in xchg["ex"])
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=device)
     units = torch.tensor([float(min(live0, live1)) * args.steps], dtype=torch.float64, device=device)
@@ -207,13 +243,17 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {info['n']} AirObjects, {info['R']} SectorRadars, "
                                    f"{info['launched']}/{info['m']} missiles in flight per GPU, dt=10 ms, "
-                                   f"Philox measurement noise, per-radar compaction"
-                                   + (", per-tick RCCL all-gather of the packed detection list" if world > 1 else ""),
+                                   f"Philox measurement noise, "
+                                   + ("packed union compaction + per-tick RCCL all-gather of the detection list, "
+                                      "overlapped with the next sweep" if world > 1 else "per-radar compaction"),
                        "entities_per_gpu": n_slots, "live_per_gpu": int(live1), "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_tick_sweep",
                          "avg_kernel_us": sweep_avg_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if world > 1:
+            out["config"]["exchange_entries_per_rank"] = xchg["ex"][0].capacity
+            out["config"]["exchange_overflow"] = bool(overflow)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(info, eng, args.cpu_budget)
         else:

@@ -22,15 +22,24 @@ class DetectionExchange:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.capacity = int(capacity)
         self.gathered = torch.zeros(self.world, self.capacity + 1, dtype=torch.int64, device=device)
+        backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self._flat = backend == "nccl" or torch.device(device).type == "cpu"
 
-    def all_gather(self, packed):
-        """packed: int64[capacity+1] from zrk_compact on this rank.  Returns int64[world, capacity+1]."""
+    def all_gather(self, packed, async_op=False):
+        """packed: int64[capacity+1] from zrk_compact on this rank.  Fills and returns
+        int64[world, capacity+1]; with async_op=True returns the work handle instead (wait() on it
+        before reading `gathered` or overwriting `packed`), so the exchange of tick t overlaps the
+        sweep of tick t+1."""
         assert packed.numel() == self.capacity + 1
         if self.world == 1:
             self.gathered[0].copy_(packed)
-        else:
-            dist.all_gather_into_tensor(self.gathered.view(-1), packed, group=self.group)
-        return self.gathered
+            return None if async_op else self.gathered
+        if self._flat:
+            work = dist.all_gather_into_tensor(self.gathered.view(-1), packed, group=self.group, async_op=async_op)
+        else:                       # backends without the flat form for this device type
+            work = dist.all_gather([self.gathered[g] for g in range(self.world)], packed, group=self.group,
+                                   async_op=async_op)
+        return work if async_op else self.gathered
 
     def counts(self):
         """Per-rank detection counts (synchronises)."""
