@@ -45,7 +45,9 @@ extern "C" {
 typedef struct zrk_ctx zrk_ctx;
 
 /* Entity table: AirEnv's object list (modules/AirEnv.py:24) as SoA columns.
- * Slots are never reused; slot order is list order (targets, then missiles as appended). */
+ * Rows are never reused.  Unless list_index says otherwise, row order is list order (targets, then
+ * missiles as appended).  Everything that names an entity across this ABI (missile `slot` / `target`,
+ * kill lists, launch requests, event rows) is a ROW; detection lists hold LIST indices. */
 typedef struct {
     int64_t capacity;               /* plane stride of every vec3 column */
     const double *start_pos;        /* DEVICE [3][cap]  Trajectory.start_pos   modules/AirObject.py:20 */
@@ -55,7 +57,12 @@ typedef struct {
     const uint8_t *kind;            /* DEVICE [cap]     0 target, 1 missile */
     double *pos[2];                 /* DEVICE [3][cap] x2  obj.pos, double-buffered: pos[cur] is this tick's,
                                        pos[cur^1] holds what prev_pos aliases (modules/AirObject.py:41) */
-    uint32_t *vis_mask;             /* DEVICE [cap]     bit r = seen by radar r this tick */
+    uint32_t *vis_mask;             /* DEVICE [cap]     bit r = seen by radar r this tick; indexed by LIST index */
+    const int32_t *list_index;      /* DEVICE [cap] or NULL.  NULL: row i of the table is element i of AirEnv's
+                                       list.  Otherwise the rows may be stored in any order (e.g. spatially sorted,
+                                       which makes waves coherent) and list_index[row] is the element's position in
+                                       the list: detection lists, the noise key and the "already stepped this tick"
+                                       rule of Missile.step follow the list, never the storage order. */
 } zrk_entities;
 
 /* The fields SectorRadar.find_visible_objects reads (modules/Radar.py:44-73). */

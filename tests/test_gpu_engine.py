@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _engine(n, R, m, seed, noise, lists=True, union=False):
+def _engine(n, R, m, seed, noise, lists=True, union=False, sort=True):
     from zrk_modulation_amd import scenario as S
     from zrk_modulation_amd.engine import HotPathEngine
     ids, sp, vel, t0 = S.synthetic_targets(n, seed)
@@ -22,7 +22,7 @@ def _engine(n, R, m, seed, noise, lists=True, union=False):
             rd["scan_mode"] = "vertical"
         rd["azimuth_start"] = 20.0 * k
     eng = HotPathEngine(device="cuda:0", dt_ms=500, seed=4242, noise=noise, gid0=0)
-    eng.load(ids, sp, vel, t0, radars, missile_capacity=m, union_capacity=(n + m) if union else None)
+    eng.load(ids, sp, vel, t0, radars, missile_capacity=m, union_capacity=(n + m) if union else None, sort=sort)
     if lists:
         eng.enable_lists()
     # closer targets so that missiles arrive within the test
@@ -39,13 +39,15 @@ class OracleMirror:
         self.O, self.L = O, O.lib()
         st = eng.store
         n = self.n = st.n_uploaded
-        self.sp = np.ascontiguousarray(st.h_sp[:n].T).reshape(-1); self.vel = np.ascontiguousarray(st.h_vel[:n].T).reshape(-1)
-        self.t0 = st.h_t0[:n].copy(); self.pos = np.ascontiguousarray(st.h_pos0[:n].T).reshape(-1).copy()
+        L = eng.list_view                                 # table rows -> AirEnv list order
+        self.lidx = st.h_lidx[:n].astype(np.int64) if st.h_lidx is not None else np.arange(n)
+        self.sp = np.ascontiguousarray(L(st.h_sp[:n]).T).reshape(-1); self.vel = np.ascontiguousarray(L(st.h_vel[:n]).T).reshape(-1)
+        self.t0 = L(st.h_t0[:n]).copy(); self.pos = np.ascontiguousarray(L(st.h_pos0[:n]).T).reshape(-1).copy()
         self.prev = self.pos.copy(); self.pv = np.zeros(n, np.uint8); self.alive = np.ones(n, np.uint8)
-        self.kind = st.h_kind[:n].copy(); self.mrow = np.full(n, -1, np.int32)
+        self.kind = L(st.h_kind[:n]).copy(); self.mrow = np.full(n, -1, np.int32)
         m = self.m = st.m
-        self.mrow[st.hm_slot[:m]] = np.arange(m, dtype=np.int32)
-        self.m_tgt = st.hm_tgt[:m].copy()
+        self.mrow[self.lidx[st.hm_slot[:m]]] = np.arange(m, dtype=np.int32)
+        self.m_tgt = self.lidx[st.hm_tgt[:m]].astype(np.int32)
         self.m_radius = st.dm_radius[:m].cpu().numpy().copy(); self.m_period = st.dm_period[:m].cpu().numpy().copy()
         self.m_status = np.ones(max(m, 1), np.uint8)
         self.ev = (np.zeros(max(m, 1), np.int32), np.zeros(max(m, 1), np.int32), np.zeros(max(m, 1), np.uint8))
@@ -91,7 +93,7 @@ def _device_noise_table(eng, tick, R, n):
     import torch
     st = eng.store
     tab = torch.zeros(R, n, 3, dtype=torch.float64, device=st.device)
-    for r in range(R):
+    for r in range(R):            # entity key = gid0 + LIST index, so entity0 + i enumerates the list
         st.ctx.check(st.lib.zrk_selftest_noise(st.ctx.handle, eng.seed, tick, r, eng.gid0, tab[r].data_ptr(), n, None), "noise")
     return np.ascontiguousarray(tab.cpu().numpy()).reshape(-1)
 
@@ -99,13 +101,14 @@ def _device_noise_table(eng, tick, R, n):
 def _compare_tick(eng, mir, events, tag):
     st = eng.store
     n = st.n_uploaded
-    vis = st.d_vis[:n].cpu().numpy().view(np.uint32)
+    vis = st.d_vis[:n].cpu().numpy().view(np.uint32)               # already indexed by list index
     assert np.array_equal(vis, mir.vis), f"{tag}: visibility masks differ"
-    P = st.host_pos("cur")
+    P = eng.list_view(st.host_pos("cur"))
     assert np.array_equal(np.ascontiguousarray(P.T).reshape(-1).view(np.uint64), mir.pos.view(np.uint64)), \
         f"{tag}: position bits differ"
     k = int(st.dm_evn.item()) if st.m else 0
-    got = list(zip(st.dm_evm[:k].cpu().tolist(), st.dm_evt[:k].cpu().tolist()))
+    to_list = lambda rows: [int(mir.lidx[r]) if r >= 0 else -1 for r in rows]      # noqa: E731  event rows -> list indices
+    got = list(zip(to_list(st.dm_evm[:k].cpu().tolist()), to_list(st.dm_evt[:k].cpu().tolist())))
     assert got == events, f"{tag}: detonation events differ: {got} vs {events}"
     alive = st.d_alive[:n].cpu().numpy()
     # device tombstones lag one tick exactly like the reference's (applied at the start of the next tick)
@@ -141,6 +144,12 @@ def test_run_k_ticks_equals_k_single_ticks():
     for _ in range(40):
         b.run(1)
     assert np.array_equal(a.store.host_pos("cur"), b.store.host_pos("cur"))
+    c = _engine(5000, 4, 100, seed=5, noise="philox", sort=False)[0]      # rows in list order: same observables
+    c.run(40)
+    assert np.array_equal(a.list_view(a.store.host_pos("cur")), c.store.host_pos("cur"))
+    assert np.array_equal(a.store.d_vis[:a.store.n_uploaded].cpu().numpy(), c.store.d_vis[:c.store.n_uploaded].cpu().numpy())
+    for x, y in zip(a.detections(), c.detections()):
+        assert np.array_equal(x, y)
     assert np.array_equal(a.store.d_alive.cpu().numpy(), b.store.d_alive.cpu().numpy())
     for x, y in zip(a.detections(), b.detections()):
         assert np.array_equal(x, y)

@@ -34,6 +34,7 @@ class ZrkEntities(C.Structure):
         ("kind", C.c_void_p),
         ("pos", C.c_void_p * 2),
         ("vis_mask", C.c_void_p),
+        ("list_index", C.c_void_p),
     ]
 
 

@@ -37,7 +37,7 @@ struct RadarHot {
     float elx, ely, ehx, ehy;   // unit vectors of the (clamped) azimuth edges
     float s_lo_up, s_hi_up;     // sin(elevation) bounds for dz >= 0
     float s_lo_dn, s_hi_dn;     // and for dz < 0 (elevation wraps to (90,180])
-    float seam_g;               // kGuard when elevation 0 / 180 must be told apart, else -1
+    float az_guard;             // kGuard * max_distance: farther than this outside an azimuth edge = certainly out
     float az_sgn;               // +1: inside = both edge tests (width <= 180); -1: either (edges stored negated)
     uint32_t pad[2];
 };
@@ -62,8 +62,9 @@ struct RadarBlock {                                 // lives in the kernel-argum
 struct SweepParams {
     const double *sp, *vel, *t0;
     const uint8_t *alive;
+    const int32_t *lidx;        // list index of each table row (NULL: the table is in list order)
     double *pos;
-    uint32_t *vis;
+    uint32_t *vis;              // indexed by LIST index
     int32_t *block_counts;      // [R][nb]
     int64_t n, cap;
     double t;
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P)
 
     uint32_t mask = 0;
     const bool live = (i < P.n) && P.alive[i];
+    const int64_t li = (P.lidx && i < P.n) ? (int64_t)P.lidx[i] : i;   // where this row sits in AirEnv's list
     if (live) {
         const int64_t cap = P.cap;
         double x, y, z;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P)
             x = P.pos[i]; y = P.pos[cap + i]; z = P.pos[2 * cap + i];
         }
         NoiseState ns{0u, 0u, 0u, 0u};
-        if (PHILOX) ns = noise_init(P.seed, P.tick, (uint64_t)(P.gid0 + i));
+        if (PHILOX) ns = noise_init(P.seed, P.tick, (uint64_t)(P.gid0 + li));   // keyed by list index: layout-independent
         for (int r = 0; r < P.R; ++r) {
             // one scalar-load burst for the whole hot record, resident in SGPRs before any use
             uint32_t w[18];
@@ -205,14 +207,20 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P)
             const float ehx = __builtin_bit_cast(float, w[10]), ehy = __builtin_bit_cast(float, w[11]);
             const float s_lo_up = __builtin_bit_cast(float, w[12]), s_hi_up = __builtin_bit_cast(float, w[13]);
             const float s_lo_dn = __builtin_bit_cast(float, w[14]), s_hi_dn = __builtin_bit_cast(float, w[15]);
-            const float az_sgn = __builtin_bit_cast(float, w[17]);
+            const float az_guard = __builtin_bit_cast(float, w[16]), az_sgn = __builtin_bit_cast(float, w[17]);
 
             const double dx = x - rpx, dy = y - rpy, dz = z - rpz;
             const float fx = (float)dx, fy = (float)dy, fz = (float)dz;
             const float d2f = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+            // float32 range gate.  With rows stored in spatial order the lanes of a wave mostly agree,
+            // so a wave none of whose lanes is in range (or, below, anywhere near the azimuth wedge)
+            // leaves the radar here instead of paying for the rest of the classification.
+            const bool in_range = d2f <= d2f_out;
+            if (!__ballot(in_range)) continue;
             const float cl = __builtin_fmaf(elx, fy, -(ely * fx));     // az_sgn * cross(e_lo, p)
             const float ch = __builtin_fmaf(fx, ehy, -(fy * ehx));     // az_sgn * cross(p, e_hi)
             const float m_az = az_sgn * fminf(cl, ch);                 // > 0 inside the azimuth sector [m]
+            if (!__ballot(in_range & !(m_az < -az_guard))) continue;   // every lane certainly outside the wedge
             const float dist = __builtin_amdgcn_sqrtf(d2f);
             // elevation: el = theta for dz >= 0, 180 + theta for dz < 0 (sign taken in binary64, so a
             // tiny negative dz that rounds to -0.0f still selects the lower-hemisphere bounds)
@@ -226,7 +234,6 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P)
             // (degenerate ranges are encoded by the host as d2f_out = inf, d2f_in = -1 -> always exact).
             const float t = fminf(fminf(m_az, a), b);
             const float gd = kGuard * dist;
-            const bool in_range = d2f <= d2f_out;
             bool vis = in_range & (t > gd);
             const bool amb = in_range & ((fabsf(t) <= gd) | !(d2f < d2f_in));
             if (amb) vis = visible_exact(P.rb.cold[r], dx, dy, dz);
@@ -243,7 +250,8 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P)
             P.pos[i] = x; P.pos[cap + i] = y; P.pos[2 * cap + i] = z;
         }
     }
-    if (i < P.n) P.vis[i] = mask;
+    if (i < P.n) P.vis[li] = mask;
+    if (P.lidx) return;         // rows are not in list order: k_count_blocks counts from vis instead
 
     // per-workgroup detection counts per radar (row R: seen by any radar), consumed by the scan:
     // lane r of each wave collects the wave's count for radar r, then one LDS add per lane
@@ -260,6 +268,31 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P)
     if (lane <= P.R && cnt_lane) atomicAdd(&s_cnt[lane], cnt_lane);
     __syncthreads();
     if (tid <= P.R) P.block_counts[(int64_t)tid * P.nb + blockIdx.x] = s_cnt[tid];
+}
+
+// Per-block detection counts straight from vis_mask, for tables whose rows are not in list order
+// (then the sweep's workgroups do not coincide with the compaction's blocks of the list).
+__global__ __launch_bounds__(ZRK_BLOCK) void k_count_blocks(const uint32_t *__restrict__ vis, int64_t n, int R, int nb,
+                                                            int32_t *__restrict__ counts)
+{
+    __shared__ int s_cnt[ZRK_MAX_RADARS + 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t i = (int64_t)blockIdx.x * ZRK_BLOCK + tid;
+    if (tid <= ZRK_MAX_RADARS) s_cnt[tid] = 0;
+    __syncthreads();
+    const uint32_t mask = (i < n) ? vis[i] : 0u;
+    int cnt_lane = 0;
+    for (int r = 0; r < R; ++r) {
+        const unsigned long long b = __ballot((mask >> r) & 1u);
+        cnt_lane = (lane == r) ? (int)__popcll(b) : cnt_lane;
+    }
+    {
+        const unsigned long long b = __ballot(mask != 0u);
+        cnt_lane = (lane == R) ? (int)__popcll(b) : cnt_lane;
+    }
+    if (lane <= R && cnt_lane) atomicAdd(&s_cnt[lane], cnt_lane);
+    __syncthreads();
+    if (tid <= R) counts[(int64_t)tid * nb + blockIdx.x] = s_cnt[tid];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -401,7 +434,7 @@ __global__ void k_noise_apply(double *__restrict__ pos, int64_t cap, const int32
 // Missile.step 'active' branch for one row (modules/Missile.py:162-193).  Returns 0 none, 1 hit, 2 timeout.
 __device__ __forceinline__ uint8_t missile_step_row(const double *__restrict__ sp, const double *__restrict__ vel,
                                                     const double *__restrict__ t0, const uint8_t *alive,
-                                                    const double *pos_prev, int64_t cap,
+                                                    const int32_t *__restrict__ lidx, const double *pos_prev, int64_t cap,
                                                     const int32_t *__restrict__ m_slot, const int32_t *__restrict__ m_tgt,
                                                     const double *__restrict__ m_radius, double *__restrict__ m_period,
                                                     uint8_t *__restrict__ m_status, int64_t row, double t, double dts)
@@ -414,7 +447,8 @@ __device__ __forceinline__ uint8_t missile_step_row(const double *__restrict__ s
                      pz = sp[2 * cap + s] + vel[2 * cap + s] * d;
         const int32_t j = m_tgt[row];
         double tx, ty, tz;
-        if (alive[j] && j < s) {          // already stepped this tick (list order): fresh, noise-free
+        const bool earlier = lidx ? (lidx[j] < lidx[s]) : (j < s);
+        if (alive[j] && earlier) {        // already stepped this tick (list order): fresh, noise-free
             const double dj = t - t0[j];
             tx = sp[j] + vel[j] * dj; ty = sp[cap + j] + vel[cap + j] * dj; tz = sp[2 * cap + j] + vel[2 * cap + j] * dj;
         } else {                          // not stepped yet, or removed: what it held after last tick
@@ -436,14 +470,16 @@ __device__ __forceinline__ uint8_t missile_step_row(const double *__restrict__ s
 // One thread per in-flight missile (any table size); events are ordered by k_missile_events.
 __global__ void k_missile_step(const double *__restrict__ sp, const double *__restrict__ vel,
                                const double *__restrict__ t0, const uint8_t *__restrict__ alive,
-                               const double *__restrict__ pos_prev, int64_t cap, const int32_t *__restrict__ m_slot,
+                               const int32_t *__restrict__ lidx, const double *__restrict__ pos_prev, int64_t cap,
+                               const int32_t *__restrict__ m_slot,
                                const int32_t *__restrict__ m_tgt, const double *__restrict__ m_radius,
                                double *__restrict__ m_period, uint8_t *__restrict__ m_status,
                                uint8_t *__restrict__ ev_code, int64_t m, double t, double dts)
 {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= m) return;
-    ev_code[row] = missile_step_row(sp, vel, t0, alive, pos_prev, cap, m_slot, m_tgt, m_radius, m_period, m_status, row, t, dts);
+    ev_code[row] = missile_step_row(sp, vel, t0, alive, lidx, pos_prev, cap, m_slot, m_tgt, m_radius, m_period, m_status, row, t,
+                                    dts);
 }
 
 __device__ __forceinline__ void kill_one(uint8_t *alive, const double *src, double *dst, int64_t cap, int32_t s)
@@ -673,7 +709,7 @@ void derive_radar(const zrk_radar &hr, bool exact_only, RadarHot &h, RadarCold &
     h.d2f_in = plain_range ? (float)(c.d2_max * (1.0 - 1e-5)) : -1.f;
     h.d2f_out = plain_range ? (float)(c.d2_max * (1.0 + 1e-5)) : INFINITY;
     h.s_lo_up = h.s_lo_dn = 2.f; h.s_hi_up = h.s_hi_dn = -2.f;
-    h.seam_g = kGuard;
+    h.az_guard = plain_range ? (float)(kGuard * std::sqrt(c.d2_max) * 1.001) : INFINITY;
     h.az_sgn = 1.f;
     const bool finite = std::isfinite(c.az_lo) && std::isfinite(c.az_hi) && std::isfinite(c.el_lo) && std::isfinite(c.el_hi);
     if (!finite || exact_only) h.d2f_in = -1.f;   // decide every in-range pair in binary64
@@ -697,7 +733,6 @@ void derive_radar(const zrk_radar &hr, bool exact_only, RadarHot &h, RadarCold &
         h.s_lo_dn = (c.el_lo - 180.0 <= -90.0) ? -2.f : (float)std::sin(lo_d * deg);
         h.s_hi_dn = (c.el_hi >= 180.0) ? 2.f : (float)std::sin(hi_d * deg);
     }
-    if (c.el_lo <= 0.0 && c.el_hi >= 180.0) h.seam_g = -1.f;
 }
 
 }  // namespace
@@ -705,6 +740,7 @@ void derive_radar(const zrk_radar &hr, bool exact_only, RadarHot &h, RadarCold &
 struct zrk_ctx {
     int device;
     std::string err;
+    bool counts_from_sweep = true;     // did the last zrk_tick_sweep leave per-block counts in the workspace?
 };
 
 namespace {
@@ -775,7 +811,7 @@ ZRK_API int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int c
     if (n < 0 || n > e->capacity || (cur != 0 && cur != 1)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: n/cur out of range");
     if (n == 0) return 0;
     SweepParams P;
-    P.sp = e->start_pos; P.vel = e->velocity; P.t0 = e->start_time; P.alive = e->alive;
+    P.sp = e->start_pos; P.vel = e->velocity; P.t0 = e->start_time; P.alive = e->alive; P.lidx = e->list_index;
     P.pos = e->pos[cur]; P.vis = e->vis_mask;
     P.n = n; P.cap = e->capacity;
     P.t = (double)time_ms / 1000.0;                 // to_seconds, modules/AirObject.py:5-7
@@ -792,6 +828,7 @@ ZRK_API int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int c
         hipLaunchKernelGGL(k_tick_sweep<true>, dim3(P.nb), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P);
     else
         hipLaunchKernelGGL(k_tick_sweep<false>, dim3(P.nb), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P);
+    ctx->counts_from_sweep = (e->list_index == nullptr);
     return check_launch(ctx, "k_tick_sweep");
 }
 
@@ -811,6 +848,8 @@ ZRK_API int zrk_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R
     }
     const int nb = nblocks(n, ZRK_BLOCK);
     Workspace w = carve(workspace, nb);
+    if (!ctx->counts_from_sweep)
+        hipLaunchKernelGGL(k_count_blocks, dim3(nb), dim3(ZRK_BLOCK), 0, s, vis_mask, n, R, nb, w.counts);
     hipLaunchKernelGGL(k_scan_counts, dim3(R + 1), dim3(kScanThreads), 0, s, w.counts, w.offs, w.totals, nb);
     hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(ZRK_BLOCK), 0, s, vis_mask, n, R, nb, w.offs, w.totals, base_index,
                        det_idx, det_capacity, det_off, packed, packed_capacity, gid0);
@@ -839,8 +878,8 @@ ZRK_API int zrk_missile_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const
     }
     const double t = (double)time_ms / 1000.0, dts = (double)dt_ms / 1000.0;
     hipLaunchKernelGGL(k_missile_step, dim3(nblocks(m, 256)), dim3(256), 0, s, e->start_pos, e->velocity, e->start_time,
-                       e->alive, e->pos[cur ^ 1], e->capacity, mis->slot, mis->target, mis->radius, mis->period,
-                       mis->status, mis->ev_code, m, t, dts);
+                       e->alive, e->list_index, e->pos[cur ^ 1], e->capacity, mis->slot, mis->target, mis->radius,
+                       mis->period, mis->status, mis->ev_code, m, t, dts);
     if (m <= 1024 * (int64_t)kMissileItems) {
         hipLaunchKernelGGL(k_missile_finish, dim3(1), dim3(1024), 0, s, mis->ev_code, mis->slot, mis->target, m,
                            mis->ev_missile, mis->ev_target, mis->ev_count, apply_kills, e->alive, e->pos[cur],

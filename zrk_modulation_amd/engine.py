@@ -144,6 +144,18 @@ class DeviceSim:
         self.time_ms += self.dt_ms
 
 
+def morton_order_xy(start_pos, bits=12):
+    """Row order that keeps neighbours in (x, y) together: argsort of the interleaved cell bits."""
+    xy = np.asarray(start_pos, np.float64)[:, :2]
+    lo, hi = xy.min(0), xy.max(0)
+    q = ((xy - lo) / np.maximum(hi - lo, 1e-9) * ((1 << bits) - 1)).astype(np.uint64)
+    code = np.zeros(len(xy), np.uint64)
+    for b in range(bits):
+        code |= ((q[:, 0] >> np.uint64(b)) & np.uint64(1)) << np.uint64(2 * b)
+        code |= ((q[:, 1] >> np.uint64(b)) & np.uint64(1)) << np.uint64(2 * b + 1)
+    return np.argsort(code, kind="stable")
+
+
 class HotPathEngine:
     """Headless L1 loop for large scenes: the whole tick stays on the device (events, tombstones,
     compaction) and `run(K)` enqueues K ticks through one C call (zrk_run_ticks).
@@ -166,13 +178,31 @@ class HotPathEngine:
         self.R = 0
 
     def load(self, ids, start_pos, velocity, start_time, radars, missile_capacity=0, det_capacity=None,
-             union_capacity=None):
-        """ids/start_pos/velocity/start_time: target columns; radars: list of dicts with the
-        SectorRadar constructor fields (reference modules/Radar.py:13-42)."""
+             union_capacity=None, sort=True):
+        """ids/start_pos/velocity/start_time: target columns in LIST order; radars: list of dicts with
+        the SectorRadar constructor fields (reference modules/Radar.py:13-42).
+
+        sort=True stores the rows in Morton order of their (x, y) start position: consecutive rows
+        are neighbours in space, so the 64 lanes of a wave mostly agree on whether a radar sees them
+        and the divergent parts of the sweep (noise draw, binary64 fallback) run for few waves.
+        Every observable stays in list order (detection lists, noise keys, event order): the table
+        carries a list_index column (include/zrk_hot.h)."""
         C, _lib = self._C, self._lib
         n = len(ids)
+        ids = np.asarray(ids); start_pos = np.asarray(start_pos, np.float64).reshape(n, 3)
+        velocity = np.asarray(velocity, np.float64).reshape(n, 3)
+        start_time = np.broadcast_to(np.asarray(start_time, np.float64), (n,))
         st = self.store = EntityStore(self.device, n + missile_capacity, max(missile_capacity, 64))
-        st.add_entities(ids, start_pos, velocity, start_time, kind=0)
+        self.n_list = n                                  # length of AirEnv's list so far
+        if sort and n > 1:
+            order = morton_order_xy(start_pos)
+            st.add_entities(ids[order], start_pos[order], velocity[order], start_time[order], kind=0,
+                            list_index=order.astype(np.int32))
+            self.row_of_list = np.empty(n, np.int64)
+            self.row_of_list[order] = np.arange(n)
+        else:
+            st.add_entities(ids, start_pos, velocity, start_time, kind=0)
+            self.row_of_list = None
         st.flush()
         self.R = R = len(radars)
         self.c_radars = (_lib.ZrkRadar * max(R, 1))()
@@ -215,6 +245,9 @@ class HotPathEngine:
         k = len(target_slots)
         if k == 0:
             return 0
+        target_slots = np.asarray(target_slots, np.int64)
+        if self.row_of_list is not None:                 # callers speak list indices, the table speaks rows
+            target_slots = self.row_of_list[target_slots]
         req = np.zeros(k, dtype=np.dtype([("target_slot", "<i4"), ("_pad", "<i4"), ("missile_pos", "<f8", 3),
                                           ("speed", "<f8"), ("period", "<f8")]))
         req["target_slot"] = np.asarray(target_slots, np.int32)
@@ -230,8 +263,13 @@ class HotPathEngine:
         if len(ok) == 0:
             return 0
         t0 = self.loop.time_ms / 1000
+        li = None
+        if self.row_of_list is not None:
+            li = np.arange(self.n_list, self.n_list + len(ok), dtype=np.int32)
+            self.row_of_list = np.concatenate([self.row_of_list, st.n + np.arange(len(ok))])
+        self.n_list += len(ok)
         first = st.add_entities(id0 + ok, np.broadcast_to(np.asarray(launcher_pos, np.float64), (len(ok), 3)),
-                                res["velocity"][ok], t0, kind=1)
+                                res["velocity"][ok], t0, kind=1, list_index=li)
         st.flush()
         st.add_missile_rows(np.arange(first, first + len(ok), dtype=np.int32),
                             np.asarray(target_slots, np.int32)[ok], radius, period)
@@ -267,6 +305,10 @@ class HotPathEngine:
         off = self.det_off[:self.R + 1].cpu().numpy()
         idx = self.det_idx[:off[-1]].cpu().numpy()
         return [idx[off[r]:off[r + 1]] for r in range(self.R)]
+
+    def list_view(self, rows_first):
+        """Reorder a per-row array (first axis = table rows) into list order."""
+        return rows_first if self.row_of_list is None else rows_first[self.row_of_list]
 
     def radar_state(self):
         return [(self.c_radars[r].cur_azimuth, self.c_radars[r].cur_elevation) for r in range(self.R)]

@@ -77,6 +77,8 @@ class EntityStore:
         self.h_sp = np.zeros((0, 3)); self.h_vel = np.zeros((0, 3)); self.h_t0 = np.zeros(0)
         self.h_pos0 = np.zeros((0, 3))
         self.h_alive = np.zeros(0, np.uint8)
+        self.h_lidx = None         # list index of each row when rows are not stored in list order
+        self.d_lidx = None
         self.slots_of_id = {}
         # host mirror of the missile table's static columns
         self.hm_slot = np.zeros(0, np.int32); self.hm_tgt = np.zeros(0, np.int32)
@@ -112,6 +114,12 @@ class EntityStore:
         e.alive, e.kind = self.d_alive.data_ptr(), self.d_kind.data_ptr()
         e.pos[0], e.pos[1] = self.d_pos[0].data_ptr(), self.d_pos[1].data_ptr()
         e.vis_mask = self.d_vis.data_ptr()
+        if self.h_lidx is not None:
+            old = self.d_lidx
+            self.d_lidx = torch.zeros(cap, dtype=torch.int32, device=dev)
+            if old is not None:
+                self.d_lidx[:self.n_uploaded] = old[:self.n_uploaded]
+            e.list_index = self.d_lidx.data_ptr()
         self.ents = e
         self._ws = None
         self._det_idx = None
@@ -155,8 +163,10 @@ class EntityStore:
         return self._det_idx
 
     # -- population -------------------------------------------------------------------------
-    def add_entities(self, ids, start_pos, velocity, start_time, kind=0, pos0=None):
-        """Append rows (host side); they reach the device at the next flush()."""
+    def add_entities(self, ids, start_pos, velocity, start_time, kind=0, pos0=None, list_index=None):
+        """Append rows (host side); they reach the device at the next flush().  `list_index` (all rows
+        or none, for the whole life of the store) says where each row sits in AirEnv's list when the
+        rows are stored in another order."""
         sp = np.asarray(start_pos, np.float64).reshape(-1, 3)
         k = sp.shape[0]
         vel = np.asarray(velocity, np.float64).reshape(k, 3)
@@ -169,6 +179,12 @@ class EntityStore:
         self.h_sp = np.concatenate([self.h_sp, sp]); self.h_vel = np.concatenate([self.h_vel, vel])
         self.h_t0 = np.concatenate([self.h_t0, t0]); self.h_pos0 = np.concatenate([self.h_pos0, p0])
         self.h_alive = np.concatenate([self.h_alive, np.ones(k, np.uint8)])
+        if list_index is not None:
+            assert self.h_lidx is not None or first == 0, "list_index must be given for every row or for none"
+            li = np.asarray(list_index, np.int32).reshape(k)
+            self.h_lidx = li.copy() if self.h_lidx is None else np.concatenate([self.h_lidx, li])
+        else:
+            assert self.h_lidx is None, "list_index must be given for every row or for none"
         if self.slots_of_id is not None and k <= 4096:
             for j in range(k):
                 self.slots_of_id.setdefault(int(ids[j]), []).append(first + j)
@@ -187,9 +203,11 @@ class EntityStore:
         a, b = self.n_uploaded, self.n
         if a == b:
             return
-        if b > self.cap:
-            self._alloc_entities(max(b, 2 * self.cap))
+        if b > self.cap or (self.h_lidx is not None and self.d_lidx is None):
+            self._alloc_entities(max(b, 2 * self.cap if b > self.cap else self.cap))
         dev = self.device
+        if self.h_lidx is not None:
+            self.d_lidx[a:b] = torch.from_numpy(np.ascontiguousarray(self.h_lidx[a:b])).to(dev)
         self.d_sp[:, a:b] = torch.from_numpy(np.ascontiguousarray(self.h_sp[a:b].T)).to(dev)
         self.d_vel[:, a:b] = torch.from_numpy(np.ascontiguousarray(self.h_vel[a:b].T)).to(dev)
         self.d_t0[a:b] = torch.from_numpy(np.ascontiguousarray(self.h_t0[a:b])).to(dev)
