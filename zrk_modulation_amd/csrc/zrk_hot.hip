@@ -75,6 +75,26 @@ struct SweepParams {
     RadarBlock rb;
 };
 
+// The missile phase rides along in other kernels' grids (its own launches would cost more in kernel
+// boundaries than in work): the per-row step as extra workgroups of the sweep, the ordered event list
+// and the tombstones as an extra workgroup of the count scan.  m == 0: nothing to do.
+struct MissileArgs {
+    const double *sp, *vel, *t0;
+    uint8_t *alive;
+    const int32_t *lidx;
+    const double *pos_cur;
+    double *pos_prev;
+    int64_t cap;
+    const int32_t *m_slot, *m_tgt;
+    const double *m_radius;
+    double *m_period;
+    uint8_t *m_status, *ev_code;
+    int32_t *ev_missile, *ev_target, *ev_count;
+    int64_t m;
+    double t, dts;
+    int32_t apply, _pad;
+};
+
 __device__ __forceinline__ double dot3(double ax, double ay, double az, double bx, double by, double bz)
 {
     return __builtin_fma(az, bz, __builtin_fma(ay, by, ax * bx));
@@ -166,9 +186,23 @@ __device__ __forceinline__ void noise_draw3(NoiseState &st, float sigma, float o
 // scalar-load burst per radar, no uniform branches (degenerate radars are encoded in the thresholds
 // by the host), predicates folded into two float minima, and only two divergent regions -- the
 // binary64 fallback for guard-band pairs and the noise draw for detections.
+__device__ uint8_t missile_step_row(const double *__restrict__ sp, const double *__restrict__ vel,
+                                    const double *__restrict__ t0, const uint8_t *alive,
+                                    const int32_t *__restrict__ lidx, const double *pos_prev, int64_t cap,
+                                    const int32_t *__restrict__ m_slot, const int32_t *__restrict__ m_tgt,
+                                    const double *__restrict__ m_radius, double *__restrict__ m_period,
+                                    uint8_t *__restrict__ m_status, int64_t row, double t, double dts);
+
 template <bool PHILOX>
-__global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P)
+__global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, const MissileArgs M)
 {
+    if ((int)blockIdx.x >= P.nb) {             // trailing workgroups: Missile.step for every in-flight row
+        const int64_t row = (int64_t)(blockIdx.x - P.nb) * ZRK_BLOCK + threadIdx.x;
+        if (row < M.m)
+            M.ev_code[row] = missile_step_row(M.sp, M.vel, M.t0, M.alive, M.lidx, M.pos_prev, M.cap, M.m_slot, M.m_tgt,
+                                              M.m_radius, M.m_period, M.m_status, row, M.t, M.dts);
+        return;
+    }
     __shared__ int s_cnt[ZRK_MAX_RADARS + 1];
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * ZRK_BLOCK + tid;
@@ -301,12 +335,19 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_count_blocks(const uint32_t *__re
 constexpr int kScanThreads = 1024;
 constexpr int kScanItems = 4;
 
+__device__ void missile_finish_entry(int *s_wave, const MissileArgs &M);
+
 __global__ __launch_bounds__(kScanThreads) void k_scan_counts(const int32_t *__restrict__ counts,
                                                               int32_t *__restrict__ offs,
-                                                              int32_t *__restrict__ totals, int nb)
+                                                              int32_t *__restrict__ totals, int nb, int rows,
+                                                              const MissileArgs M)
 {
     __shared__ int s_wave[kScanThreads / 64];
     __shared__ int s_carry;
+    if ((int)blockIdx.x >= rows) {              // the one extra workgroup: missile events + tombstones
+        missile_finish_entry(s_wave, M);
+        return;
+    }
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t *c = counts + (int64_t)r * nb;
     int32_t *o = offs + (int64_t)r * nb;
@@ -432,12 +473,12 @@ __global__ void k_noise_apply(double *__restrict__ pos, int64_t cap, const int32
 }
 
 // Missile.step 'active' branch for one row (modules/Missile.py:162-193).  Returns 0 none, 1 hit, 2 timeout.
-__device__ __forceinline__ uint8_t missile_step_row(const double *__restrict__ sp, const double *__restrict__ vel,
-                                                    const double *__restrict__ t0, const uint8_t *alive,
-                                                    const int32_t *__restrict__ lidx, const double *pos_prev, int64_t cap,
-                                                    const int32_t *__restrict__ m_slot, const int32_t *__restrict__ m_tgt,
-                                                    const double *__restrict__ m_radius, double *__restrict__ m_period,
-                                                    uint8_t *__restrict__ m_status, int64_t row, double t, double dts)
+__device__ uint8_t missile_step_row(const double *__restrict__ sp, const double *__restrict__ vel,
+                                    const double *__restrict__ t0, const uint8_t *alive,
+                                    const int32_t *__restrict__ lidx, const double *pos_prev, int64_t cap,
+                                    const int32_t *__restrict__ m_slot, const int32_t *__restrict__ m_tgt,
+                                    const double *__restrict__ m_radius, double *__restrict__ m_period,
+                                    uint8_t *__restrict__ m_status, int64_t row, double t, double dts)
 {
     uint8_t code = 0;
     const int32_t s = m_slot[row];
@@ -494,15 +535,13 @@ __device__ __forceinline__ void kill_one(uint8_t *alive, const double *src, doub
 // of this tick sees a half-applied removal.
 constexpr int kMissileItems = 16;
 
-__global__ __launch_bounds__(1024) void k_missile_finish(const uint8_t *__restrict__ ev_code,
-                                                         const int32_t *__restrict__ m_slot,
-                                                         const int32_t *__restrict__ m_tgt, int64_t m,
-                                                         int32_t *__restrict__ ev_missile,
-                                                         int32_t *__restrict__ ev_target,
-                                                         int32_t *__restrict__ ev_count, int apply, uint8_t *alive,
-                                                         const double *pos_cur, double *pos_prev, int64_t cap)
+__device__ __forceinline__ void missile_finish_block(int *s_wave, const uint8_t *__restrict__ ev_code,
+                                                     const int32_t *__restrict__ m_slot,
+                                                     const int32_t *__restrict__ m_tgt, int64_t m,
+                                                     int32_t *__restrict__ ev_missile, int32_t *__restrict__ ev_target,
+                                                     int32_t *__restrict__ ev_count, int apply, uint8_t *alive,
+                                                     const double *pos_cur, double *pos_prev, int64_t cap)
 {
-    __shared__ int s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (int)((m + 1023) / 1024);                 // consecutive rows per thread (<= kMissileItems)
     const int64_t row0 = (int64_t)tid * per;
@@ -538,6 +577,25 @@ __global__ __launch_bounds__(1024) void k_missile_finish(const uint8_t *__restri
             }
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void k_missile_finish(const uint8_t *__restrict__ ev_code,
+                                                         const int32_t *__restrict__ m_slot,
+                                                         const int32_t *__restrict__ m_tgt, int64_t m,
+                                                         int32_t *__restrict__ ev_missile,
+                                                         int32_t *__restrict__ ev_target,
+                                                         int32_t *__restrict__ ev_count, int apply, uint8_t *alive,
+                                                         const double *pos_cur, double *pos_prev, int64_t cap)
+{
+    __shared__ int s_wave[16];
+    missile_finish_block(s_wave, ev_code, m_slot, m_tgt, m, ev_missile, ev_target, ev_count, apply, alive, pos_cur,
+                         pos_prev, cap);
+}
+
+__device__ void missile_finish_entry(int *s_wave, const MissileArgs &M)
+{
+    missile_finish_block(s_wave, M.ev_code, M.m_slot, M.m_tgt, M.m, M.ev_missile, M.ev_target, M.ev_count, M.apply, M.alive,
+                         M.pos_cur, M.pos_prev, M.cap);
 }
 
 // Ordered event list from ev_code: one workgroup walks the (short) missile table in row order.
@@ -801,15 +859,39 @@ ZRK_API int64_t zrk_workspace_bytes(int64_t n_max)
     return (64 + 2 * (int64_t)(ZRK_MAX_RADARS + 1) * nb) * (int64_t)sizeof(int32_t);
 }
 
-ZRK_API int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_t time_ms,
-                           const zrk_radar *radars, int R, uint32_t flags, uint64_t seed, uint64_t tick,
-                           int64_t gid0, void *workspace, void *stream)
+namespace {
+
+MissileArgs no_missiles()
+{
+    MissileArgs M;
+    std::memset(&M, 0, sizeof(M));
+    return M;
+}
+
+MissileArgs missile_args(const zrk_entities *e, int cur, const zrk_missiles *mis, int64_t m, int64_t time_ms,
+                         int64_t dt_ms, int apply)
+{
+    MissileArgs M;
+    M.sp = e->start_pos; M.vel = e->velocity; M.t0 = e->start_time; M.alive = e->alive; M.lidx = e->list_index;
+    M.pos_cur = e->pos[cur]; M.pos_prev = e->pos[cur ^ 1]; M.cap = e->capacity;
+    M.m_slot = mis->slot; M.m_tgt = mis->target; M.m_radius = mis->radius; M.m_period = mis->period;
+    M.m_status = mis->status; M.ev_code = mis->ev_code;
+    M.ev_missile = mis->ev_missile; M.ev_target = mis->ev_target; M.ev_count = mis->ev_count;
+    M.m = m;
+    M.t = (double)time_ms / 1000.0; M.dts = (double)dt_ms / 1000.0;
+    M.apply = apply; M._pad = 0;
+    return M;
+}
+
+int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_t time_ms, const zrk_radar *radars,
+                 int R, uint32_t flags, uint64_t seed, uint64_t tick, int64_t gid0, void *workspace, void *stream,
+                 const MissileArgs &M)
 {
     if (!ctx || !e || !workspace || (R > 0 && !radars)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
     if (R < 0 || R > ZRK_MAX_RADARS)
         return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: radar count out of range");
     if (n < 0 || n > e->capacity || (cur != 0 && cur != 1)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: n/cur out of range");
-    if (n == 0) return 0;
+    if (n == 0 && M.m == 0) return 0;
     SweepParams P;
     P.sp = e->start_pos; P.vel = e->velocity; P.t0 = e->start_time; P.alive = e->alive; P.lidx = e->list_index;
     P.pos = e->pos[cur]; P.vis = e->vis_mask;
@@ -824,17 +906,29 @@ ZRK_API int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int c
         derive_radar(radars[r], (flags & ZRK_F_EXACT_ONLY) != 0, hot, P.rb.cold[r]);
         std::memcpy(P.rb.hotw[r], &hot, sizeof(hot));
     }
+    const int grid = P.nb + nblocks(M.m, ZRK_BLOCK);       // trailing workgroups step the missiles
     if (flags & ZRK_F_PHILOX)
-        hipLaunchKernelGGL(k_tick_sweep<true>, dim3(P.nb), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P);
+        hipLaunchKernelGGL(k_tick_sweep<true>, dim3(grid), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
     else
-        hipLaunchKernelGGL(k_tick_sweep<false>, dim3(P.nb), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P);
+        hipLaunchKernelGGL(k_tick_sweep<false>, dim3(grid), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
     ctx->counts_from_sweep = (e->list_index == nullptr);
     return check_launch(ctx, "k_tick_sweep");
 }
 
-ZRK_API int zrk_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int32_t base_index,
-                        void *workspace, int32_t *det_idx, int64_t det_capacity, int32_t *det_off, int64_t *packed,
-                        int64_t packed_capacity, int64_t gid0, void *stream)
+}  // namespace
+
+ZRK_API int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_t time_ms,
+                           const zrk_radar *radars, int R, uint32_t flags, uint64_t seed, uint64_t tick,
+                           int64_t gid0, void *workspace, void *stream)
+{
+    return launch_sweep(ctx, e, n, cur, time_ms, radars, R, flags, seed, tick, gid0, workspace, stream, no_missiles());
+}
+
+namespace {
+
+int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int32_t base_index, void *workspace,
+                   int32_t *det_idx, int64_t det_capacity, int32_t *det_off, int64_t *packed, int64_t packed_capacity,
+                   int64_t gid0, void *stream, const MissileArgs &M)
 {
     if (!ctx || !vis_mask || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_compact: null argument");
     if ((det_idx && !det_off) || (!det_idx && !packed)) return fail(ctx, ZRK_E_INVALID, "zrk_compact: no output requested");
@@ -850,10 +944,21 @@ ZRK_API int zrk_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R
     Workspace w = carve(workspace, nb);
     if (!ctx->counts_from_sweep)
         hipLaunchKernelGGL(k_count_blocks, dim3(nb), dim3(ZRK_BLOCK), 0, s, vis_mask, n, R, nb, w.counts);
-    hipLaunchKernelGGL(k_scan_counts, dim3(R + 1), dim3(kScanThreads), 0, s, w.counts, w.offs, w.totals, nb);
+    hipLaunchKernelGGL(k_scan_counts, dim3(R + 1 + (M.m > 0 ? 1 : 0)), dim3(kScanThreads), 0, s, w.counts, w.offs, w.totals,
+                       nb, R + 1, M);
     hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(ZRK_BLOCK), 0, s, vis_mask, n, R, nb, w.offs, w.totals, base_index,
                        det_idx, det_capacity, det_off, packed, packed_capacity, gid0);
     return check_launch(ctx, "zrk_compact");
+}
+
+}  // namespace
+
+ZRK_API int zrk_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int32_t base_index,
+                        void *workspace, int32_t *det_idx, int64_t det_capacity, int32_t *det_off, int64_t *packed,
+                        int64_t packed_capacity, int64_t gid0, void *stream)
+{
+    return launch_compact(ctx, vis_mask, n, R, base_index, workspace, det_idx, det_capacity, det_off, packed, packed_capacity,
+                          gid0, stream, no_missiles());
 }
 
 ZRK_API int zrk_noise_apply(zrk_ctx *ctx, double *pos, int64_t capacity, const int32_t *idx, int32_t idx_base,
@@ -1005,15 +1110,19 @@ ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missile
         st->cur ^= 1;
         const bool prof = sweep_ms && (k % stride == 0);
         if (prof) (void)hipEventRecord(ev[2 * (k / stride)], s);
-        rc = zrk_tick_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE, st->seed, st->tick,
-                            st->gid0, workspace, stream);
+        // Missiles read last tick's positions (pos[cur^1]) and trajectories only, so their per-row step rides in
+        // the sweep's grid; the ordered event list and the tombstones (effective from the next tick,
+        // AirEnv.py:33-40) ride in the count scan's grid, behind the sweep.  Tables too long for one
+        // finishing workgroup, or ticks without compaction, take the stand-alone launches instead.
+        const bool fused = m > 0 && m <= 1024 * (int64_t)kMissileItems && (det_idx || packed) && st->n > 0 && R > 0;
+        const MissileArgs M = fused ? missile_args(e, st->cur, mis, m, st->time_ms, st->dt_ms, 1) : no_missiles();
+        rc = launch_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE, st->seed, st->tick,
+                          st->gid0, workspace, stream, M);
         if (prof) (void)hipEventRecord(ev[2 * (k / stride) + 1], s);
         if (rc == 0 && (det_idx || packed))
-            rc = zrk_compact(ctx, e->vis_mask, st->n, R, st->base_index, workspace, det_idx, det_capacity, det_off, packed,
-                             packed_capacity, st->gid0, stream);
-        // missiles read last tick's positions (pos[cur^1]) and trajectories only, so their phase may follow the
-        // sweep; detonations tombstone behind it, i.e. effective from the next tick (AirEnv.py:33-40)
-        if (rc == 0 && m > 0) rc = zrk_missile_step(ctx, e, st->cur, mis, m, st->time_ms, st->dt_ms, 1, stream);
+            rc = launch_compact(ctx, e->vis_mask, st->n, R, st->base_index, workspace, det_idx, det_capacity, det_off, packed,
+                                packed_capacity, st->gid0, stream, M);
+        if (rc == 0 && m > 0 && !fused) rc = zrk_missile_step(ctx, e, st->cur, mis, m, st->time_ms, st->dt_ms, 1, stream);
         zrk_scan_advance(radars, scan, R);                                   // Radar.py:205
         st->time_ms += st->dt_ms;                                            // Manager.py:140
         st->tick += 1;
