@@ -31,7 +31,7 @@ extern "C" {
 
 #define ZRK_ABI_VERSION 1
 #define ZRK_MAX_RADARS 32           /* one bit per radar in the visibility mask */
-#define ZRK_BLOCK 256               /* entities per sweep/compaction block */
+#define ZRK_BLOCK 256               /* table rows per sweep workgroup */
 
 #define ZRK_E_INVALID (-1)          /* bad argument (null pointer, size out of range) */
 #define ZRK_E_HIP (-2)              /* a HIP call failed; see zrk_last_error */

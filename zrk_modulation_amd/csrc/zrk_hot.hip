@@ -25,6 +25,7 @@
 namespace {
 
 constexpr double kRad2Deg = 180.0 / 3.14159265358979323846;   // numpy.degrees factor
+constexpr int kCompBlock = 1024;          // list slots per compaction workgroup (count / scan / scatter unit)
 constexpr float kGuard = 3e-5f;                               // relative half-width of the "ambiguous" band
 
 // Device-side radar records.  Hot: what every (radar, entity) pair touches -- the float32
@@ -65,7 +66,6 @@ struct SweepParams {
     const int32_t *lidx;        // list index of each table row (NULL: the table is in list order)
     double *pos;
     uint32_t *vis;              // indexed by LIST index
-    int32_t *block_counts;      // [R][nb]
     int64_t n, cap;
     double t;
     uint64_t seed, tick;
@@ -203,11 +203,8 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
                                               M.m_radius, M.m_period, M.m_status, row, M.t, M.dts);
         return;
     }
-    __shared__ int s_cnt[ZRK_MAX_RADARS + 1];
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * ZRK_BLOCK + tid;
-    if (tid <= ZRK_MAX_RADARS) s_cnt[tid] = 0;
-    __syncthreads();
 
     uint32_t mask = 0;
     const bool live = (i < P.n) && P.alive[i];
@@ -285,33 +282,16 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
         }
     }
     if (i < P.n) P.vis[li] = mask;
-    if (P.lidx) return;         // rows are not in list order: k_count_blocks counts from vis instead
-
-    // per-workgroup detection counts per radar (row R: seen by any radar), consumed by the scan:
-    // lane r of each wave collects the wave's count for radar r, then one LDS add per lane
-    const int lane = tid & 63;
-    int cnt_lane = 0;
-    for (int r = 0; r < P.R; ++r) {
-        const unsigned long long b = __ballot((mask >> r) & 1u);
-        cnt_lane = (lane == r) ? (int)__popcll(b) : cnt_lane;
-    }
-    {
-        const unsigned long long b = __ballot(mask != 0u);
-        cnt_lane = (lane == P.R) ? (int)__popcll(b) : cnt_lane;
-    }
-    if (lane <= P.R && cnt_lane) atomicAdd(&s_cnt[lane], cnt_lane);
-    __syncthreads();
-    if (tid <= P.R) P.block_counts[(int64_t)tid * P.nb + blockIdx.x] = s_cnt[tid];
 }
 
-// Per-block detection counts straight from vis_mask, for tables whose rows are not in list order
-// (then the sweep's workgroups do not coincide with the compaction's blocks of the list).
-__global__ __launch_bounds__(ZRK_BLOCK) void k_count_blocks(const uint32_t *__restrict__ vis, int64_t n, int R, int nb,
-                                                            int32_t *__restrict__ counts)
+// Compaction, phase 1: per-block detection counts per radar (row R: seen by any radar) from vis_mask,
+// in list order.  Lane r of each wave collects the wave's count for radar r, then one LDS add per lane.
+__global__ __launch_bounds__(kCompBlock) void k_count_blocks(const uint32_t *__restrict__ vis, int64_t n, int R, int nb,
+                                                             int32_t *__restrict__ counts)
 {
     __shared__ int s_cnt[ZRK_MAX_RADARS + 1];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t i = (int64_t)blockIdx.x * ZRK_BLOCK + tid;
+    const int64_t i = (int64_t)blockIdx.x * kCompBlock + tid;
     if (tid <= ZRK_MAX_RADARS) s_cnt[tid] = 0;
     __syncthreads();
     const uint32_t mask = (i < n) ? vis[i] : 0u;
@@ -392,17 +372,17 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_counts(const int32_t *__r
 // Compaction, phase 3: stable scatter.  Lane order == slot order inside a wave, so
 // popcount(ballot & lanes-below) is the rank; waves and workgroups are ordered by the scans.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ZRK_BLOCK) void k_scatter(const uint32_t *__restrict__ vis, int64_t n, int R,
+__global__ __launch_bounds__(kCompBlock) void k_scatter(const uint32_t *__restrict__ vis, int64_t n, int R,
                                                        int nb, const int32_t *__restrict__ offs,
                                                        const int32_t *__restrict__ totals, int32_t base_index,
                                                        int32_t *__restrict__ det_idx, int64_t det_capacity,
                                                        int32_t *__restrict__ det_off, int64_t *__restrict__ packed,
                                                        int64_t packed_capacity, int64_t gid0)
 {
-    __shared__ int s_wcnt[ZRK_BLOCK / 64][ZRK_MAX_RADARS + 1];
+    __shared__ int s_wcnt[kCompBlock / 64][ZRK_MAX_RADARS + 1];
     __shared__ int s_base[ZRK_MAX_RADARS + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t i = (int64_t)blockIdx.x * ZRK_BLOCK + tid;
+    const int64_t i = (int64_t)blockIdx.x * kCompBlock + tid;
     const uint32_t m = (i < n) ? vis[i] : 0u;
     if (wave == 0) {
         // exclusive scan of the R per-radar totals across the first wave; s_base[r] = where this
@@ -798,7 +778,6 @@ void derive_radar(const zrk_radar &hr, bool exact_only, RadarHot &h, RadarCold &
 struct zrk_ctx {
     int device;
     std::string err;
-    bool counts_from_sweep = true;     // did the last zrk_tick_sweep leave per-block counts in the workspace?
 };
 
 namespace {
@@ -855,7 +834,7 @@ ZRK_API const char *zrk_last_error(zrk_ctx *ctx) { return ctx ? ctx->err.c_str()
 ZRK_API int64_t zrk_workspace_bytes(int64_t n_max)
 {
     if (n_max < 0) return ZRK_E_INVALID;
-    const int64_t nb = (n_max + ZRK_BLOCK - 1) / ZRK_BLOCK + 1;
+    const int64_t nb = (n_max + kCompBlock - 1) / kCompBlock + 1;
     return (64 + 2 * (int64_t)(ZRK_MAX_RADARS + 1) * nb) * (int64_t)sizeof(int32_t);
 }
 
@@ -899,7 +878,6 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
     P.t = (double)time_ms / 1000.0;                 // to_seconds, modules/AirObject.py:5-7
     P.seed = seed; P.tick = tick; P.gid0 = gid0;
     P.R = R; P.nb = nblocks(n, ZRK_BLOCK); P.flags = flags;
-    P.block_counts = carve(workspace, P.nb).counts;
     std::memset(&P.rb, 0, sizeof(P.rb));
     for (int r = 0; r < R; ++r) {
         RadarHot hot;
@@ -911,7 +889,6 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
         hipLaunchKernelGGL(k_tick_sweep<true>, dim3(grid), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
     else
         hipLaunchKernelGGL(k_tick_sweep<false>, dim3(grid), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
-    ctx->counts_from_sweep = (e->list_index == nullptr);
     return check_launch(ctx, "k_tick_sweep");
 }
 
@@ -940,13 +917,12 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         if (packed && hipMemsetAsync(packed, 0, sizeof(int64_t), s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "memset packed");
         return 0;
     }
-    const int nb = nblocks(n, ZRK_BLOCK);
+    const int nb = nblocks(n, kCompBlock);
     Workspace w = carve(workspace, nb);
-    if (!ctx->counts_from_sweep)
-        hipLaunchKernelGGL(k_count_blocks, dim3(nb), dim3(ZRK_BLOCK), 0, s, vis_mask, n, R, nb, w.counts);
+    hipLaunchKernelGGL(k_count_blocks, dim3(nb), dim3(kCompBlock), 0, s, vis_mask, n, R, nb, w.counts);
     hipLaunchKernelGGL(k_scan_counts, dim3(R + 1 + (M.m > 0 ? 1 : 0)), dim3(kScanThreads), 0, s, w.counts, w.offs, w.totals,
                        nb, R + 1, M);
-    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(ZRK_BLOCK), 0, s, vis_mask, n, R, nb, w.offs, w.totals, base_index,
+    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(kCompBlock), 0, s, vis_mask, n, R, nb, w.offs, w.totals, base_index,
                        det_idx, det_capacity, det_off, packed, packed_capacity, gid0);
     return check_launch(ctx, "zrk_compact");
 }
