@@ -58,6 +58,7 @@ typedef struct {
     double *pos[2];                 /* DEVICE [3][cap] x2  obj.pos, double-buffered: pos[cur] is this tick's,
                                        pos[cur^1] holds what prev_pos aliases (modules/AirObject.py:41) */
     uint32_t *vis_mask;             /* DEVICE [cap]     bit r = seen by radar r this tick; indexed by LIST index */
+    uint32_t *vis_mask_alt;         /* DEVICE [cap] or NULL: second mask buffer for zrk_run_ticks (see there) */
     const int32_t *list_index;      /* DEVICE [cap] or NULL.  NULL: row i of the table is element i of AirEnv's
                                        list.  Otherwise the rows may be stored in any order (e.g. spatially sorted,
                                        which makes waves coherent) and list_index[row] is the element's position in
@@ -203,7 +204,7 @@ typedef struct {
     int32_t cur;                    /* position buffer holding the LAST completed tick */
     int32_t base_index;             /* added to slots in det_idx */
     uint32_t flags;                 /* ZRK_F_PHILOX etc.; ZRK_F_ADVANCE is implied */
-    uint32_t _pad;
+    int32_t vis_cur;                /* out: 0 = vis_mask, 1 = vis_mask_alt holds the last tick's masks */
 } zrk_loop;
 
 /*
@@ -212,7 +213,10 @@ typedef struct {
  * -> zrk_scan_advance -> time += dt.
  *   replaces the per-tick `module.step()` calls of Manager.run_simulation for AirEnv and every
  *   SectorRadar (modules/Manager.py:123-131, :140).
- * Detection outputs hold the last tick's lists.  If sweep_ms != NULL the sweep kernel of every
+ * Detection outputs hold the last tick's lists.  If ents->vis_mask_alt is given (and compaction is on)
+ * the ticks alternate between the two mask buffers: each tick stores only its detections (list-indexed
+ * stores are scattered when the table is spatially sorted, so the zeros are not worth writing) into the
+ * buffer the previous tick's compaction cleared; st->vis_cur says which buffer is current afterwards.  If sweep_ms != NULL the sweep kernel of every
  * prof_stride-th tick is bracketed by HIP events on `stream`, the stream is synchronised at the
  * end and sweep_ms[k / prof_stride] receives the kernel's duration in milliseconds.
  */

@@ -101,7 +101,7 @@ def _device_noise_table(eng, tick, R, n):
 def _compare_tick(eng, mir, events, tag):
     st = eng.store
     n = st.n_uploaded
-    vis = st.d_vis[:n].cpu().numpy().view(np.uint32)               # already indexed by list index
+    vis = st.vis()[:n].cpu().numpy().view(np.uint32)               # already indexed by list index
     assert np.array_equal(vis, mir.vis), f"{tag}: visibility masks differ"
     P = eng.list_view(st.host_pos("cur"))
     assert np.array_equal(np.ascontiguousarray(P.T).reshape(-1).view(np.uint64), mir.pos.view(np.uint64)), \
@@ -147,7 +147,7 @@ def test_run_k_ticks_equals_k_single_ticks():
     c = _engine(5000, 4, 100, seed=5, noise="philox", sort=False)[0]      # rows in list order: same observables
     c.run(40)
     assert np.array_equal(a.list_view(a.store.host_pos("cur")), c.store.host_pos("cur"))
-    assert np.array_equal(a.store.d_vis[:a.store.n_uploaded].cpu().numpy(), c.store.d_vis[:c.store.n_uploaded].cpu().numpy())
+    assert np.array_equal(a.store.vis()[:a.store.n_uploaded].cpu().numpy(), c.store.vis()[:c.store.n_uploaded].cpu().numpy())
     for x, y in zip(a.detections(), c.detections()):
         assert np.array_equal(x, y)
     assert np.array_equal(a.store.d_alive.cpu().numpy(), b.store.d_alive.cpu().numpy())
@@ -160,7 +160,7 @@ def test_union_list_is_consistent_with_masks_and_lists():
     eng.run(3)
     st = eng.store
     n = st.n_uploaded
-    vis = st.d_vis[:n].cpu().numpy().view(np.uint32)
+    vis = st.vis()[:n].cpu().numpy().view(np.uint32)
     packed = eng.packed.cpu().numpy()
     cnt = int(packed[0])
     seen = np.nonzero(vis)[0]
@@ -214,7 +214,7 @@ def test_full_size_properties(workload):
     eng3.load(ids, sp, vel, t0, radars, missile_capacity=m)
     eng3.launch_missiles(S.missile_targets(n, m))
     eng3.run(1)
-    assert np.array_equal(eng3.store.d_vis[:st2.n_uploaded].cpu().numpy().view(np.uint32), acc)
+    assert np.array_equal(eng3.store.vis()[:st2.n_uploaded].cpu().numpy().view(np.uint32), acc)
     # (4) run on for a while: tombstones are monotone and positions stay finite
     before = eng.alive_count()
     eng.run(200)

@@ -25,7 +25,7 @@ def test_library_exports_every_symbol_the_header_declares():
 def test_ctypes_structs_match_the_header_layout():
     from zrk_modulation_amd import _lib
     assert C.sizeof(_lib.ZrkRadar) == 8 * 8
-    assert C.sizeof(_lib.ZrkEntities) == 8 * 10
+    assert C.sizeof(_lib.ZrkEntities) == 8 * 11
     assert C.sizeof(_lib.ZrkMissiles) == 8 * 10
     assert C.sizeof(_lib.ZrkLaunchReq) == 48 and C.sizeof(_lib.ZrkLaunchRes) == 40
     assert C.sizeof(_lib.ZrkScan) == 32 and C.sizeof(_lib.ZrkLoop) == 64

@@ -34,6 +34,7 @@ class ZrkEntities(C.Structure):
         ("kind", C.c_void_p),
         ("pos", C.c_void_p * 2),
         ("vis_mask", C.c_void_p),
+        ("vis_mask_alt", C.c_void_p),
         ("list_index", C.c_void_p),
     ]
 
@@ -104,7 +105,7 @@ class ZrkLoop(C.Structure):
         ("cur", C.c_int32),
         ("base_index", C.c_int32),
         ("flags", C.c_uint32),
-        ("_pad", C.c_uint32),
+        ("vis_cur", C.c_int32),
     ]
 
 

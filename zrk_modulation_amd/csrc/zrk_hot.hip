@@ -26,6 +26,7 @@ namespace {
 
 constexpr double kRad2Deg = 180.0 / 3.14159265358979323846;   // numpy.degrees factor
 constexpr int kCompBlock = 1024;          // list slots per compaction workgroup (count / scan / scatter unit)
+constexpr uint32_t kSparseVis = 1u << 16;  // internal sweep flag: write only non-zero masks
 constexpr float kGuard = 3e-5f;                               // relative half-width of the "ambiguous" band
 
 // Device-side radar records.  Hot: what every (radar, entity) pair touches -- the float32
@@ -281,7 +282,9 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
             P.pos[i] = x; P.pos[cap + i] = y; P.pos[2 * cap + i] = z;
         }
     }
-    if (i < P.n) P.vis[li] = mask;
+    // sparse mode: the buffer is known to be all zero (the previous tick's scatter cleared it), so only
+    // detections are written -- list-indexed stores are scattered when the table is spatially sorted
+    if (i < P.n && (mask || !(P.flags & kSparseVis))) P.vis[li] = mask;
 }
 
 // Compaction, phase 1: per-block detection counts per radar (row R: seen by any radar) from vis_mask,
@@ -377,13 +380,15 @@ __global__ __launch_bounds__(kCompBlock) void k_scatter(const uint32_t *__restri
                                                        const int32_t *__restrict__ totals, int32_t base_index,
                                                        int32_t *__restrict__ det_idx, int64_t det_capacity,
                                                        int32_t *__restrict__ det_off, int64_t *__restrict__ packed,
-                                                       int64_t packed_capacity, int64_t gid0)
+                                                       int64_t packed_capacity, int64_t gid0,
+                                                       uint32_t *__restrict__ zero_next)
 {
     __shared__ int s_wcnt[kCompBlock / 64][ZRK_MAX_RADARS + 1];
     __shared__ int s_base[ZRK_MAX_RADARS + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t i = (int64_t)blockIdx.x * kCompBlock + tid;
     const uint32_t m = (i < n) ? vis[i] : 0u;
+    if (zero_next && i < n) zero_next[i] = 0u;        // next tick's (other) mask buffer, cleared in passing
     if (wave == 0) {
         // exclusive scan of the R per-radar totals across the first wave; s_base[r] = where this
         // workgroup's detections of radar r start in det_idx (row R: in the packed union list)
@@ -864,7 +869,7 @@ MissileArgs missile_args(const zrk_entities *e, int cur, const zrk_missiles *mis
 
 int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_t time_ms, const zrk_radar *radars,
                  int R, uint32_t flags, uint64_t seed, uint64_t tick, int64_t gid0, void *workspace, void *stream,
-                 const MissileArgs &M)
+                 const MissileArgs &M, uint32_t *vis = nullptr)
 {
     if (!ctx || !e || !workspace || (R > 0 && !radars)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
     if (R < 0 || R > ZRK_MAX_RADARS)
@@ -873,7 +878,7 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
     if (n == 0 && M.m == 0) return 0;
     SweepParams P;
     P.sp = e->start_pos; P.vel = e->velocity; P.t0 = e->start_time; P.alive = e->alive; P.lidx = e->list_index;
-    P.pos = e->pos[cur]; P.vis = e->vis_mask;
+    P.pos = e->pos[cur]; P.vis = vis ? vis : e->vis_mask;
     P.n = n; P.cap = e->capacity;
     P.t = (double)time_ms / 1000.0;                 // to_seconds, modules/AirObject.py:5-7
     P.seed = seed; P.tick = tick; P.gid0 = gid0;
@@ -905,7 +910,7 @@ namespace {
 
 int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int32_t base_index, void *workspace,
                    int32_t *det_idx, int64_t det_capacity, int32_t *det_off, int64_t *packed, int64_t packed_capacity,
-                   int64_t gid0, void *stream, const MissileArgs &M)
+                   int64_t gid0, void *stream, const MissileArgs &M, uint32_t *zero_next)
 {
     if (!ctx || !vis_mask || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_compact: null argument");
     if ((det_idx && !det_off) || (!det_idx && !packed)) return fail(ctx, ZRK_E_INVALID, "zrk_compact: no output requested");
@@ -923,7 +928,7 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
     hipLaunchKernelGGL(k_scan_counts, dim3(R + 1 + (M.m > 0 ? 1 : 0)), dim3(kScanThreads), 0, s, w.counts, w.offs, w.totals,
                        nb, R + 1, M);
     hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(kCompBlock), 0, s, vis_mask, n, R, nb, w.offs, w.totals, base_index,
-                       det_idx, det_capacity, det_off, packed, packed_capacity, gid0);
+                       det_idx, det_capacity, det_off, packed, packed_capacity, gid0, zero_next);
     return check_launch(ctx, "zrk_compact");
 }
 
@@ -934,7 +939,7 @@ ZRK_API int zrk_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R
                         int64_t packed_capacity, int64_t gid0, void *stream)
 {
     return launch_compact(ctx, vis_mask, n, R, base_index, workspace, det_idx, det_capacity, det_off, packed, packed_capacity,
-                          gid0, stream, no_missiles());
+                          gid0, stream, no_missiles(), nullptr);
 }
 
 ZRK_API int zrk_noise_apply(zrk_ctx *ctx, double *pos, int64_t capacity, const int32_t *idx, int32_t idx_base,
@@ -1092,12 +1097,20 @@ ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missile
         // finishing workgroup, or ticks without compaction, take the stand-alone launches instead.
         const bool fused = m > 0 && m <= 1024 * (int64_t)kMissileItems && (det_idx || packed) && st->n > 0 && R > 0;
         const MissileArgs M = fused ? missile_args(e, st->cur, mis, m, st->time_ms, st->dt_ms, 1) : no_missiles();
-        rc = launch_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE, st->seed, st->tick,
-                          st->gid0, workspace, stream, M);
+        // two mask buffers: tick t writes only its detections into one (cleared by the previous tick's
+        // scatter) while its own scatter clears the other for tick t+1.  The first tick of a call writes
+        // densely, so nothing is assumed about what the buffers held before.
+        const bool two_vis = e->vis_mask_alt && (det_idx || packed) && st->n > 0 && R > 0;
+        if (two_vis) st->vis_cur ^= 1; else st->vis_cur = 0;
+        uint32_t *vis_now = st->vis_cur ? e->vis_mask_alt : e->vis_mask;
+        uint32_t *vis_next = two_vis ? (st->vis_cur ? e->vis_mask : e->vis_mask_alt) : nullptr;
+        const uint32_t sparse = (two_vis && k > 0) ? kSparseVis : 0u;
+        rc = launch_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse, st->seed,
+                          st->tick, st->gid0, workspace, stream, M, vis_now);
         if (prof) (void)hipEventRecord(ev[2 * (k / stride) + 1], s);
         if (rc == 0 && (det_idx || packed))
-            rc = launch_compact(ctx, e->vis_mask, st->n, R, st->base_index, workspace, det_idx, det_capacity, det_off, packed,
-                                packed_capacity, st->gid0, stream, M);
+            rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_capacity, det_off, packed,
+                                packed_capacity, st->gid0, stream, M, vis_next);
         if (rc == 0 && m > 0 && !fused) rc = zrk_missile_step(ctx, e, st->cur, mis, m, st->time_ms, st->dt_ms, 1, stream);
         zrk_scan_advance(radars, scan, R);                                   // Radar.py:205
         st->time_ms += st->dt_ms;                                            // Manager.py:140

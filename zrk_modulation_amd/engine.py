@@ -193,6 +193,8 @@ class HotPathEngine:
         velocity = np.asarray(velocity, np.float64).reshape(n, 3)
         start_time = np.broadcast_to(np.asarray(start_time, np.float64), (n,))
         st = self.store = EntityStore(self.device, n + missile_capacity, max(missile_capacity, 64))
+        st.two_vis = True
+        st._alloc_entities(st.cap)
         self.n_list = n                                  # length of AirEnv's list so far
         if sort and n > 1:
             order = morton_order_xy(start_pos)
@@ -293,6 +295,7 @@ class HotPathEngine:
             self.packed.numel() if self.packed is not None else 0, int(K), ms_ptr, int(prof_stride), st._stream()),
             "zrk_run_ticks")
         st.cur = int(self.loop.cur)
+        st.vis_cur = int(self.loop.vis_cur)
         st.time_ms = int(self.loop.time_ms) - self.dt_ms
         st.n_stepped = st.n_uploaded
         st._bump()

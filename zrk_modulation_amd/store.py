@@ -77,6 +77,8 @@ class EntityStore:
         self.h_sp = np.zeros((0, 3)); self.h_vel = np.zeros((0, 3)); self.h_t0 = np.zeros(0)
         self.h_pos0 = np.zeros((0, 3))
         self.h_alive = np.zeros(0, np.uint8)
+        self.two_vis = False       # hand zrk_run_ticks both mask buffers (HotPathEngine turns this on)
+        self.vis_cur = 0
         self.h_lidx = None         # list index of each row when rows are not stored in list order
         self.d_lidx = None
         self.slots_of_id = {}
@@ -99,7 +101,8 @@ class EntityStore:
                    t0=torch.zeros(cap, dtype=f64, device=dev), alive=torch.zeros(cap, dtype=torch.uint8, device=dev),
                    kind=torch.zeros(cap, dtype=torch.uint8, device=dev),
                    pos=torch.zeros(2, 3, cap, dtype=f64, device=dev),
-                   vis=torch.zeros(cap, dtype=torch.int32, device=dev))
+                   vis=torch.zeros(cap, dtype=torch.int32, device=dev),
+                   vis_alt=torch.zeros(cap, dtype=torch.int32, device=dev))
         if self.cap:
             k = self.n_uploaded
             for name, t in new.items():
@@ -114,6 +117,9 @@ class EntityStore:
         e.alive, e.kind = self.d_alive.data_ptr(), self.d_kind.data_ptr()
         e.pos[0], e.pos[1] = self.d_pos[0].data_ptr(), self.d_pos[1].data_ptr()
         e.vis_mask = self.d_vis.data_ptr()
+        self.vis_cur = 0
+        if self.two_vis:
+            e.vis_mask_alt = self.d_vis_alt.data_ptr()
         if self.h_lidx is not None:
             old = self.d_lidx
             self.d_lidx = torch.zeros(cap, dtype=torch.int32, device=dev)
@@ -250,6 +256,10 @@ class EntityStore:
     def _bump(self):
         self.version += 1
         self._snap.clear()
+
+    def vis(self):
+        """The mask buffer holding the last tick's visibility (int32 view of the uint32 masks)."""
+        return self.d_vis_alt if self.vis_cur else self.d_vis
 
     def host_pos(self, which="cur"):
         """(n,3) float64 copy of pos[cur] ('cur') or pos[cur^1] ('prev'); cached until the next kernel."""
