@@ -50,6 +50,20 @@ def build_engine(workload, rank, world, device, seed_off=0):
     return eng, dict(n=n, R=R, m=m, launched=launched, scene=(ids, sp, vel, t0, radars))
 
 
+def pmc_traffic(workload, world):
+    """HBM bytes per sweep launch from the committed PMC passes (profiles/r01_pmc_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 --pmc runs of this workload, corrected as
+    MI355X_MICROARCH.md prescribes and calibrated on a pure-streaming launch).  Counters cannot be read
+    from inside this process, so the figure is the recorded one for the same workload, else null."""
+    try:
+        rec = json.load(open(ROOT / "profiles" / "r01_pmc_traffic.json"))
+        if rec["workload"] == workload and world == 1:
+            return rec["traffic_bytes"]
+    except Exception:
+        pass
+    return None
+
+
 def usable_cores():
     """Threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
     cores = os.cpu_count() or 1
@@ -248,7 +262,8 @@ def main():
                                       "overlapped with the next sweep" if world > 1 else "per-radar compaction"),
                        "entities_per_gpu": n_slots, "live_per_gpu": int(live1), "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_tick_sweep",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, world),
+                         "kernel": "k_tick_sweep",
                          "avg_kernel_us": sweep_avg_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world > 1:
