@@ -216,7 +216,8 @@ typedef struct {
  * Detection outputs hold the last tick's lists.  If ents->vis_mask_alt is given (and compaction is on)
  * the ticks alternate between the two mask buffers: each tick stores only its detections (list-indexed
  * stores are scattered when the table is spatially sorted, so the zeros are not worth writing) into the
- * buffer the previous tick's compaction cleared; st->vis_cur says which buffer is current afterwards.  If sweep_ms != NULL the sweep kernel of every
+ * buffer the previous tick's compaction cleared; st->vis_cur says which buffer is current afterwards.
+ * From the second tick on the two buffers belong to this loop, also between calls: do not write them.  If sweep_ms != NULL the sweep kernel of every
  * prof_stride-th tick is bracketed by HIP events on `stream`, the stream is synchronised at the
  * end and sweep_ms[k / prof_stride] receives the kernel's duration in milliseconds.
  */

@@ -783,6 +783,8 @@ void derive_radar(const zrk_radar &hr, bool exact_only, RadarHot &h, RadarCold &
 struct zrk_ctx {
     int device;
     std::string err;
+    const void *ring_key = nullptr;    // mask buffers zrk_run_ticks has been alternating between ...
+    int64_t ring_age = 0;              // ... for this many consecutive ticks (>= 1: the next one starts cleared)
 };
 
 namespace {
@@ -1098,13 +1100,16 @@ ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missile
         const bool fused = m > 0 && m <= 1024 * (int64_t)kMissileItems && (det_idx || packed) && st->n > 0 && R > 0;
         const MissileArgs M = fused ? missile_args(e, st->cur, mis, m, st->time_ms, st->dt_ms, 1) : no_missiles();
         // two mask buffers: tick t writes only its detections into one (cleared by the previous tick's
-        // scatter) while its own scatter clears the other for tick t+1.  The first tick of a call writes
-        // densely, so nothing is assumed about what the buffers held before.
+        // scatter) while its own scatter clears the other for tick t+1.  The first tick on a pair of buffers
+        // writes densely; from then on the pair belongs to this loop, also between calls (a caller that
+        // writes them itself must pass other buffers or call with vis_mask_alt = NULL).
         const bool two_vis = e->vis_mask_alt && (det_idx || packed) && st->n > 0 && R > 0;
+        if (ctx->ring_key != (const void *)e->vis_mask || !two_vis) { ctx->ring_key = e->vis_mask; ctx->ring_age = 0; }
         if (two_vis) st->vis_cur ^= 1; else st->vis_cur = 0;
         uint32_t *vis_now = st->vis_cur ? e->vis_mask_alt : e->vis_mask;
         uint32_t *vis_next = two_vis ? (st->vis_cur ? e->vis_mask : e->vis_mask_alt) : nullptr;
-        const uint32_t sparse = (two_vis && k > 0) ? kSparseVis : 0u;
+        const uint32_t sparse = (two_vis && ctx->ring_age > 0) ? kSparseVis : 0u;
+        if (two_vis) ctx->ring_age += 1;
         rc = launch_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse, st->seed,
                           st->tick, st->gid0, workspace, stream, M, vis_now);
         if (prof) (void)hipEventRecord(ev[2 * (k / stride) + 1], s);
