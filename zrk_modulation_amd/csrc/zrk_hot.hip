@@ -376,17 +376,21 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_counts(const int32_t *__r
 // popcount(ballot & lanes-below) is the rank; waves and workgroups are ordered by the scans.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kCompBlock) void k_scatter(const uint32_t *__restrict__ vis, int64_t n, int R,
-                                                       int nb, const int32_t *__restrict__ offs,
-                                                       const int32_t *__restrict__ totals, int32_t base_index,
-                                                       int32_t *__restrict__ det_idx, int64_t det_capacity,
-                                                       int32_t *__restrict__ det_off, int64_t *__restrict__ packed,
-                                                       int64_t packed_capacity, int64_t gid0,
-                                                       uint32_t *__restrict__ zero_next)
+                                                        int nb, const int32_t *__restrict__ offs,
+                                                        const int32_t *__restrict__ totals, int32_t base_index,
+                                                        int32_t *__restrict__ det_idx, int64_t det_capacity,
+                                                        int32_t *__restrict__ det_off, int64_t *__restrict__ packed,
+                                                        int64_t packed_capacity, int64_t gid0,
+                                                        uint32_t *__restrict__ zero_next)
 {
-    __shared__ int s_wcnt[kCompBlock / 64][ZRK_MAX_RADARS + 1];
+    constexpr int kWaves = kCompBlock / 64;
+    __shared__ int s_wcnt[kWaves];
     __shared__ int s_base[ZRK_MAX_RADARS + 1];
+    __shared__ unsigned short s_idx[kCompBlock];      // detected slots of this block, in list order ...
+    __shared__ uint32_t s_msk[kCompBlock];            // ... and their masks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t i = (int64_t)blockIdx.x * kCompBlock + tid;
+    const int64_t blk0 = (int64_t)blockIdx.x * kCompBlock;
+    const int64_t i = blk0 + tid;
     const uint32_t m = (i < n) ? vis[i] : 0u;
     if (zero_next && i < n) zero_next[i] = 0u;        // next tick's (other) mask buffer, cleared in passing
     if (wave == 0) {
@@ -406,41 +410,46 @@ __global__ __launch_bounds__(kCompBlock) void k_scatter(const uint32_t *__restri
             s_base[lane] = rbase + offs[(int64_t)lane * nb + blockIdx.x];
         }
     }
-    // lane r of each wave holds the wave's count for radar r (lane R: union)
-    int cnt_lane = 0;
-    for (int r = 0; r < R; ++r) {
-        const unsigned long long b = __ballot((m >> r) & 1u);
-        cnt_lane = (lane == r) ? (int)__popcll(b) : cnt_lane;
-    }
+    // Only ~15 % of the slots carry a detection: squeeze those into LDS first (stable), then each wave
+    // walks the short list for "its" radars instead of every wave walking every radar over all slots.
     const unsigned long long bu = __ballot(m != 0u);
-    cnt_lane = (lane == R) ? (int)__popcll(bu) : cnt_lane;
-    if (lane <= R) s_wcnt[wave][lane] = cnt_lane;
+    if (lane == 0) s_wcnt[wave] = (int)__popcll(bu);
     __syncthreads();
-    // lane r: where this wave's detections of radar r start
-    int wbase_lane = 0;
-    if (lane <= R) {
-        wbase_lane = s_base[lane];
-        for (int w = 0; w < wave; ++w) wbase_lane += s_wcnt[w][lane];
+    int woff = 0, found = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        const int c = s_wcnt[w];
+        if (w < wave) woff += c;
+        found += c;
     }
-    if (det_idx) {
-        for (int r = 0; r < R; ++r) {
-            const unsigned long long b = __ballot((m >> r) & 1u);
-            const int wbase = __builtin_amdgcn_readlane(wbase_lane, r);
-            if ((m >> r) & 1u) {
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-                const int64_t dst = (int64_t)wbase + rank;
-                if (dst < det_capacity) det_idx[dst] = base_index + (int32_t)i;
-            }
-        }
+    if (m != 0u) {
+        const int k = woff + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bu >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bu, 0u));
+        s_idx[k] = (unsigned short)tid;
+        s_msk[k] = m;
     }
+    __syncthreads();
     if (packed) {
         // union list for the multi-GPU exchange: packed[0] = count, then (global index << 32 | mask)
         if (blockIdx.x == 0 && tid == 0) packed[0] = totals[R];
-        const int wbase = __builtin_amdgcn_readlane(wbase_lane, R);
-        if (m != 0u) {
-            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bu >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bu, 0u));
-            const int64_t dst = (int64_t)wbase + rank;
-            if (dst + 1 < packed_capacity) packed[dst + 1] = ((gid0 + i) << 32) | (int64_t)m;
+        const int64_t ubase = s_base[R];
+        for (int k = tid; k < found; k += kCompBlock) {
+            const int64_t dst = ubase + k;
+            if (dst + 1 < packed_capacity) packed[dst + 1] = ((gid0 + blk0 + s_idx[k]) << 32) | (int64_t)s_msk[k];
+        }
+    }
+    if (det_idx) {
+        for (int r = wave; r < R; r += kWaves) {           // this wave's radars
+            int run = s_base[r];
+            for (int c = 0; c < found; c += 64) {
+                const int k = c + lane;
+                const bool bit = (k < found) && ((s_msk[k] >> r) & 1u);
+                const unsigned long long b = __ballot(bit);
+                if (bit) {
+                    const int64_t dst = (int64_t)run + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                    if (dst < det_capacity) det_idx[dst] = base_index + (int32_t)(blk0 + s_idx[k]);
+                }
+                run += (int)__popcll(b);
+            }
         }
     }
 }
