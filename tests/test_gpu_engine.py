@@ -221,3 +221,68 @@ def test_full_size_properties(workload):
     after = eng.alive_count()
     assert after <= before
     assert np.isfinite(eng.store.host_pos("cur")).all()
+
+
+def test_sharded_population_equals_single_table():
+    """BASELINE config 4 in miniature: the population cut into contiguous index
+    ranges, one engine per shard with its global offset, gives -- concatenated in rank order -- exactly
+    the single-table result: masks, positions, per-radar lists, union list.  The noise stream is keyed by
+    the global list index, so the cut does not show in the noise either."""
+    import torch
+    from zrk_modulation_amd import scenario as S
+    from zrk_modulation_amd.engine import HotPathEngine
+    from zrk_modulation_amd.exchange import DetectionExchange
+    n, R, shards, ticks = 48_000, 6, 3, 12
+    ids, sp, vel, t0 = S.synthetic_targets(n, 404)
+    radars = S.synthetic_radars(R)
+    whole = HotPathEngine(device="cuda:0", dt_ms=100, seed=9, noise="philox", gid0=0)
+    whole.load(ids, sp, vel, t0, radars, union_capacity=n).enable_lists()
+    parts = []
+    per = n // shards
+    for g in range(shards):
+        lo, hi = g * per, (g + 1) * per
+        e = HotPathEngine(device="cuda:0", dt_ms=100, seed=9, noise="philox", gid0=lo)
+        e.load(ids[lo:hi], sp[lo:hi], vel[lo:hi], t0[lo:hi], radars, union_capacity=per).enable_lists()
+        parts.append(e)
+    for _ in range(ticks):
+        whole.run(1)
+        for e in parts:
+            e.run(1)
+    wst = whole.store
+    vis_whole = wst.vis()[:n].cpu().numpy()
+    vis_parts = np.concatenate([e.store.vis()[:per].cpu().numpy() for e in parts])
+    assert np.array_equal(vis_whole, vis_parts)
+    pos_whole = whole.list_view(wst.host_pos("cur"))
+    pos_parts = np.concatenate([e.list_view(e.store.host_pos("cur")) for e in parts])
+    assert np.array_equal(pos_whole, pos_parts)
+    # rank-ordered concatenation of the shards' packed union lists == the single table's
+    packed_whole = whole.packed.cpu().numpy()
+    cnt = int(packed_whole[0])
+    merged = np.concatenate([e.packed.cpu().numpy()[1:1 + int(e.packed[0].item())] for e in parts])
+    assert np.array_equal(merged, packed_whole[1:1 + cnt])
+    # and through the exchange's own decoding (single process: world 1 per shard)
+    for r, lst in enumerate(whole.detections()):
+        per_shard = [e.detections()[r] + g * per for g, e in enumerate(parts)]
+        assert np.array_equal(np.concatenate(per_shard), lst)
+    ex = DetectionExchange(n, torch.device("cuda", 0))
+    ex.all_gather(whole.packed)
+    assert np.array_equal(ex.radar_list(2).cpu().numpy(), whole.detections()[2])
+
+
+def test_ensemble_replicas_are_independent_and_match_oracle():
+    """BASELINE config 5 in miniature: independent scenarios (own seed, own targets, own missiles) as
+    replicas on one GPU -- no collective, no shared state: each replica matches its own oracle replay and
+    is unaffected by the others running beside it."""
+    n, R, m = 10_000, 4, 100
+    solo, _, _ = _engine(n, R, m, seed=900, noise="off")
+    for _ in range(10):
+        solo.run(1)
+    solo_pos = solo.list_view(solo.store.host_pos("cur")).copy()
+    engines = [_engine(n, R, m, seed=900 + k, noise="off") for k in range(4)]
+    mirrors = [OracleMirror(e, scene[4]) for e, scene, _ in engines]
+    for k in range(10):
+        for (e, _, _), mir in zip(engines, mirrors):
+            events = mir.tick(k * 500, 500, 0, None)
+            e.run(1)
+            _compare_tick(e, mir, events, f"replica tick {k}")
+    assert np.array_equal(engines[0][0].list_view(engines[0][0].store.host_pos("cur")), solo_pos)
