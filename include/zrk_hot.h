@@ -11,7 +11,10 @@
  * Conventions
  *   - Every pointer marked DEVICE is HIP device memory owned by the caller; the
  *     library never allocates or frees across this boundary.  `workspace` is a
- *     caller-owned DEVICE scratch buffer of at least zrk_workspace_bytes() bytes.
+ *     caller-owned DEVICE scratch buffer of at least zrk_workspace_bytes() bytes that
+ *     belongs to one context and one stream at a time; the library initialises it on
+ *     first use and expects to find it as it left it (a buffer released and allocated
+ *     again at the same address must be zero-filled before it comes back).
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work
  *     is enqueued there and nothing synchronises unless stated.
  *   - One host thread per context.  Return value 0 = ok, negative = ZRK_E_*;
@@ -29,13 +32,14 @@
 extern "C" {
 #endif
 
-#define ZRK_ABI_VERSION 1
+#define ZRK_ABI_VERSION 2
 #define ZRK_MAX_RADARS 32           /* one bit per radar in the visibility mask */
 #define ZRK_BLOCK 256               /* table rows per sweep workgroup */
 
 #define ZRK_E_INVALID (-1)          /* bad argument (null pointer, size out of range) */
 #define ZRK_E_HIP (-2)              /* a HIP call failed; see zrk_last_error */
 #define ZRK_E_CAPACITY (-3)         /* an output buffer is too small */
+#define ZRK_E_STATE (-4)            /* the workspace was modified behind the library's back */
 
 /* flags of zrk_tick_sweep */
 #define ZRK_F_ADVANCE 1u            /* recompute pos from the trajectory before sweeping */
@@ -124,7 +128,6 @@ int64_t zrk_workspace_bytes(int64_t n_max);
  * ZRK_F_PHILOX, every detection perturbs it by N(0, 5^2) per axis (a stream keyed by
  * (seed, tick, gid0 + i)) before the next radar looks.  vis_mask[i] gets bit r per detecting
  * radar (0 for dead slots).
- * Also leaves per-block detection counts in `workspace` for zrk_compact.
  */
 int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *ents, int64_t n, int cur, int64_t time_ms,
                    const zrk_radar *radars /* HOST */, int R, uint32_t flags,
@@ -133,19 +136,27 @@ int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *ents, int64_t n, int cur, i
 /*
  * Ordered detection lists: for each radar r the slots with bit r set, ascending, i.e. the
  * order of FoundObjectsMessage.visible_objects (modules/Radar.py:48-73, :168-174).
- * det_idx[det_off[r] .. det_off[r+1]) holds base_index + slot; det_off has R+1 entries.
- * Must follow zrk_tick_sweep on the same stream with the same n, R and workspace.
- * det_capacity bounds det_idx; on overflow det_off is still exact and entries past the
- * capacity are dropped (det_off[R] > det_capacity tells the caller).
+ * Radar r's list is det_idx[r*det_stride .. r*det_stride + det_cnt[r]), each entry base_index + slot;
+ * det_cnt has R+1 entries, det_cnt[R] = number of slots seen by at least one radar.
+ * Must follow zrk_tick_sweep on the same stream with the same n and R.
+ * A list longer than det_stride is truncated, det_cnt[r] stays exact (det_cnt[r] > det_stride tells
+ * the caller); det_stride = n can never truncate.
  * `packed` (optional) receives the union list used by the multi-GPU exchange: packed[0] = number
  * of slots seen by at least one radar, then for each such slot, ascending,
  * ((gid0 + slot) << 32) | vis_mask -- per-radar lists are stable filters of it.
+ * One launch for tables up to about 8e6 rows (count, wait for the lower-numbered workgroups' counts,
+ * scatter); three launches (count, scan, scatter) beyond.
  */
 int zrk_compact(zrk_ctx *ctx, const uint32_t *vis_mask /* DEVICE */, int64_t n, int R,
-                int32_t base_index, void *workspace, int32_t *det_idx /* DEVICE, may be NULL */,
-                int64_t det_capacity, int32_t *det_off /* DEVICE [R+1] */,
+                int32_t base_index, void *workspace, int32_t *det_idx /* DEVICE [R][det_stride], may be NULL */,
+                int64_t det_stride, int32_t *det_cnt /* DEVICE [R+1] */,
                 int64_t *packed /* DEVICE, may be NULL */, int64_t packed_capacity, int64_t gid0,
                 void *stream);
+
+/* Synchronises `stream` and reports whether every compaction on `workspace` so far ran to completion:
+ * 0, or ZRK_E_STATE if a workgroup found control words it did not expect (a workspace shared between
+ * contexts or overwritten by the caller).  Diagnostics; the hot loop never calls it. */
+int zrk_compact_status(zrk_ctx *ctx, void *workspace /* DEVICE */, void *stream);
 
 /* SectorRadar.smooth_objects with caller-supplied draws (modules/Radar.py:138-142):
  * pos[idx[j]] += noise[j] for j < k, noise row-major k x 3. */
@@ -223,7 +234,7 @@ typedef struct {
  */
 int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *ents, const zrk_missiles *mis, int64_t m, zrk_loop *st,
                   zrk_radar *radars /* HOST, in/out */, const zrk_scan *scan /* HOST */, int R, void *workspace,
-                  int32_t *det_idx, int64_t det_capacity, int32_t *det_off, int64_t *packed,
+                  int32_t *det_idx, int64_t det_stride, int32_t *det_cnt, int64_t *packed,
                   int64_t packed_capacity, int K, float *sweep_ms /* HOST, may be NULL */, int prof_stride,
                   void *stream);
 

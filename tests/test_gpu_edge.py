@@ -126,14 +126,15 @@ def test_empty_ragged_and_limits():
     st2.sweep([radar] * _lib.ZRK_MAX_RADARS, 0)
     near = np.linalg.norm(np.concatenate([a, b]), axis=1) <= 5e4
     assert np.array_equal(st2.d_vis[:5300].cpu().numpy().view(np.uint32) == 0xFFFFFFFF, near)
-    # detection buffer too small: offsets stay exact, entries beyond the capacity are dropped
+    # detection segment too small: counts stay exact, entries beyond the stride are dropped
     det = st2.det_buffer(16)
     st2.sweep([radar], 0)
     small = st2.det_buffer(1)[:64]
     st2.ctx.check(st2.lib.zrk_compact(st2.ctx.handle, st2.d_vis.data_ptr(), 5300, 1, 0, st2.workspace().data_ptr(),
-                                      small.data_ptr(), 64, st2._det_off.data_ptr(), None, 0, 0, None), "compact")
-    assert int(st2._det_off[1].item()) == int(near.sum()) > 64
+                                      small.data_ptr(), 64, st2._det_cnt.data_ptr(), None, 0, 0, None), "compact")
+    assert int(st2._det_cnt[0].item()) == int(near.sum()) > 64
     assert np.array_equal(small.cpu().numpy(), np.nonzero(near)[0][:64])
+    st2.compact_status()
 
 
 def test_long_missile_table_takes_the_multi_launch_path():

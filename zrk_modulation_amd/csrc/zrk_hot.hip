@@ -12,9 +12,11 @@
 // cache into SGPRs; an LDS tile of radars would only add a copy.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -378,8 +380,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_counts(const int32_t *__r
 __global__ __launch_bounds__(kCompBlock) void k_scatter(const uint32_t *__restrict__ vis, int64_t n, int R,
                                                         int nb, const int32_t *__restrict__ offs,
                                                         const int32_t *__restrict__ totals, int32_t base_index,
-                                                        int32_t *__restrict__ det_idx, int64_t det_capacity,
-                                                        int32_t *__restrict__ det_off, int64_t *__restrict__ packed,
+                                                        int32_t *__restrict__ det_idx, int64_t det_stride,
+                                                        int32_t *__restrict__ det_cnt, int64_t *__restrict__ packed,
                                                         int64_t packed_capacity, int64_t gid0,
                                                         uint32_t *__restrict__ zero_next)
 {
@@ -393,22 +395,11 @@ __global__ __launch_bounds__(kCompBlock) void k_scatter(const uint32_t *__restri
     const int64_t i = blk0 + tid;
     const uint32_t m = (i < n) ? vis[i] : 0u;
     if (zero_next && i < n) zero_next[i] = 0u;        // next tick's (other) mask buffer, cleared in passing
-    if (wave == 0) {
-        // exclusive scan of the R per-radar totals across the first wave; s_base[r] = where this
-        // workgroup's detections of radar r start in det_idx (row R: in the packed union list)
-        const int tot = (lane < R) ? totals[lane] : 0;
-        int incl = tot;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
-        }
-        const int grand = __shfl(incl, R > 0 ? R - 1 : 0);
-        if (lane <= R) {
-            const int rbase = (lane < R) ? incl - tot : 0;      // the union row is a list of its own
-            if (det_idx && blockIdx.x == 0) det_off[lane] = (lane < R) ? rbase : (R > 0 ? grand : 0);
-            s_base[lane] = rbase + offs[(int64_t)lane * nb + blockIdx.x];
-        }
+    if (tid <= R) {
+        // s_base[r] = rank of this workgroup's first detection of radar r in that radar's list
+        // (row R: in the packed union list)
+        if (det_cnt && blockIdx.x == 0) det_cnt[tid] = totals[tid];
+        s_base[tid] = offs[(int64_t)tid * nb + blockIdx.x];
     }
     // Only ~15 % of the slots carry a detection: squeeze those into LDS first (stable), then each wave
     // walks the short list for "its" radars instead of every wave walking every radar over all slots.
@@ -446,10 +437,201 @@ __global__ __launch_bounds__(kCompBlock) void k_scatter(const uint32_t *__restri
                 const unsigned long long b = __ballot(bit);
                 if (bit) {
                     const int64_t dst = (int64_t)run + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-                    if (dst < det_capacity) det_idx[dst] = base_index + (int32_t)(blk0 + s_idx[k]);
+                    if (dst < det_stride) det_idx[(int64_t)r * det_stride + dst] = base_index + (int32_t)(blk0 + s_idx[k]);
                 }
                 run += (int)__popcll(b);
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Compaction in ONE launch (the default up to kFusedMaxBlocks workgroups): every workgroup takes a ticket
+// (its position in list order), squeezes its detections into LDS, publishes its R+1 counts as
+// (epoch << 32 | count) words and adds up the words of all lower tickets -- which belong to workgroups that
+// are already running, so the wait cannot deadlock whatever the residency -- then scatters.  No chained
+// dependency: a workgroup's counts depend on nobody.  The last ticket writes the totals; the last
+// workgroup to finish rearms the ticket counter.  `epoch` differs per launch, so the words need no reset.
+// ---------------------------------------------------------------------------------------------
+#ifndef ZRK_PROBE
+#define ZRK_PROBE(slot)                          // tools/compact_phases.hip records wall-clock stamps here
+#endif
+constexpr int kFusedMaxItems = 8;                // list slots per thread
+constexpr int kFusedMaxBlocks = 1024;
+constexpr int kAggStride = 40;                   // 64-bit words per workgroup record (>= ZRK_MAX_RADARS + 1)
+constexpr int kFusedCtlInts = 64;                // ticket, done, error, padding
+constexpr int kSpinLimit = 1 << 22;
+
+__device__ __forceinline__ unsigned long long agg_load(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(kCompBlock) void k_compact_fused(const uint32_t *__restrict__ vis, int64_t n, int R, int nb,
+                                                              int items, int lanes_per_rec, int by_ticket,
+                                                              uint32_t epoch, int32_t *ctl, unsigned long long *agg, int32_t base_index,
+                                                              int32_t *__restrict__ det_idx, int64_t det_stride,
+                                                              int32_t *__restrict__ det_cnt,
+                                                              int64_t *__restrict__ packed, int64_t packed_capacity,
+                                                              int64_t gid0, uint32_t *__restrict__ zero_next,
+                                                              const MissileArgs M)
+{
+    constexpr int kWaves = kCompBlock / 64;
+    __shared__ int s_wave[kWaves];
+    __shared__ int s_wcnt[kFusedMaxItems * kWaves];
+    __shared__ int s_cnt[ZRK_MAX_RADARS + 1];
+    __shared__ int s_pre[ZRK_MAX_RADARS + 1];
+    __shared__ int s_ticket, s_found;
+    __shared__ unsigned short s_idx[kFusedMaxItems * kCompBlock];
+    __shared__ uint32_t s_msk[kFusedMaxItems * kCompBlock];
+    if ((int)blockIdx.x >= nb) {                   // the one extra workgroup: missile events + tombstones
+        missile_finish_entry(s_wave, M);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_ticket = by_ticket ? atomicAdd(&ctl[0], 1) : (int)blockIdx.x;
+    if (tid <= ZRK_MAX_RADARS) s_pre[tid] = 0;
+    __syncthreads();
+    const int b = s_ticket;
+    if (b < 0 || b >= nb) {                        // a workspace that was not ours: refuse rather than scribble
+        if (tid == 0) atomicExch(&ctl[2], 1);
+        return;
+    }
+    const int64_t blk0 = (int64_t)b * items * kCompBlock;
+    ZRK_PROBE(0);
+    uint32_t mk[kFusedMaxItems];
+#pragma unroll
+    for (int it = 0; it < kFusedMaxItems; ++it) {  // every load in flight before anything looks at one
+        const int64_t i = blk0 + (int64_t)it * kCompBlock + tid;
+        mk[it] = (it < items && i < n) ? vis[i] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < kFusedMaxItems; ++it) {
+        if (it < items) {
+            const int64_t i = blk0 + (int64_t)it * kCompBlock + tid;
+            if (zero_next && i < n) zero_next[i] = 0u;   // next tick's (other) mask buffer, cleared in passing
+            const unsigned long long bu = __ballot(mk[it] != 0u);
+            if (lane == 0) s_wcnt[it * kWaves + wave] = (int)__popcll(bu);
+        }
+    }
+    ZRK_PROBE(1);
+    __syncthreads();
+    if (wave == 0) {                               // exclusive scan of the (item, wave) counts: list order
+        const int m2 = items * kWaves;
+        const int a0 = (2 * lane < m2) ? s_wcnt[2 * lane] : 0, a1 = (2 * lane + 1 < m2) ? s_wcnt[2 * lane + 1] : 0;
+        int incl = a0 + a1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        const int excl = incl - a0 - a1;
+        if (2 * lane < m2) s_wcnt[2 * lane] = excl;
+        if (2 * lane + 1 < m2) s_wcnt[2 * lane + 1] = excl + a0;
+        if (lane == 63) s_found = incl;
+    }
+    __syncthreads();
+    const int found = s_found;
+#pragma unroll
+    for (int it = 0; it < kFusedMaxItems; ++it) {
+        if (it < items) {
+            const unsigned long long bu = __ballot(mk[it] != 0u);
+            if (mk[it] != 0u) {
+                const int k = s_wcnt[it * kWaves + wave] +
+                              (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bu >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bu, 0u));
+                s_idx[k] = (unsigned short)(it * kCompBlock + tid);
+                s_msk[k] = mk[it];
+            }
+        }
+    }
+    __syncthreads();
+    ZRK_PROBE(2);
+    for (int r = wave; r < R; r += kWaves) {       // per-radar counts over the short list
+        int run = 0;
+        for (int c = 0; c < found; c += 256) {
+            uint32_t q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = c + u * 64 + lane;
+                q[u] = (k < found) ? s_msk[k] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) run += (int)__popcll(__ballot((q[u] >> r) & 1u));
+        }
+        if (lane == 0) s_cnt[r] = run;
+    }
+    if (tid == 0) s_cnt[R] = found;
+    __syncthreads();
+    ZRK_PROBE(3);
+    if (tid <= R)
+        __hip_atomic_store(&agg[(int64_t)b * kAggStride + tid], ((unsigned long long)epoch << 32) | (uint32_t)s_cnt[tid],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        // lower tickets: record p, counter c is word p * lanes_per_rec + c of a (p, c) grid dealt out to the
+        // threads kCompBlock apart (lanes_per_rec: a power of two >= R+1), kBatch loads in flight per thread
+        constexpr int kBatch = 8;
+        const int c = tid & (lanes_per_rec - 1);
+        const int p_first = tid / lanes_per_rec, p_step = kCompBlock / lanes_per_rec;
+        int acc = 0;
+        bool timed_out = false;
+        if (c <= R) {
+            for (int p0 = p_first; p0 < b; p0 += p_step * kBatch) {
+                unsigned long long v[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int p = p0 + u * p_step;
+                    v[u] = (p < b) ? agg_load(&agg[(int64_t)p * kAggStride + c]) : ((unsigned long long)epoch << 32);
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int p = p0 + u * p_step;
+                    int spins = 0;
+                    while ((uint32_t)(v[u] >> 32) != epoch) {
+                        if (++spins > kSpinLimit) { timed_out = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        v[u] = agg_load(&agg[(int64_t)p * kAggStride + c]);
+                    }
+                    acc += (int)(uint32_t)v[u];
+                }
+            }
+            if (acc) atomicAdd(&s_pre[c], acc);
+            if (timed_out) atomicExch(&ctl[2], 2);
+        }
+    }
+    __syncthreads();
+    ZRK_PROBE(4);
+    if (packed) {
+        const int64_t ubase = s_pre[R];
+        for (int k = tid; k < found; k += kCompBlock) {
+            const int64_t dst = ubase + k;
+            if (dst + 1 < packed_capacity) packed[dst + 1] = ((gid0 + blk0 + s_idx[k]) << 32) | (int64_t)s_msk[k];
+        }
+    }
+    if (det_idx) {
+        for (int r = wave; r < R; r += kWaves) {
+            int run = s_pre[r];
+            for (int c = 0; c < found; c += 64) {
+                const int k = c + lane;
+                const bool bit = (k < found) && ((s_msk[k] >> r) & 1u);
+                const unsigned long long bb = __ballot(bit);
+                if (bit) {
+                    const int64_t dst = (int64_t)run + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u));
+                    if (dst < det_stride) det_idx[(int64_t)r * det_stride + dst] = base_index + (int32_t)(blk0 + s_idx[k]);
+                }
+                run += (int)__popcll(bb);
+            }
+        }
+    }
+    if (b == nb - 1 && tid <= R) {                 // the end of the list: totals
+        const int tot = s_pre[tid] + s_cnt[tid];
+        if (det_cnt) det_cnt[tid] = tot;
+        if (packed && tid == R) packed[0] = tot;
+    }
+    ZRK_PROBE(5);
+    if (by_ticket && tid == 0) {
+        if (atomicAdd(&ctl[1], 1) == nb - 1) {     // everybody holds a ticket and is done with it
+            atomicExch(&ctl[0], 0);
+            atomicExch(&ctl[1], 0);
         }
     }
 }
@@ -791,6 +973,10 @@ void derive_radar(const zrk_radar &hr, bool exact_only, RadarHot &h, RadarCold &
 
 struct zrk_ctx {
     int device;
+    int cus = 256;                     // compute units of the device
+    int fused_max_blocks = 0;          // single-launch compaction up to this many workgroups (0: never)
+    uint32_t epoch = 0;                // tag of the next single-launch compaction
+    const void *fused_ws = nullptr;    // workspace whose control words this context has cleared
     std::string err;
     const void *ring_key = nullptr;    // mask buffers zrk_run_ticks has been alternating between ...
     int64_t ring_age = 0;              // ... for this many consecutive ticks (>= 1: the next one starts cleared)
@@ -814,13 +1000,20 @@ int check_launch(zrk_ctx *ctx, const char *what)
 inline int nblocks(int64_t n, int per) { return (int)((n + per - 1) / per); }
 
 struct Workspace {
+    int32_t *ctl;                  // single-launch compaction: ticket, done, error
+    unsigned long long *agg;       // ... and its per-workgroup records
     int32_t *counts, *offs, *totals;
 };
+
+constexpr int64_t kFusedBytes = kFusedCtlInts * (int64_t)sizeof(int32_t) +
+                                (int64_t)kFusedMaxBlocks * kAggStride * (int64_t)sizeof(unsigned long long);
 
 Workspace carve(void *ws, int nb)
 {
     Workspace w;
-    w.totals = (int32_t *)ws;                       // [ZRK_MAX_RADARS] (+ pad to 64 ints)
+    w.ctl = (int32_t *)ws;
+    w.agg = (unsigned long long *)(w.ctl + kFusedCtlInts);
+    w.totals = (int32_t *)((char *)ws + kFusedBytes);   // [ZRK_MAX_RADARS + 1] (+ pad to 64 ints)
     w.counts = w.totals + 64;
     w.offs = w.counts + (int64_t)(ZRK_MAX_RADARS + 1) * nb;
     return w;
@@ -839,6 +1032,13 @@ ZRK_API int zrk_ctx_create(int device, zrk_ctx **out)
     if (hipSetDevice(device) != hipSuccess) return ZRK_E_HIP;
     zrk_ctx *c = new zrk_ctx;
     c->device = device;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = cus;
+    c->fused_max_blocks = kFusedMaxBlocks;
+    if (const char *v = std::getenv("ZRK_COMPACT_FUSED_MAX_BLOCKS")) {     // 0 = always the three-launch path
+        const long k = std::strtol(v, nullptr, 10);
+        c->fused_max_blocks = (int)std::min<long>(std::max<long>(k, 0), kFusedMaxBlocks);
+    }
     *out = c;
     return 0;
 }
@@ -851,7 +1051,7 @@ ZRK_API int64_t zrk_workspace_bytes(int64_t n_max)
 {
     if (n_max < 0) return ZRK_E_INVALID;
     const int64_t nb = (n_max + kCompBlock - 1) / kCompBlock + 1;
-    return (64 + 2 * (int64_t)(ZRK_MAX_RADARS + 1) * nb) * (int64_t)sizeof(int32_t);
+    return kFusedBytes + (64 + 2 * (int64_t)(ZRK_MAX_RADARS + 1) * nb) * (int64_t)sizeof(int32_t);
 }
 
 namespace {
@@ -920,18 +1120,40 @@ ZRK_API int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int c
 namespace {
 
 int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int32_t base_index, void *workspace,
-                   int32_t *det_idx, int64_t det_capacity, int32_t *det_off, int64_t *packed, int64_t packed_capacity,
+                   int32_t *det_idx, int64_t det_stride, int32_t *det_cnt, int64_t *packed, int64_t packed_capacity,
                    int64_t gid0, void *stream, const MissileArgs &M, uint32_t *zero_next)
 {
     if (!ctx || !vis_mask || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_compact: null argument");
-    if ((det_idx && !det_off) || (!det_idx && !packed)) return fail(ctx, ZRK_E_INVALID, "zrk_compact: no output requested");
-    if (R < 0 || R > ZRK_MAX_RADARS || n < 0 || det_capacity < 0 || (packed && packed_capacity < 1))
+    if ((det_idx && !det_cnt) || (!det_idx && !packed)) return fail(ctx, ZRK_E_INVALID, "zrk_compact: no output requested");
+    if (R < 0 || R > ZRK_MAX_RADARS || n < 0 || det_stride < 0 || (packed && packed_capacity < 1))
         return fail(ctx, ZRK_E_INVALID, "zrk_compact: size out of range");
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
-        if (det_idx && hipMemsetAsync(det_off, 0, sizeof(int32_t) * (R + 1), s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "memset det_off");
+        if (det_idx && hipMemsetAsync(det_cnt, 0, sizeof(int32_t) * (R + 1), s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "memset det_cnt");
         if (packed && hipMemsetAsync(packed, 0, sizeof(int64_t), s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "memset packed");
         return 0;
+    }
+    // single launch: about one workgroup per compute unit, each thread holding up to kFusedMaxItems slots
+    int items = (int)std::min<int64_t>(kFusedMaxItems, std::max<int64_t>(1, (n + (int64_t)kCompBlock * ctx->cus - 1) / ((int64_t)kCompBlock * ctx->cus)));
+    if (const char *v = std::getenv("ZRK_COMPACT_ITEMS")) items = std::min(kFusedMaxItems, std::max(1, std::atoi(v)));
+    const int64_t nbf = (n + (int64_t)kCompBlock * items - 1) / ((int64_t)kCompBlock * items);
+    if (nbf <= ctx->fused_max_blocks) {
+        Workspace w = carve(workspace, 0);
+        if (ctx->fused_ws != workspace) {          // first use by this context: no ticket, no record, no error
+            if (hipMemsetAsync(workspace, 0, kFusedBytes, s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "memset workspace");
+            ctx->fused_ws = workspace;
+        }
+        if (++ctx->epoch == 0) ctx->epoch = 1;
+        int lanes = 1;
+        while (lanes < R + 1) lanes <<= 1;
+        // Workgroups that all fit on the device at once may wait for each other in blockIdx order; beyond that
+        // only tickets guarantee that whoever is waited for is already running.
+        int by_ticket = nbf > 2 * (int64_t)ctx->cus;
+        if (const char *v = std::getenv("ZRK_COMPACT_ORDER")) by_ticket = std::strcmp(v, "block") != 0;
+        hipLaunchKernelGGL(k_compact_fused, dim3((int)nbf + (M.m > 0 ? 1 : 0)), dim3(kCompBlock), 0, s, vis_mask, n, R, (int)nbf,
+                           items, lanes, by_ticket, ctx->epoch, w.ctl, w.agg, base_index, det_idx, det_stride, det_cnt, packed,
+                           packed_capacity, gid0, zero_next, M);
+        return check_launch(ctx, "k_compact_fused");
     }
     const int nb = nblocks(n, kCompBlock);
     Workspace w = carve(workspace, nb);
@@ -939,18 +1161,32 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
     hipLaunchKernelGGL(k_scan_counts, dim3(R + 1 + (M.m > 0 ? 1 : 0)), dim3(kScanThreads), 0, s, w.counts, w.offs, w.totals,
                        nb, R + 1, M);
     hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(kCompBlock), 0, s, vis_mask, n, R, nb, w.offs, w.totals, base_index,
-                       det_idx, det_capacity, det_off, packed, packed_capacity, gid0, zero_next);
+                       det_idx, det_stride, det_cnt, packed, packed_capacity, gid0, zero_next);
     return check_launch(ctx, "zrk_compact");
 }
 
 }  // namespace
 
 ZRK_API int zrk_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int32_t base_index,
-                        void *workspace, int32_t *det_idx, int64_t det_capacity, int32_t *det_off, int64_t *packed,
+                        void *workspace, int32_t *det_idx, int64_t det_stride, int32_t *det_cnt, int64_t *packed,
                         int64_t packed_capacity, int64_t gid0, void *stream)
 {
-    return launch_compact(ctx, vis_mask, n, R, base_index, workspace, det_idx, det_capacity, det_off, packed, packed_capacity,
+    return launch_compact(ctx, vis_mask, n, R, base_index, workspace, det_idx, det_stride, det_cnt, packed, packed_capacity,
                           gid0, stream, no_missiles(), nullptr);
+}
+
+ZRK_API int zrk_compact_status(zrk_ctx *ctx, void *workspace, void *stream)
+{
+    if (!ctx || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_compact_status: null argument");
+    int32_t ctl[4] = {0, 0, 0, 0};
+    hipStream_t s = (hipStream_t)stream;
+    if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(ctl, workspace, sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(ctx, ZRK_E_HIP, "zrk_compact_status: copy failed");
+    if (ctx->fused_ws != workspace) return 0;      // never used with this context
+    if (ctl[2] == 0 && ctl[0] == 0 && ctl[1] == 0) return 0;
+    ctx->fused_ws = nullptr;                       // cleared again on the next use
+    return fail(ctx, ZRK_E_STATE, ctl[2] == 2 ? "zrk_compact: a workgroup gave up waiting for its predecessors"
+                                              : "zrk_compact: workspace control words were not as this library left them");
 }
 
 ZRK_API int zrk_noise_apply(zrk_ctx *ctx, double *pos, int64_t capacity, const int32_t *idx, int32_t idx_base,
@@ -1082,7 +1318,7 @@ ZRK_API int zrk_scan_advance(zrk_radar *radars, const zrk_scan *scan, int R)
 
 ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int64_t m, zrk_loop *st,
                           zrk_radar *radars, const zrk_scan *scan, int R, void *workspace, int32_t *det_idx,
-                          int64_t det_capacity, int32_t *det_off, int64_t *packed, int64_t packed_capacity, int K,
+                          int64_t det_stride, int32_t *det_cnt, int64_t *packed, int64_t packed_capacity, int K,
                           float *sweep_ms, int prof_stride, void *stream)
 {
     if (!ctx || !e || !st || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: null argument");
@@ -1104,7 +1340,7 @@ ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missile
         if (prof) (void)hipEventRecord(ev[2 * (k / stride)], s);
         // Missiles read last tick's positions (pos[cur^1]) and trajectories only, so their per-row step rides in
         // the sweep's grid; the ordered event list and the tombstones (effective from the next tick,
-        // AirEnv.py:33-40) ride in the count scan's grid, behind the sweep.  Tables too long for one
+        // AirEnv.py:33-40) ride in the compaction's grid, behind the sweep.  Tables too long for one
         // finishing workgroup, or ticks without compaction, take the stand-alone launches instead.
         const bool fused = m > 0 && m <= 1024 * (int64_t)kMissileItems && (det_idx || packed) && st->n > 0 && R > 0;
         const MissileArgs M = fused ? missile_args(e, st->cur, mis, m, st->time_ms, st->dt_ms, 1) : no_missiles();
@@ -1123,7 +1359,7 @@ ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missile
                           st->tick, st->gid0, workspace, stream, M, vis_now);
         if (prof) (void)hipEventRecord(ev[2 * (k / stride) + 1], s);
         if (rc == 0 && (det_idx || packed))
-            rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_capacity, det_off, packed,
+            rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, packed,
                                 packed_capacity, st->gid0, stream, M, vis_next);
         if (rc == 0 && m > 0 && !fused) rc = zrk_missile_step(ctx, e, st->cur, mis, m, st->time_ms, st->dt_ms, 1, stream);
         zrk_scan_advance(radars, scan, R);                                   // Radar.py:205

@@ -131,8 +131,8 @@ class DeviceSim:
         st = self.store
         rd = self.radars[k]
         st.sweep([self.radar_params(rd)], self._xflag)
-        det, off = st.compact(1)
-        cnt = int(off[1].item())
+        det, cnts = st.compact(1)
+        cnt = int(cnts[0].item())
         found = det[:cnt].cpu().numpy() if cnt else np.zeros(0, np.int32)
         if noise_fn is not None and cnt:
             st.noise_apply(det, cnt, noise_fn(cnt))
@@ -177,7 +177,7 @@ class HotPathEngine:
         self.loop = None
         self.R = 0
 
-    def load(self, ids, start_pos, velocity, start_time, radars, missile_capacity=0, det_capacity=None,
+    def load(self, ids, start_pos, velocity, start_time, radars, missile_capacity=0, det_stride=None,
              union_capacity=None, sort=True):
         """ids/start_pos/velocity/start_time: target columns in LIST order; radars: list of dicts with
         the SectorRadar constructor fields (reference modules/Radar.py:13-42).
@@ -224,18 +224,19 @@ class HotPathEngine:
         self.loop.gid0, self.loop.seed, self.loop.tick = self.gid0, self.seed, 0
         self.loop.cur, self.loop.base_index = st.cur, 0
         self.loop.flags = F_PHILOX if self.noise == "philox" else 0
-        self.det_capacity = det_capacity
+        self.det_stride = int(det_stride or 0)
         self.det_idx = None
-        self.det_off = torch.zeros(_lib.ZRK_MAX_RADARS + 1, dtype=torch.int32, device=st.device)
+        self.det_cnt = torch.zeros(_lib.ZRK_MAX_RADARS + 1, dtype=torch.int32, device=st.device)
         self.packed = None
         if union_capacity:
             self.packed = torch.zeros(int(union_capacity) + 1, dtype=torch.int64, device=st.device)
         return self
 
-    def enable_lists(self, det_capacity=None):
+    def enable_lists(self, det_stride=None):
+        """Per-radar detection lists: R segments of `det_stride` entries (default: the table capacity)."""
         st = self.store
-        cap = det_capacity or self.det_capacity or st.cap * max(self.R, 1)
-        self.det_idx = torch.zeros(int(cap), dtype=torch.int32, device=st.device)
+        self.det_stride = int(det_stride or self.det_stride or st.cap)
+        self.det_idx = torch.zeros(self.det_stride * max(self.R, 1), dtype=torch.int32, device=st.device)
         return self
 
     def launch_missiles(self, target_slots, launcher_pos=(0.0, 0.0, 0.0), speed=1000.0, radius=150.0, period=60.0,
@@ -290,7 +291,7 @@ class HotPathEngine:
             st.ctx.handle, C.byref(st.ents), C.byref(st.mis), st.m, C.byref(self.loop), self.c_radars, self.c_scan,
             self.R, st.workspace().data_ptr(),
             self.det_idx.data_ptr() if self.det_idx is not None else None,
-            self.det_idx.numel() if self.det_idx is not None else 0, self.det_off.data_ptr(),
+            self.det_stride if self.det_idx is not None else 0, self.det_cnt.data_ptr(),
             self.packed.data_ptr() if self.packed is not None else None,
             self.packed.numel() if self.packed is not None else 0, int(K), ms_ptr, int(prof_stride), st._stream()),
             "zrk_run_ticks")
@@ -305,9 +306,13 @@ class HotPathEngine:
         return int(self.store.d_alive[:self.store.n_uploaded].sum().item())
 
     def detections(self):
-        off = self.det_off[:self.R + 1].cpu().numpy()
-        idx = self.det_idx[:off[-1]].cpu().numpy()
-        return [idx[off[r]:off[r + 1]] for r in range(self.R)]
+        cnt = self.det_cnt[:self.R].cpu().numpy()
+        idx = self.det_idx.cpu().numpy() if cnt.max(initial=0) * 4 > self.det_stride else None
+        out = []
+        for r in range(self.R):
+            lo, k = r * self.det_stride, min(int(cnt[r]), self.det_stride)
+            out.append(idx[lo:lo + k] if idx is not None else self.det_idx[lo:lo + k].cpu().numpy())
+        return out
 
     def list_view(self, rows_first):
         """Reorder a per-row array (first axis = table rows) into list order."""

@@ -47,8 +47,8 @@ class SectorRadar(BaseModel):
             raise TypeError("SectorRadar needs the ActiveObjectsMessage of a device-backed AirEnv "
                             "(zrk_modulation_amd.modules.AirEnv); plain object lists have no CPU path here")
         store.sweep([self._params()], 0)
-        det, off = store.compact(1)
-        cnt = int(off[1].item())
+        det, cnts = store.compact(1)
+        cnt = int(cnts[0].item())
         slots = det[:cnt].cpu().numpy() if cnt else np.zeros(0, np.int32)
         return store, det, cnt, slots
 

@@ -88,7 +88,7 @@ class EntityStore:
         self._alloc_missiles(max(int(missile_capacity), 64))
         self._ws = None
         self._det_idx = None
-        self._det_off = torch.zeros(_lib.ZRK_MAX_RADARS + 1, dtype=torch.int32, device=self.device)
+        self._det_cnt = torch.zeros(_lib.ZRK_MAX_RADARS + 1, dtype=torch.int32, device=self.device)
 
     # -- allocation -------------------------------------------------------------------------
     def _stream(self):
@@ -320,15 +320,21 @@ class EntityStore:
             self._bump()
         return R
 
-    def compact(self, R, base_index=0, n=None, det_capacity=None):
-        """zrk_compact after sweep(); returns (det_idx tensor, det_off tensor[R+1]) on the device."""
+    def compact(self, R, base_index=0, n=None, det_stride=None):
+        """zrk_compact after sweep(); returns (det_idx tensor [R][stride], det_cnt tensor [R+1]) on the device.
+        Radar r's list is det_idx[r*stride : r*stride + det_cnt[r]] with stride = `det_stride` or n."""
         n = self.n_uploaded if n is None else n
-        capn = n * max(R, 1) if det_capacity is None else det_capacity
-        det = self.det_buffer(capn)
+        stride = n if det_stride is None else det_stride
+        det = self.det_buffer(stride * max(R, 1))
         self.ctx.check(self.lib.zrk_compact(self.ctx.handle, self.d_vis.data_ptr(), n, R, base_index,
-                                            self.workspace().data_ptr(), det.data_ptr(), det.numel(),
-                                            self._det_off.data_ptr(), None, 0, 0, self._stream()), "zrk_compact")
-        return det, self._det_off
+                                            self.workspace().data_ptr(), det.data_ptr(), stride,
+                                            self._det_cnt.data_ptr(), None, 0, 0, self._stream()), "zrk_compact")
+        return det, self._det_cnt
+
+    def compact_status(self):
+        """Synchronise and raise ZrkError if a compaction on this store's workspace did not run to completion."""
+        self.ctx.check(self.lib.zrk_compact_status(self.ctx.handle, self.workspace().data_ptr(), self._stream()),
+                       "zrk_compact_status")
 
     def noise_apply(self, det_idx, k, noise, idx_base=0):
         nz = torch.as_tensor(np.ascontiguousarray(noise, np.float64).reshape(k, 3), device=self.device)
