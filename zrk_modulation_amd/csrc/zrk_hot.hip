@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,6 +26,18 @@
 #define ZRK_API extern "C" __attribute__((visibility("default")))
 
 namespace {
+
+// Diagnostics build only (make probe -> libzrk_hot_probe.so, used by tools/sweep_phases.py): wall-clock
+// stamps (s_memrealtime, 100 MHz) per sweep wave.  The product library compiles these to nothing.
+#ifdef ZRK_PROBE_BUILD
+__device__ long long *g_wave_probe;
+#define ZRK_WAVE_PROBE(wave, slot, value)                                                                  \
+    do {                                                                                                   \
+        if ((threadIdx.x & 63) == 0 && g_wave_probe) g_wave_probe[(int64_t)(wave) * 8 + (slot)] = (value);  \
+    } while (0)
+#else
+#define ZRK_WAVE_PROBE(wave, slot, value)
+#endif
 
 constexpr double kRad2Deg = 180.0 / 3.14159265358979323846;   // numpy.degrees factor
 constexpr int kCompBlock = 1024;          // list slots per compaction workgroup (count / scan / scatter unit)
@@ -47,6 +60,18 @@ struct RadarHot {
 };
 static_assert(sizeof(RadarHot) == 80, "RadarHot must be 20 dwords");
 
+// What the pre-pass of sweep_row reads: the range sphere and the azimuth wedge, widened (host: derive_pre)
+// by everything this tick's noise can add to a row before the radar looks at it.
+struct RadarPre {
+    float px, py, pz;           // radar position, binary32
+    float d2_out;               // beyond this squared distance: certainly out of range
+    float elx, ely, ehx, ehy;   // azimuth edges as in RadarHot
+    float az_sgn;
+    float az_out;               // farther than this outside the wedge: certainly outside
+    uint32_t pad[2];
+};
+static_assert(sizeof(RadarPre) == 48, "RadarPre must be 12 dwords");
+
 struct RadarCold {
     double d2_max;              // largest d2 with sqrt(d2) <= max_distance  (== `dist > max` gate)
     double az_lo, az_hi;        // current_azimuth, current_azimuth + azimuth_range
@@ -59,6 +84,7 @@ struct RadarDev {               // host-side scratch while deriving
 };
 
 struct RadarBlock {                                 // lives in the kernel-argument segment (by value)
+    uint32_t prew[ZRK_MAX_RADARS][12];              // pre-pass records (RadarPre) as dwords, see sweep_row
     uint32_t hotw[ZRK_MAX_RADARS][20];              // RadarHot records as dwords (indexed, never addressed)
     RadarCold cold[ZRK_MAX_RADARS];
 };
@@ -73,7 +99,8 @@ struct SweepParams {
     double t;
     uint64_t seed, tick;
     int64_t gid0;
-    int32_t R, nb;
+    int32_t R, nb;              // nb: sweep workgroups, behind the mb leading workgroups that step the missiles
+    int32_t mb, _pad0;
     uint32_t flags;
     RadarBlock rb;
 };
@@ -196,36 +223,99 @@ __device__ uint8_t missile_step_row(const double *__restrict__ sp, const double 
                                     const double *__restrict__ m_radius, double *__restrict__ m_period,
                                     uint8_t *__restrict__ m_status, int64_t row, double t, double dts);
 
-template <bool PHILOX>
-__global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, const MissileArgs M)
+// Bounding box of the wave: three minima and three maxima over the 64 lanes, wave-uniform on return.
+// min / max are idempotent, so rotations inside each row of 16 (by 1, 2, 4, 8) and the two row broadcasts
+// may overlap freely; lane 63 ends up with the result of all four rows.  One v_min/v_max with a DPP source
+// per step; the six reductions are interleaved, which also covers the two wait states a DPP read needs
+// after a VALU write of the same register.
+__device__ __forceinline__ void wave_bbox(float &lx, float &ly, float &lz, float &hx, float &hy, float &hz)
 {
-    if ((int)blockIdx.x >= P.nb) {             // trailing workgroups: Missile.step for every in-flight row
-        const int64_t row = (int64_t)(blockIdx.x - P.nb) * ZRK_BLOCK + threadIdx.x;
-        if (row < M.m)
-            M.ev_code[row] = missile_step_row(M.sp, M.vel, M.t0, M.alive, M.lidx, M.pos_prev, M.cap, M.m_slot, M.m_tgt,
-                                              M.m_radius, M.m_period, M.m_status, row, M.t, M.dts);
-        return;
-    }
-    const int tid = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * ZRK_BLOCK + tid;
+#define ZRK_BBOX_STEP(ctrl)                                                                                \
+    asm volatile("v_min_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                        \
+                 "v_min_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                        \
+                 "v_min_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                        \
+                 "v_max_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                        \
+                 "v_max_f32_dpp %4, %4, %4 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                        \
+                 "v_max_f32_dpp %5, %5, %5 " ctrl " row_mask:0xf bank_mask:0xf"                             \
+                 : "+v"(lx), "+v"(ly), "+v"(lz), "+v"(hx), "+v"(hy), "+v"(hz))
+    asm volatile("s_nop 1" ::: );
+    ZRK_BBOX_STEP("row_ror:1");
+    ZRK_BBOX_STEP("row_ror:2");
+    ZRK_BBOX_STEP("row_ror:4");
+    ZRK_BBOX_STEP("row_ror:8");
+    ZRK_BBOX_STEP("row_bcast:15");
+    ZRK_BBOX_STEP("row_bcast:31");
+#undef ZRK_BBOX_STEP
+    lx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lx), 63));
+    ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ly), 63));
+    lz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lz), 63));
+    hx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hx), 63));
+    hy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hy), 63));
+    hz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hz), 63));
+}
 
+// Lane r's record for the wave-level cull of sweep_row, read as a vector load from the kernel-argument
+// segment (the sweep parameters are its first bytes).  Issued before the row loads: nobody waits for it.
+__device__ __forceinline__ RadarPre load_pre_record()
+{
+    const RadarPre *tab = (const RadarPre *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SweepParams, rb.prew));
+    return tab[threadIdx.x & (ZRK_MAX_RADARS - 1)];
+}
+
+// Radars 0..R-1 in order over one row at (x, y, z); returns the visibility mask, leaves the (perturbed)
+// position in x, y, z.  Called with the whole wave converged (the early-outs are wave-level votes).
+template <bool PHILOX>
+__device__ __forceinline__ uint32_t sweep_row(const SweepParams &P, const RadarPre &q, int64_t li, bool live, double &x,
+                                              double &y, double &z)
+{
     uint32_t mask = 0;
-    const bool live = (i < P.n) && P.alive[i];
-    const int64_t li = (P.lidx && i < P.n) ? (int64_t)P.lidx[i] : i;   // where this row sits in AirEnv's list
-    if (live) {
-        const int64_t cap = P.cap;
-        double x, y, z;
-        if (P.flags & ZRK_F_ADVANCE) {
-            // Trajectory.get_pos: three separate roundings per axis
-            const double d = P.t - P.t0[i];
-            double sx = P.vel[i] * d, sy = P.vel[cap + i] * d, sz = P.vel[2 * cap + i] * d;
-            x = P.sp[i] + sx; y = P.sp[cap + i] + sy; z = P.sp[2 * cap + i] + sz;
-        } else {
-            x = P.pos[i]; y = P.pos[cap + i]; z = P.pos[2 * cap + i];
-        }
+    {
+        // keyed by list index: layout-independent.  Seeded when the first lane of the wave is detected -- in
+        // spatial order most waves never are, and the ten Philox rounds are a fifth of a quiet wave's work.
         NoiseState ns{0u, 0u, 0u, 0u};
-        if (PHILOX) ns = noise_init(P.seed, P.tick, (uint64_t)(P.gid0 + li));   // keyed by list index: layout-independent
-        for (int r = 0; r < P.R; ++r) {
+        bool seeded = false;
+#ifdef ZRK_PROBE_BUILD
+        int probe_deep = 0;
+#endif
+        // Wave-level cull.  In spatial order the 64 rows of a wave sit in a cell about a kilometre across, and
+        // four waves in five are out of range or well outside the wedge of every radar -- yet walking the radars
+        // one after the other costs them ~20 vector instructions per radar just to find that out.  Instead the
+        // wave takes the bounding box of its live rows (six DPP reductions) and lane r tests that box against
+        // radar r: closest approach to the range sphere, interval bounds of the two wedge cross products.  The
+        // bounds (host: derive_pre) are widened by whatever this tick's noise can add before the radar looks,
+        // so "no point of the box can be in the sector" implies "no lane will be".  One pass of ~50 vector
+        // instructions settles all radars; only the radars the box may reach enter the sequential loop, which
+        // repeats its own votes on the true positions.  Conservative, never decisive; rows with non-finite
+        // coordinates (which min/max would drop from the box) switch the cull off for their wave.
+        uint32_t cand = (P.R >= 32) ? 0xFFFFFFFFu : ((1u << P.R) - 1u);
+        {
+            const float fx0 = (float)x, fy0 = (float)y, fz0 = (float)z;
+            const float kBig = 1e30f;
+            const bool tame = (fabsf(fx0) < kBig) & (fabsf(fy0) < kBig) & (fabsf(fz0) < kBig);
+            if (!__ballot(live & !tame)) {
+                const float inf = __builtin_inff();
+                float blx = live ? fx0 : inf, bly = live ? fy0 : inf, blz = live ? fz0 : inf;
+                float bhx = live ? fx0 : -inf, bhy = live ? fy0 : -inf, bhz = live ? fz0 : -inf;
+                wave_bbox(blx, bly, blz, bhx, bhy, bhz);
+                const float ex_lo = blx - q.px, ex_hi = bhx - q.px, ey_lo = bly - q.py, ey_hi = bhy - q.py;
+                const float ez_lo = blz - q.pz, ez_hi = bhz - q.pz;
+                const float gx = fmaxf(fmaxf(ex_lo, -ex_hi), 0.f), gy = fmaxf(fmaxf(ey_lo, -ey_hi), 0.f);
+                const float gz = fmaxf(fmaxf(ez_lo, -ez_hi), 0.f);
+                const float d2min = __builtin_fmaf(gz, gz, __builtin_fmaf(gy, gy, gx * gx));
+                // cl = elx * ey - ely * ex,  ch = ehy * ex - ehx * ey  over the box
+                const float a1 = q.elx * ey_lo, a2 = q.elx * ey_hi, b1 = q.ely * ex_lo, b2 = q.ely * ex_hi;
+                const float c1 = q.ehy * ex_lo, c2 = q.ehy * ex_hi, d1 = q.ehx * ey_lo, d2 = q.ehx * ey_hi;
+                const float cl_hi = fmaxf(a1, a2) - fminf(b1, b2), cl_lo = fminf(a1, a2) - fmaxf(b1, b2);
+                const float ch_hi = fmaxf(c1, c2) - fminf(d1, d2), ch_lo = fminf(c1, c2) - fmaxf(d1, d2);
+                // m_az = az_sgn * min(cl, ch) is at most ...
+                const float ub = (q.az_sgn > 0.f) ? fminf(cl_hi, ch_hi) : -fminf(cl_lo, ch_lo);
+                const bool out = (d2min > q.d2_out) | (ub < -q.az_out);
+                cand &= (uint32_t)__ballot(!out);
+                if (!__ballot(live)) cand = 0;
+            }
+        }
+        for (; cand; cand &= cand - 1) {
+            const int r = __builtin_ctz(cand);
             // one scalar-load burst for the whole hot record, resident in SGPRs before any use
             uint32_t w[18];
 #pragma unroll
@@ -249,12 +339,15 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
             // float32 range gate.  With rows stored in spatial order the lanes of a wave mostly agree,
             // so a wave none of whose lanes is in range (or, below, anywhere near the azimuth wedge)
             // leaves the radar here instead of paying for the rest of the classification.
-            const bool in_range = d2f <= d2f_out;
-            if (!__ballot(in_range)) continue;
+            const bool in_range = live & (d2f <= d2f_out);
+            if (!__ballot(live & in_range)) continue;
             const float cl = __builtin_fmaf(elx, fy, -(ely * fx));     // az_sgn * cross(e_lo, p)
             const float ch = __builtin_fmaf(fx, ehy, -(fy * ehx));     // az_sgn * cross(p, e_hi)
             const float m_az = az_sgn * fminf(cl, ch);                 // > 0 inside the azimuth sector [m]
             if (!__ballot(in_range & !(m_az < -az_guard))) continue;   // every lane certainly outside the wedge
+#ifdef ZRK_PROBE_BUILD
+            ++probe_deep;
+#endif
             const float dist = __builtin_amdgcn_sqrtf(d2f);
             // elevation: el = theta for dz >= 0, 180 + theta for dz < 0 (sign taken in binary64, so a
             // tiny negative dz that rounds to -0.0f still selects the lower-hemisphere bounds)
@@ -271,6 +364,10 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
             bool vis = in_range & (t > gd);
             const bool amb = in_range & ((fabsf(t) <= gd) | !(d2f < d2f_in));
             if (amb) vis = visible_exact(P.rb.cold[r], dx, dy, dz);
+            if (PHILOX && !seeded && __ballot(vis)) {
+                ns = noise_init(P.seed, P.tick, (uint64_t)(P.gid0 + li));
+                seeded = true;
+            }
             if (vis) {
                 mask |= 1u << r;
                 if (PHILOX) {
@@ -280,13 +377,129 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
                 }
             }
         }
-        if (PHILOX || (P.flags & ZRK_F_ADVANCE)) {
-            P.pos[i] = x; P.pos[cap + i] = y; P.pos[2 * cap + i] = z;
-        }
+#ifdef ZRK_PROBE_BUILD
+        ZRK_WAVE_PROBE((P.gid0 * 0 + li * 0) + (int64_t)(((int)blockIdx.x - P.mb) * (ZRK_BLOCK / 64) + (threadIdx.x >> 6)), 5, (long long)probe_deep);
+#endif
+    }
+    return mask;
+}
+
+template <bool PHILOX>
+__global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, const MissileArgs M)
+{
+    if ((int)blockIdx.x < P.mb) {              // leading workgroups: Missile.step for every in-flight row (a long
+        // dependent chain -- dispatched first, it is over long before the sweep's last wave is)
+        const int64_t row = (int64_t)blockIdx.x * ZRK_BLOCK + threadIdx.x;
+        if (row < M.m)
+            M.ev_code[row] = missile_step_row(M.sp, M.vel, M.t0, M.alive, M.lidx, M.pos_prev, M.cap, M.m_slot, M.m_tgt,
+                                              M.m_radius, M.m_period, M.m_status, row, M.t, M.dts);
+        return;
+    }
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)((int)blockIdx.x - P.mb) * ZRK_BLOCK + tid;
+    const int64_t cap = P.cap;
+    const RadarPre pre = load_pre_record();
+    const int64_t ic = (i < P.n) ? i : 0;
+    ZRK_WAVE_PROBE(i >> 6, 0, wall_clock64());
+    const bool live = (i < P.n) && P.alive[ic];
+    const int64_t li = (P.lidx && i < P.n) ? (int64_t)P.lidx[i] : i;   // where this row sits in AirEnv's list
+    double x, y, z;
+    if (P.flags & ZRK_F_ADVANCE) {
+        // Trajectory.get_pos: three separate roundings per axis
+        const double d = P.t - P.t0[ic];
+        double sx = P.vel[ic] * d, sy = P.vel[cap + ic] * d, sz = P.vel[2 * cap + ic] * d;
+        x = P.sp[ic] + sx; y = P.sp[cap + ic] + sy; z = P.sp[2 * cap + ic] + sz;
+    } else {
+        x = P.pos[ic]; y = P.pos[cap + ic]; z = P.pos[2 * cap + ic];
+    }
+#ifdef ZRK_PROBE_BUILD
+    asm volatile("" ::"v"(x), "v"(y), "v"(z) : "memory");
+#endif
+    ZRK_WAVE_PROBE(i >> 6, 1, wall_clock64());
+    const uint32_t mask = sweep_row<PHILOX>(P, pre, li, live, x, y, z);
+    ZRK_WAVE_PROBE(i >> 6, 2, wall_clock64());
+    ZRK_WAVE_PROBE(i >> 6, 4, (long long)__popcll(__ballot(mask != 0)));
+    if (live && (PHILOX || (P.flags & ZRK_F_ADVANCE))) {
+        P.pos[i] = x; P.pos[cap + i] = y; P.pos[2 * cap + i] = z;
     }
     // sparse mode: the buffer is known to be all zero (the previous tick's scatter cleared it), so only
     // detections are written -- list-indexed stores are scattered when the table is spatially sorted
     if (i < P.n && (mask || !(P.flags & kSparseVis))) P.vis[li] = mask;
+    ZRK_WAVE_PROBE(i >> 6, 3, wall_clock64());
+}
+
+// The same pass as a persistent grid: every wave walks chunks of 64 rows a grid-stride apart and asks for
+// the next chunk's columns as soon as the current chunk's have arrived, so the memory system works on
+// chunk k+1 while the vector pipes work on chunk k.  (The one-row-per-thread grid above alternates
+// between the two: all resident waves load, then all compute.)  ZRK_F_ADVANCE only.
+template <bool PHILOX>
+__global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep_pipe(const SweepParams P, const MissileArgs M)
+{
+    if ((int)blockIdx.x < P.mb) {
+        const int64_t row = (int64_t)blockIdx.x * ZRK_BLOCK + threadIdx.x;
+        if (row < M.m)
+            M.ev_code[row] = missile_step_row(M.sp, M.vel, M.t0, M.alive, M.lidx, M.pos_prev, M.cap, M.m_slot, M.m_tgt,
+                                              M.m_radius, M.m_period, M.m_status, row, M.t, M.dts);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int64_t cap = P.cap;
+    const int64_t nwaves = (int64_t)P.nb * (ZRK_BLOCK / 64), nchunks = (P.n + 63) / 64;
+    int64_t c = (int64_t)((int)blockIdx.x - P.mb) * (ZRK_BLOCK / 64) + (threadIdx.x >> 6);
+    if (c >= nchunks) return;
+    const RadarPre pre = load_pre_record();
+    double spx, spy, spz, vx, vy, vz, t0;
+    uint8_t al;
+    int32_t lix;
+#define ZRK_LOAD_ROW(ix)                                                                                   \
+    do {                                                                                                   \
+        const int64_t q_ = (ix) < P.n ? (ix) : P.n - 1;                                                    \
+        spx = P.sp[q_]; spy = P.sp[cap + q_]; spz = P.sp[2 * cap + q_];                                    \
+        vx = P.vel[q_]; vy = P.vel[cap + q_]; vz = P.vel[2 * cap + q_];                                    \
+        t0 = P.t0[q_]; al = P.alive[q_]; lix = P.lidx ? P.lidx[q_] : (int32_t)q_;                          \
+    } while (0)
+    ZRK_LOAD_ROW(c * 64 + lane);
+    // Results are stored one chunk late, BEFORE the next loads are issued: the vector-memory counter
+    // retires in order, so waiting for a chunk's loads then never waits for stores younger than them.
+    double ox = 0.0, oy = 0.0, oz = 0.0;
+    int64_t oi = -1, oli = 0;
+    uint32_t omask = 0;
+    bool olive = false;
+    for (;;) {
+        const int64_t i = c * 64 + lane;
+        ZRK_WAVE_PROBE(c, 0, wall_clock64());
+        const double d = P.t - t0;
+        const double sx = vx * d, sy = vy * d, sz = vz * d;
+        double x = spx + sx, y = spy + sy, z = spz + sz;
+        const bool live = (i < P.n) && al;
+        const int64_t li = lix;
+        const int live_i = live;
+        // everything this chunk needs from its loads exists (so they have arrived) ...
+        asm volatile("" ::"v"(x), "v"(y), "v"(z), "v"(live_i), "v"(li) : "memory");
+        ZRK_WAVE_PROBE(c, 1, wall_clock64());
+        if (olive) {
+            P.pos[oi] = ox; P.pos[cap + oi] = oy; P.pos[2 * cap + oi] = oz;
+        }
+        if (oi >= 0 && oi < P.n && (omask || !(P.flags & kSparseVis))) P.vis[oli] = omask;
+        asm volatile("" ::: "memory");
+        const int64_t cn = c + nwaves;
+        const bool more = cn < nchunks;
+        if (more) ZRK_LOAD_ROW(cn * 64 + lane);                // ... now ask for the next one
+        asm volatile("" ::: "memory");
+        ZRK_WAVE_PROBE(c, 6, wall_clock64());
+        omask = sweep_row<PHILOX>(P, pre, li, live, x, y, z);
+        ZRK_WAVE_PROBE(c, 2, wall_clock64());
+        ZRK_WAVE_PROBE(c, 3, wall_clock64());
+        ZRK_WAVE_PROBE(c, 4, (long long)__popcll(__ballot(omask != 0)));
+        ox = x; oy = y; oz = z; oi = i; oli = li; olive = live;
+        if (!more) break;
+        c = cn;
+    }
+    if (olive) {
+        P.pos[oi] = ox; P.pos[cap + oi] = oy; P.pos[2 * cap + oi] = oz;
+    }
+    if (oi < P.n && (omask || !(P.flags & kSparseVis))) P.vis[oli] = omask;
+#undef ZRK_LOAD_ROW
 }
 
 // Compaction, phase 1: per-block detection counts per radar (row R: seen by any radar) from vis_mask,
@@ -969,6 +1182,34 @@ void derive_radar(const zrk_radar &hr, bool exact_only, RadarHot &h, RadarCold &
     }
 }
 
+// Bounds of the pre-pass: a row that, seen from its position BEFORE this tick's noise, is farther than
+// d2_out from the radar or more than az_out outside the azimuth wedge cannot be in the sector whatever
+// happens earlier in the tick.  Slack: every detection moves a row by at most kNoiseReach (Box-Muller on
+// 16-bit uniforms: radius <= 5 * sqrt(-2 ln(2^-17)) = 24.3 m in the x-y plane and along z, 34.4 m in space),
+// at most R - 1 times before a radar looks; the distance to a wedge face and to the range sphere are
+// 1-Lipschitz in the position.  Binary32 coordinates are off by 2^-24 relative per axis: covered by
+// 4e-6 * (|radar| + reach) + 1 m and the factor on the square.  Degenerate radars keep the encoding of their
+// hot record (d2f_out < 0: never visible; infinite: every row is a candidate).
+void derive_pre(const zrk_radar &hr, const RadarHot &h, bool philox, int R, RadarPre &p)
+{
+    constexpr double kNoiseReach = 34.4;
+    std::memset(&p, 0, sizeof(p));
+    p.px = (float)hr.pos[0]; p.py = (float)hr.pos[1]; p.pz = (float)hr.pos[2];
+    p.elx = h.elx; p.ely = h.ely; p.ehx = h.ehx; p.ehy = h.ehy; p.az_sgn = h.az_sgn;
+    p.az_out = INFINITY;
+    if (h.d2f_out < 0.f) { p.d2_out = -1.f; return; }
+    p.d2_out = INFINITY;
+    if (std::isinf(h.d2f_out) || std::isnan(h.d2f_out)) return;
+    const double reach = std::sqrt((double)h.d2f_out);
+    const double centre = std::fabs(hr.pos[0]) + std::fabs(hr.pos[1]) + std::fabs(hr.pos[2]);
+    if (!std::isfinite(centre)) return;
+    const double slack = (philox ? kNoiseReach * std::max(R - 1, 0) : 0.0) + 4e-6 * (centre + reach) + 1.0;
+    const double b = (reach + slack) * (reach + slack) * (1.0 + 1e-5);
+    if (b < 3e38) p.d2_out = (float)b;
+    const double a = ((double)h.az_guard + slack) * (1.0 + 1e-5);
+    if (std::isfinite(a) && a < 3e38) p.az_out = (float)a;
+}
+
 }  // namespace
 
 struct zrk_ctx {
@@ -1020,6 +1261,13 @@ Workspace carve(void *ws, int nb)
 }
 
 }  // namespace
+
+#ifdef ZRK_PROBE_BUILD
+ZRK_API int zrk_debug_wave_probe(long long *buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wave_probe), &buf, sizeof(buf)) == hipSuccess ? 0 : ZRK_E_HIP;
+}
+#endif
 
 ZRK_API int zrk_abi_version(void) { return ZRK_ABI_VERSION; }
 
@@ -1094,13 +1342,32 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
     P.t = (double)time_ms / 1000.0;                 // to_seconds, modules/AirObject.py:5-7
     P.seed = seed; P.tick = tick; P.gid0 = gid0;
     P.R = R; P.nb = nblocks(n, ZRK_BLOCK); P.flags = flags;
+    P.mb = nblocks(M.m, ZRK_BLOCK); P._pad0 = 0;
     std::memset(&P.rb, 0, sizeof(P.rb));
-    for (int r = 0; r < R; ++r) {
-        RadarHot hot;
-        derive_radar(radars[r], (flags & ZRK_F_EXACT_ONLY) != 0, hot, P.rb.cold[r]);
-        std::memcpy(P.rb.hotw[r], &hot, sizeof(hot));
+    for (int r = 0; r < ZRK_MAX_RADARS; ++r) {
+        RadarPre pre;
+        std::memset(&pre, 0, sizeof(pre));
+        pre.d2_out = -1.f;                                  // beyond R: nobody is a candidate
+        if (r < R) {
+            RadarHot hot;
+            derive_radar(radars[r], (flags & ZRK_F_EXACT_ONLY) != 0, hot, P.rb.cold[r]);
+            std::memcpy(P.rb.hotw[r], &hot, sizeof(hot));
+            derive_pre(radars[r], hot, (flags & ZRK_F_PHILOX) != 0, R, pre);
+        }
+        std::memcpy(P.rb.prew[r], &pre, sizeof(pre));
     }
-    const int grid = P.nb + nblocks(M.m, ZRK_BLOCK);       // trailing workgroups step the missiles
+    int wps = 0;                                            // persistent grid: waves per SIMD (0: one row per thread)
+    if (const char *v = std::getenv("ZRK_SWEEP_WAVES_PER_SIMD")) wps = std::min(8, std::max(0, std::atoi(v)));
+    if (wps > 0 && (flags & ZRK_F_ADVANCE) && n > 0) {
+        P.nb = std::min(P.nb, ctx->cus * wps);              // ZRK_BLOCK = 4 waves = one per SIMD
+        const int grid = P.nb + P.mb;
+        if (flags & ZRK_F_PHILOX)
+            hipLaunchKernelGGL(k_tick_sweep_pipe<true>, dim3(grid), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
+        else
+            hipLaunchKernelGGL(k_tick_sweep_pipe<false>, dim3(grid), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
+        return check_launch(ctx, "k_tick_sweep_pipe");
+    }
+    const int grid = P.nb + P.mb;                          // leading workgroups step the missiles
     if (flags & ZRK_F_PHILOX)
         hipLaunchKernelGGL(k_tick_sweep<true>, dim3(grid), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
     else
