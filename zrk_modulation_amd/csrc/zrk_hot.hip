@@ -95,6 +95,8 @@ struct SweepParams {
     const int32_t *lidx;        // list index of each table row (NULL: the table is in list order)
     double *pos;
     uint32_t *vis;              // indexed by LIST index
+    int32_t *cost;              // per row block: radars its waves had to walk this tick (NULL: not recorded)
+    const int32_t *order;       // row block of each workgroup, expensive ones first (NULL: identity)
     int64_t n, cap;
     double t;
     uint64_t seed, tick;
@@ -123,6 +125,17 @@ struct MissileArgs {
     int64_t m;
     double t, dts;
     int32_t apply, _pad;
+};
+
+// Dispatch order of the next sweep.  The sweep's duration is set by the expensive waves (rows inside some
+// sector: ten-odd radars walked one after the other, noise drawn) that start last; which row blocks are
+// expensive changes slowly from tick to tick (the sectors turn a few degrees), so each sweep leaves its
+// per-block cost behind and an extra workgroup of the compaction turns it into next tick's order: blocks
+// that cost anything first.  Purely a schedule: every block is swept exactly once whatever the order says.
+struct OrderArgs {
+    int32_t *cost;
+    int32_t *order;
+    int32_t nb, _pad;
 };
 
 __device__ __forceinline__ double dot3(double ax, double ay, double az, double bx, double by, double bz)
@@ -262,129 +275,158 @@ __device__ __forceinline__ RadarPre load_pre_record()
     return tab[threadIdx.x & (ZRK_MAX_RADARS - 1)];
 }
 
-// Radars 0..R-1 in order over one row at (x, y, z); returns the visibility mask, leaves the (perturbed)
-// position in x, y, z.  Called with the whole wave converged (the early-outs are wave-level votes).
-template <bool PHILOX>
-__device__ __forceinline__ uint32_t sweep_row(const SweepParams &P, const RadarPre &q, int64_t li, bool live, double &x,
-                                              double &y, double &z)
+// Radars 0..R-1 in order over the NR rows each lane holds, at (x, y, z)[j]; leaves the visibility masks in
+// mask[j] and the (perturbed) positions in place.  Called with the whole wave converged (the early-outs are
+// wave-level votes).  The rows of a lane are independent of each other: NR > 1 gives the vector pipe NR
+// interleaved dependency chains per radar, one scalar-load burst and one wave-level cull for NR * 64 rows.
+template <bool PHILOX, int NR>
+__device__ __forceinline__ int sweep_rows(const SweepParams &P, const RadarPre &q, const int64_t (&li)[NR],
+                                           const bool (&live)[NR], double (&x)[NR], double (&y)[NR], double (&z)[NR],
+                                           uint32_t (&mask)[NR])
 {
-    uint32_t mask = 0;
-    {
-        // keyed by list index: layout-independent.  Seeded when the first lane of the wave is detected -- in
-        // spatial order most waves never are, and the ten Philox rounds are a fifth of a quiet wave's work.
-        NoiseState ns{0u, 0u, 0u, 0u};
-        bool seeded = false;
-#ifdef ZRK_PROBE_BUILD
-        int probe_deep = 0;
-#endif
-        // Wave-level cull.  In spatial order the 64 rows of a wave sit in a cell about a kilometre across, and
-        // four waves in five are out of range or well outside the wedge of every radar -- yet walking the radars
-        // one after the other costs them ~20 vector instructions per radar just to find that out.  Instead the
-        // wave takes the bounding box of its live rows (six DPP reductions) and lane r tests that box against
-        // radar r: closest approach to the range sphere, interval bounds of the two wedge cross products.  The
-        // bounds (host: derive_pre) are widened by whatever this tick's noise can add before the radar looks,
-        // so "no point of the box can be in the sector" implies "no lane will be".  One pass of ~50 vector
-        // instructions settles all radars; only the radars the box may reach enter the sequential loop, which
-        // repeats its own votes on the true positions.  Conservative, never decisive; rows with non-finite
-        // coordinates (which min/max would drop from the box) switch the cull off for their wave.
-        uint32_t cand = (P.R >= 32) ? 0xFFFFFFFFu : ((1u << P.R) - 1u);
-        {
-            const float fx0 = (float)x, fy0 = (float)y, fz0 = (float)z;
-            const float kBig = 1e30f;
-            const bool tame = (fabsf(fx0) < kBig) & (fabsf(fy0) < kBig) & (fabsf(fz0) < kBig);
-            if (!__ballot(live & !tame)) {
-                const float inf = __builtin_inff();
-                float blx = live ? fx0 : inf, bly = live ? fy0 : inf, blz = live ? fz0 : inf;
-                float bhx = live ? fx0 : -inf, bhy = live ? fy0 : -inf, bhz = live ? fz0 : -inf;
-                wave_bbox(blx, bly, blz, bhx, bhy, bhz);
-                const float ex_lo = blx - q.px, ex_hi = bhx - q.px, ey_lo = bly - q.py, ey_hi = bhy - q.py;
-                const float ez_lo = blz - q.pz, ez_hi = bhz - q.pz;
-                const float gx = fmaxf(fmaxf(ex_lo, -ex_hi), 0.f), gy = fmaxf(fmaxf(ey_lo, -ey_hi), 0.f);
-                const float gz = fmaxf(fmaxf(ez_lo, -ez_hi), 0.f);
-                const float d2min = __builtin_fmaf(gz, gz, __builtin_fmaf(gy, gy, gx * gx));
-                // cl = elx * ey - ely * ex,  ch = ehy * ex - ehx * ey  over the box
-                const float a1 = q.elx * ey_lo, a2 = q.elx * ey_hi, b1 = q.ely * ex_lo, b2 = q.ely * ex_hi;
-                const float c1 = q.ehy * ex_lo, c2 = q.ehy * ex_hi, d1 = q.ehx * ey_lo, d2 = q.ehx * ey_hi;
-                const float cl_hi = fmaxf(a1, a2) - fminf(b1, b2), cl_lo = fminf(a1, a2) - fmaxf(b1, b2);
-                const float ch_hi = fmaxf(c1, c2) - fminf(d1, d2), ch_lo = fminf(c1, c2) - fmaxf(d1, d2);
-                // m_az = az_sgn * min(cl, ch) is at most ...
-                const float ub = (q.az_sgn > 0.f) ? fminf(cl_hi, ch_hi) : -fminf(cl_lo, ch_lo);
-                const bool out = (d2min > q.d2_out) | (ub < -q.az_out);
-                cand &= (uint32_t)__ballot(!out);
-                if (!__ballot(live)) cand = 0;
-            }
-        }
-        for (; cand; cand &= cand - 1) {
-            const int r = __builtin_ctz(cand);
-            // one scalar-load burst for the whole hot record, resident in SGPRs before any use
-            uint32_t w[18];
+    // keyed by list index: layout-independent.  Seeded when the first lane of the wave is detected -- in
+    // spatial order most waves never are, and the ten Philox rounds are a fifth of a quiet wave's work.
+    NoiseState ns[NR];
+    bool seeded[NR];
 #pragma unroll
-            for (int k = 0; k < 18; ++k) w[k] = P.rb.hotw[r][k];
-            asm volatile("" ::"s"(w[0]), "s"(w[1]), "s"(w[2]), "s"(w[3]), "s"(w[4]), "s"(w[5]), "s"(w[6]), "s"(w[7]),
-                         "s"(w[8]), "s"(w[9]), "s"(w[10]), "s"(w[11]), "s"(w[12]), "s"(w[13]), "s"(w[14]), "s"(w[15]),
-                         "s"(w[16]), "s"(w[17]));
-            const double rpx = __builtin_bit_cast(double, ((uint64_t)w[1] << 32) | w[0]);
-            const double rpy = __builtin_bit_cast(double, ((uint64_t)w[3] << 32) | w[2]);
-            const double rpz = __builtin_bit_cast(double, ((uint64_t)w[5] << 32) | w[4]);
-            const float d2f_in = __builtin_bit_cast(float, w[6]), d2f_out = __builtin_bit_cast(float, w[7]);
-            const float elx = __builtin_bit_cast(float, w[8]), ely = __builtin_bit_cast(float, w[9]);
-            const float ehx = __builtin_bit_cast(float, w[10]), ehy = __builtin_bit_cast(float, w[11]);
-            const float s_lo_up = __builtin_bit_cast(float, w[12]), s_hi_up = __builtin_bit_cast(float, w[13]);
-            const float s_lo_dn = __builtin_bit_cast(float, w[14]), s_hi_dn = __builtin_bit_cast(float, w[15]);
-            const float az_guard = __builtin_bit_cast(float, w[16]), az_sgn = __builtin_bit_cast(float, w[17]);
-
-            const double dx = x - rpx, dy = y - rpy, dz = z - rpz;
-            const float fx = (float)dx, fy = (float)dy, fz = (float)dz;
-            const float d2f = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
-            // float32 range gate.  With rows stored in spatial order the lanes of a wave mostly agree,
-            // so a wave none of whose lanes is in range (or, below, anywhere near the azimuth wedge)
-            // leaves the radar here instead of paying for the rest of the classification.
-            const bool in_range = live & (d2f <= d2f_out);
-            if (!__ballot(live & in_range)) continue;
-            const float cl = __builtin_fmaf(elx, fy, -(ely * fx));     // az_sgn * cross(e_lo, p)
-            const float ch = __builtin_fmaf(fx, ehy, -(fy * ehx));     // az_sgn * cross(p, e_hi)
-            const float m_az = az_sgn * fminf(cl, ch);                 // > 0 inside the azimuth sector [m]
-            if (!__ballot(in_range & !(m_az < -az_guard))) continue;   // every lane certainly outside the wedge
+    for (int j = 0; j < NR; ++j) {
+        mask[j] = 0u;
+        ns[j] = NoiseState{0u, 0u, 0u, 0u};
+        seeded[j] = false;
+    }
 #ifdef ZRK_PROBE_BUILD
-            ++probe_deep;
+    int probe_deep = 0;
 #endif
-            const float dist = __builtin_amdgcn_sqrtf(d2f);
+    // Wave-level cull.  In spatial order the rows of a wave sit in a cell about a kilometre across, and
+    // four waves in five are out of range or well outside the wedge of every radar -- yet walking the radars
+    // one after the other costs them ~20 vector instructions per radar just to find that out.  Instead the
+    // wave takes the bounding box of its live rows (six DPP reductions) and lane r tests that box against
+    // radar r: closest approach to the range sphere, interval bounds of the two wedge cross products.  The
+    // bounds (host: derive_pre) are widened by whatever this tick's noise can add before the radar looks,
+    // so "no point of the box can be in the sector" implies "no lane will be".  One pass of ~50 vector
+    // instructions settles all radars; only the radars the box may reach enter the sequential loop, which
+    // repeats its own votes on the true positions.  Conservative, never decisive; rows with non-finite
+    // coordinates (which min/max would drop from the box) switch the cull off for their wave.
+    uint32_t cand = (P.R >= 32) ? 0xFFFFFFFFu : ((1u << P.R) - 1u);
+    {
+        const float inf = __builtin_inff(), kBig = 1e30f;
+        float blx = inf, bly = inf, blz = inf, bhx = -inf, bhy = -inf, bhz = -inf;
+        bool wild = false, any_live = false;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const float fx0 = (float)x[j], fy0 = (float)y[j], fz0 = (float)z[j];
+            wild |= live[j] & !((fabsf(fx0) < kBig) & (fabsf(fy0) < kBig) & (fabsf(fz0) < kBig));
+            any_live |= live[j];
+            blx = fminf(blx, live[j] ? fx0 : inf); bly = fminf(bly, live[j] ? fy0 : inf); blz = fminf(blz, live[j] ? fz0 : inf);
+            bhx = fmaxf(bhx, live[j] ? fx0 : -inf); bhy = fmaxf(bhy, live[j] ? fy0 : -inf); bhz = fmaxf(bhz, live[j] ? fz0 : -inf);
+        }
+        if (!__ballot(wild)) {
+            wave_bbox(blx, bly, blz, bhx, bhy, bhz);
+            const float ex_lo = blx - q.px, ex_hi = bhx - q.px, ey_lo = bly - q.py, ey_hi = bhy - q.py;
+            const float ez_lo = blz - q.pz, ez_hi = bhz - q.pz;
+            const float gx = fmaxf(fmaxf(ex_lo, -ex_hi), 0.f), gy = fmaxf(fmaxf(ey_lo, -ey_hi), 0.f);
+            const float gz = fmaxf(fmaxf(ez_lo, -ez_hi), 0.f);
+            const float d2min = __builtin_fmaf(gz, gz, __builtin_fmaf(gy, gy, gx * gx));
+            // cl = elx * ey - ely * ex,  ch = ehy * ex - ehx * ey  over the box
+            const float a1 = q.elx * ey_lo, a2 = q.elx * ey_hi, b1 = q.ely * ex_lo, b2 = q.ely * ex_hi;
+            const float c1 = q.ehy * ex_lo, c2 = q.ehy * ex_hi, d1 = q.ehx * ey_lo, d2 = q.ehx * ey_hi;
+            const float cl_hi = fmaxf(a1, a2) - fminf(b1, b2), cl_lo = fminf(a1, a2) - fmaxf(b1, b2);
+            const float ch_hi = fmaxf(c1, c2) - fminf(d1, d2), ch_lo = fminf(c1, c2) - fmaxf(d1, d2);
+            // m_az = az_sgn * min(cl, ch) is at most ...
+            const float ub = (q.az_sgn > 0.f) ? fminf(cl_hi, ch_hi) : -fminf(cl_lo, ch_lo);
+            const bool out = (d2min > q.d2_out) | (ub < -q.az_out);
+            cand &= (uint32_t)__ballot(!out);
+            if (!__ballot(any_live)) cand = 0;
+        }
+    }
+    const int walked = __builtin_popcount(cand);      // wave-uniform: what this wave costs, for next tick's order
+    for (; cand; cand &= cand - 1) {
+        const int r = __builtin_ctz(cand);
+        // one scalar-load burst for the whole hot record, resident in SGPRs before any use
+        uint32_t w[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) w[k] = P.rb.hotw[r][k];
+        asm volatile("" ::"s"(w[0]), "s"(w[1]), "s"(w[2]), "s"(w[3]), "s"(w[4]), "s"(w[5]), "s"(w[6]), "s"(w[7]),
+                     "s"(w[8]), "s"(w[9]), "s"(w[10]), "s"(w[11]), "s"(w[12]), "s"(w[13]), "s"(w[14]), "s"(w[15]),
+                     "s"(w[16]), "s"(w[17]));
+        const double rpx = __builtin_bit_cast(double, ((uint64_t)w[1] << 32) | w[0]);
+        const double rpy = __builtin_bit_cast(double, ((uint64_t)w[3] << 32) | w[2]);
+        const double rpz = __builtin_bit_cast(double, ((uint64_t)w[5] << 32) | w[4]);
+        const float d2f_in = __builtin_bit_cast(float, w[6]), d2f_out = __builtin_bit_cast(float, w[7]);
+        const float elx = __builtin_bit_cast(float, w[8]), ely = __builtin_bit_cast(float, w[9]);
+        const float ehx = __builtin_bit_cast(float, w[10]), ehy = __builtin_bit_cast(float, w[11]);
+        const float s_lo_up = __builtin_bit_cast(float, w[12]), s_hi_up = __builtin_bit_cast(float, w[13]);
+        const float s_lo_dn = __builtin_bit_cast(float, w[14]), s_hi_dn = __builtin_bit_cast(float, w[15]);
+        const float az_guard = __builtin_bit_cast(float, w[16]), az_sgn = __builtin_bit_cast(float, w[17]);
+
+        double dx[NR], dy[NR], dz[NR];
+        float fx[NR], fy[NR], fz[NR], d2f[NR], m_az[NR];
+        bool in_range[NR];
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            dx[j] = x[j] - rpx; dy[j] = y[j] - rpy; dz[j] = z[j] - rpz;
+            fx[j] = (float)dx[j]; fy[j] = (float)dy[j]; fz[j] = (float)dz[j];
+            d2f[j] = __builtin_fmaf(fz[j], fz[j], __builtin_fmaf(fy[j], fy[j], fx[j] * fx[j]));
+            in_range[j] = live[j] & (d2f[j] <= d2f_out);
+            any |= in_range[j];
+        }
+        // float32 range gate.  With rows stored in spatial order the lanes of a wave mostly agree,
+        // so a wave none of whose lanes is in range (or, below, anywhere near the azimuth wedge)
+        // leaves the radar here instead of paying for the rest of the classification.
+        if (!__ballot(any)) continue;
+        any = false;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const float cl = __builtin_fmaf(elx, fy[j], -(ely * fx[j]));     // az_sgn * cross(e_lo, p)
+            const float ch = __builtin_fmaf(fx[j], ehy, -(fy[j] * ehx));     // az_sgn * cross(p, e_hi)
+            m_az[j] = az_sgn * fminf(cl, ch);                                // > 0 inside the azimuth sector [m]
+            any |= in_range[j] & !(m_az[j] < -az_guard);
+        }
+        if (!__ballot(any)) continue;                                        // every lane certainly outside the wedge
+#ifdef ZRK_PROBE_BUILD
+        ++probe_deep;
+#endif
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const float dist = __builtin_amdgcn_sqrtf(d2f[j]);
             // elevation: el = theta for dz >= 0, 180 + theta for dz < 0 (sign taken in binary64, so a
             // tiny negative dz that rounds to -0.0f still selects the lower-hemisphere bounds)
-            const float a_up = __builtin_fmaf(-s_lo_up, dist, fz), b_up = __builtin_fmaf(s_hi_up, dist, -fz);
-            const float a_dn = __builtin_fmaf(-s_lo_dn, dist, fz), b_dn = __builtin_fmaf(s_hi_dn, dist, -fz);
-            const bool up = dz >= 0.0;
+            const float a_up = __builtin_fmaf(-s_lo_up, dist, fz[j]), b_up = __builtin_fmaf(s_hi_up, dist, -fz[j]);
+            const float a_dn = __builtin_fmaf(-s_lo_dn, dist, fz[j]), b_dn = __builtin_fmaf(s_hi_dn, dist, -fz[j]);
+            const bool up = dz[j] >= 0.0;
             const float a = up ? a_up : a_dn, b = up ? b_up : b_dn;
             // t: signed distance [m] to the nearest sector face (> 0 inside).  Pairs with |t| within
             // kGuard * dist of a face, and pairs in the thin shell around the range sphere, are decided
             // in binary64; everything else is settled here.  NaN / overflow fall out as "not in range"
             // (degenerate ranges are encoded by the host as d2f_out = inf, d2f_in = -1 -> always exact).
-            const float t = fminf(fminf(m_az, a), b);
+            const float t = fminf(fminf(m_az[j], a), b);
             const float gd = kGuard * dist;
-            bool vis = in_range & (t > gd);
-            const bool amb = in_range & ((fabsf(t) <= gd) | !(d2f < d2f_in));
-            if (amb) vis = visible_exact(P.rb.cold[r], dx, dy, dz);
-            if (PHILOX && !seeded && __ballot(vis)) {
-                ns = noise_init(P.seed, P.tick, (uint64_t)(P.gid0 + li));
-                seeded = true;
+            bool vis = in_range[j] & (t > gd);
+            const bool amb = in_range[j] & ((fabsf(t) <= gd) | !(d2f[j] < d2f_in));
+            if (amb) vis = visible_exact(P.rb.cold[r], dx[j], dy[j], dz[j]);
+            if (PHILOX && !seeded[j] && __ballot(vis)) {
+                ns[j] = noise_init(P.seed, P.tick, (uint64_t)(P.gid0 + li[j]));
+                seeded[j] = true;
             }
             if (vis) {
-                mask |= 1u << r;
+                mask[j] |= 1u << r;
                 if (PHILOX) {
                     float nz[3];
-                    noise_draw3(ns, 5.0f, nz);
-                    x += (double)nz[0]; y += (double)nz[1]; z += (double)nz[2];   // modules/Radar.py:142
+                    noise_draw3(ns[j], 5.0f, nz);
+                    x[j] += (double)nz[0]; y[j] += (double)nz[1]; z[j] += (double)nz[2];   // modules/Radar.py:142
                 }
             }
         }
-#ifdef ZRK_PROBE_BUILD
-        ZRK_WAVE_PROBE((P.gid0 * 0 + li * 0) + (int64_t)(((int)blockIdx.x - P.mb) * (ZRK_BLOCK / 64) + (threadIdx.x >> 6)), 5, (long long)probe_deep);
-#endif
     }
-    return mask;
+#ifdef ZRK_PROBE_BUILD
+    ZRK_WAVE_PROBE((int64_t)(((int)blockIdx.x - P.mb) * (ZRK_BLOCK / 64) + (threadIdx.x >> 6)), 5, (long long)probe_deep);
+#endif
+    return walked;
 }
 
-template <bool PHILOX>
+// One pass over the table: NR * 64 consecutive rows per wave, row j of a lane 64 rows after row j-1.
+template <bool PHILOX, int NR>
 __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, const MissileArgs M)
 {
     if ((int)blockIdx.x < P.mb) {              // leading workgroups: Missile.step for every in-flight row (a long
@@ -396,110 +438,49 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
         return;
     }
     const int tid = threadIdx.x;
-    const int64_t i = (int64_t)((int)blockIdx.x - P.mb) * ZRK_BLOCK + tid;
+    const int bid = (int)blockIdx.x - P.mb;
+    const int blk = P.order ? P.order[bid] : bid;
+    const int64_t wave = (int64_t)blk * (ZRK_BLOCK / 64) + (tid >> 6);
     const int64_t cap = P.cap;
     const RadarPre pre = load_pre_record();
-    const int64_t ic = (i < P.n) ? i : 0;
-    ZRK_WAVE_PROBE(i >> 6, 0, wall_clock64());
-    const bool live = (i < P.n) && P.alive[ic];
-    const int64_t li = (P.lidx && i < P.n) ? (int64_t)P.lidx[i] : i;   // where this row sits in AirEnv's list
-    double x, y, z;
-    if (P.flags & ZRK_F_ADVANCE) {
-        // Trajectory.get_pos: three separate roundings per axis
-        const double d = P.t - P.t0[ic];
-        double sx = P.vel[ic] * d, sy = P.vel[cap + ic] * d, sz = P.vel[2 * cap + ic] * d;
-        x = P.sp[ic] + sx; y = P.sp[cap + ic] + sy; z = P.sp[2 * cap + ic] + sz;
-    } else {
-        x = P.pos[ic]; y = P.pos[cap + ic]; z = P.pos[2 * cap + ic];
+    ZRK_WAVE_PROBE(wave, 0, wall_clock64());
+    int64_t i[NR], li[NR];
+    bool live[NR];
+    double x[NR], y[NR], z[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        i[j] = (wave * NR + j) * 64 + (tid & 63);
+        const int64_t ic = (i[j] < P.n) ? i[j] : 0;
+        live[j] = (i[j] < P.n) && P.alive[ic];
+        li[j] = (P.lidx && i[j] < P.n) ? (int64_t)P.lidx[ic] : i[j];   // where this row sits in AirEnv's list
+        if (P.flags & ZRK_F_ADVANCE) {
+            // Trajectory.get_pos: three separate roundings per axis
+            const double d = P.t - P.t0[ic];
+            const double sx = P.vel[ic] * d, sy = P.vel[cap + ic] * d, sz = P.vel[2 * cap + ic] * d;
+            x[j] = P.sp[ic] + sx; y[j] = P.sp[cap + ic] + sy; z[j] = P.sp[2 * cap + ic] + sz;
+        } else {
+            x[j] = P.pos[ic]; y[j] = P.pos[cap + ic]; z[j] = P.pos[2 * cap + ic];
+        }
     }
 #ifdef ZRK_PROBE_BUILD
-    asm volatile("" ::"v"(x), "v"(y), "v"(z) : "memory");
+    asm volatile("" ::"v"(x[NR - 1]), "v"(y[NR - 1]), "v"(z[NR - 1]) : "memory");
 #endif
-    ZRK_WAVE_PROBE(i >> 6, 1, wall_clock64());
-    const uint32_t mask = sweep_row<PHILOX>(P, pre, li, live, x, y, z);
-    ZRK_WAVE_PROBE(i >> 6, 2, wall_clock64());
-    ZRK_WAVE_PROBE(i >> 6, 4, (long long)__popcll(__ballot(mask != 0)));
-    if (live && (PHILOX || (P.flags & ZRK_F_ADVANCE))) {
-        P.pos[i] = x; P.pos[cap + i] = y; P.pos[2 * cap + i] = z;
-    }
-    // sparse mode: the buffer is known to be all zero (the previous tick's scatter cleared it), so only
-    // detections are written -- list-indexed stores are scattered when the table is spatially sorted
-    if (i < P.n && (mask || !(P.flags & kSparseVis))) P.vis[li] = mask;
-    ZRK_WAVE_PROBE(i >> 6, 3, wall_clock64());
-}
-
-// The same pass as a persistent grid: every wave walks chunks of 64 rows a grid-stride apart and asks for
-// the next chunk's columns as soon as the current chunk's have arrived, so the memory system works on
-// chunk k+1 while the vector pipes work on chunk k.  (The one-row-per-thread grid above alternates
-// between the two: all resident waves load, then all compute.)  ZRK_F_ADVANCE only.
-template <bool PHILOX>
-__global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep_pipe(const SweepParams P, const MissileArgs M)
-{
-    if ((int)blockIdx.x < P.mb) {
-        const int64_t row = (int64_t)blockIdx.x * ZRK_BLOCK + threadIdx.x;
-        if (row < M.m)
-            M.ev_code[row] = missile_step_row(M.sp, M.vel, M.t0, M.alive, M.lidx, M.pos_prev, M.cap, M.m_slot, M.m_tgt,
-                                              M.m_radius, M.m_period, M.m_status, row, M.t, M.dts);
-        return;
-    }
-    const int lane = threadIdx.x & 63;
-    const int64_t cap = P.cap;
-    const int64_t nwaves = (int64_t)P.nb * (ZRK_BLOCK / 64), nchunks = (P.n + 63) / 64;
-    int64_t c = (int64_t)((int)blockIdx.x - P.mb) * (ZRK_BLOCK / 64) + (threadIdx.x >> 6);
-    if (c >= nchunks) return;
-    const RadarPre pre = load_pre_record();
-    double spx, spy, spz, vx, vy, vz, t0;
-    uint8_t al;
-    int32_t lix;
-#define ZRK_LOAD_ROW(ix)                                                                                   \
-    do {                                                                                                   \
-        const int64_t q_ = (ix) < P.n ? (ix) : P.n - 1;                                                    \
-        spx = P.sp[q_]; spy = P.sp[cap + q_]; spz = P.sp[2 * cap + q_];                                    \
-        vx = P.vel[q_]; vy = P.vel[cap + q_]; vz = P.vel[2 * cap + q_];                                    \
-        t0 = P.t0[q_]; al = P.alive[q_]; lix = P.lidx ? P.lidx[q_] : (int32_t)q_;                          \
-    } while (0)
-    ZRK_LOAD_ROW(c * 64 + lane);
-    // Results are stored one chunk late, BEFORE the next loads are issued: the vector-memory counter
-    // retires in order, so waiting for a chunk's loads then never waits for stores younger than them.
-    double ox = 0.0, oy = 0.0, oz = 0.0;
-    int64_t oi = -1, oli = 0;
-    uint32_t omask = 0;
-    bool olive = false;
-    for (;;) {
-        const int64_t i = c * 64 + lane;
-        ZRK_WAVE_PROBE(c, 0, wall_clock64());
-        const double d = P.t - t0;
-        const double sx = vx * d, sy = vy * d, sz = vz * d;
-        double x = spx + sx, y = spy + sy, z = spz + sz;
-        const bool live = (i < P.n) && al;
-        const int64_t li = lix;
-        const int live_i = live;
-        // everything this chunk needs from its loads exists (so they have arrived) ...
-        asm volatile("" ::"v"(x), "v"(y), "v"(z), "v"(live_i), "v"(li) : "memory");
-        ZRK_WAVE_PROBE(c, 1, wall_clock64());
-        if (olive) {
-            P.pos[oi] = ox; P.pos[cap + oi] = oy; P.pos[2 * cap + oi] = oz;
+    ZRK_WAVE_PROBE(wave, 1, wall_clock64());
+    uint32_t mask[NR];
+    const int walked = sweep_rows<PHILOX, NR>(P, pre, li, live, x, y, z, mask);
+    if (P.cost && walked && (tid & 63) == 0) atomicAdd(&P.cost[blk], walked);
+    ZRK_WAVE_PROBE(wave, 2, wall_clock64());
+    ZRK_WAVE_PROBE(wave, 4, (long long)__popcll(__ballot(mask[0] != 0)));
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        if (live[j] && (PHILOX || (P.flags & ZRK_F_ADVANCE))) {
+            P.pos[i[j]] = x[j]; P.pos[cap + i[j]] = y[j]; P.pos[2 * cap + i[j]] = z[j];
         }
-        if (oi >= 0 && oi < P.n && (omask || !(P.flags & kSparseVis))) P.vis[oli] = omask;
-        asm volatile("" ::: "memory");
-        const int64_t cn = c + nwaves;
-        const bool more = cn < nchunks;
-        if (more) ZRK_LOAD_ROW(cn * 64 + lane);                // ... now ask for the next one
-        asm volatile("" ::: "memory");
-        ZRK_WAVE_PROBE(c, 6, wall_clock64());
-        omask = sweep_row<PHILOX>(P, pre, li, live, x, y, z);
-        ZRK_WAVE_PROBE(c, 2, wall_clock64());
-        ZRK_WAVE_PROBE(c, 3, wall_clock64());
-        ZRK_WAVE_PROBE(c, 4, (long long)__popcll(__ballot(omask != 0)));
-        ox = x; oy = y; oz = z; oi = i; oli = li; olive = live;
-        if (!more) break;
-        c = cn;
+        // sparse mode: the buffer is known to be all zero (the previous tick's compaction cleared it), so only
+        // detections are written -- list-indexed stores are scattered when the table is spatially sorted
+        if (i[j] < P.n && (mask[j] || !(P.flags & kSparseVis))) P.vis[li[j]] = mask[j];
     }
-    if (olive) {
-        P.pos[oi] = ox; P.pos[cap + oi] = oy; P.pos[2 * cap + oi] = oz;
-    }
-    if (oi < P.n && (omask || !(P.flags & kSparseVis))) P.vis[oli] = omask;
-#undef ZRK_LOAD_ROW
+    ZRK_WAVE_PROBE(wave, 3, wall_clock64());
 }
 
 // Compaction, phase 1: per-block detection counts per radar (row R: seen by any radar) from vis_mask,
@@ -675,6 +656,48 @@ constexpr int kAggStride = 40;                   // 64-bit words per workgroup r
 constexpr int kFusedCtlInts = 64;                // ticket, done, error, padding
 constexpr int kSpinLimit = 1 << 22;
 
+// One workgroup: order[] = row blocks with cost > 0 (ascending), then the rest (ascending); cost[] cleared.
+// (Sorting by cost instead of two classes measured the same.)
+__device__ void build_order(int *s_wave, const OrderArgs &O)
+{
+    __shared__ int s_heavy, s_carry[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    int mine = 0;
+    for (int b = tid; b < O.nb; b += blockDim.x) mine += O.cost[b] > 0;
+    for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d);
+    if (lane == 0) s_wave[wave] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        int h = 0;
+        for (int w = 0; w < nw; ++w) h += s_wave[w];
+        s_heavy = h; s_carry[0] = 0; s_carry[1] = 0;
+    }
+    __syncthreads();
+    const int heavy_total = s_heavy;
+    for (int base = 0; base < O.nb; base += blockDim.x) {
+        const int b = base + tid;
+        const bool in = b < O.nb;
+        const bool hv = in && O.cost[b] > 0;
+        if (in) O.cost[b] = 0;
+        const unsigned long long bh = __ballot(hv), bl = __ballot(in && !hv);
+        __syncthreads();                                      // s_wave free again
+        if (lane == 0) s_wave[wave] = (int)__popcll(bh) | ((int)__popcll(bl) << 16);
+        __syncthreads();
+        int oh = s_carry[0], ol = s_carry[1], th = 0, tl = 0;
+        for (int w = 0; w < nw; ++w) {
+            const int v = s_wave[w], vh = v & 0xFFFF, vl = v >> 16;
+            if (w < wave) { oh += vh; ol += vl; }
+            th += vh; tl += vl;
+        }
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        if (hv) O.order[oh + (int)__popcll(bh & below)] = b;
+        else if (in) O.order[heavy_total + ol + (int)__popcll(bl & below)] = b;
+        __syncthreads();
+        if (tid == 0) { s_carry[0] += th; s_carry[1] += tl; }
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ unsigned long long agg_load(const unsigned long long *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -687,7 +710,7 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_fused(const uint32_t *__
                                                               int32_t *__restrict__ det_cnt,
                                                               int64_t *__restrict__ packed, int64_t packed_capacity,
                                                               int64_t gid0, uint32_t *__restrict__ zero_next,
-                                                              const MissileArgs M)
+                                                              const MissileArgs M, const OrderArgs O)
 {
     constexpr int kWaves = kCompBlock / 64;
     __shared__ int s_wave[kWaves];
@@ -697,8 +720,9 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_fused(const uint32_t *__
     __shared__ int s_ticket, s_found;
     __shared__ unsigned short s_idx[kFusedMaxItems * kCompBlock];
     __shared__ uint32_t s_msk[kFusedMaxItems * kCompBlock];
-    if ((int)blockIdx.x >= nb) {                   // the one extra workgroup: missile events + tombstones
-        missile_finish_entry(s_wave, M);
+    if ((int)blockIdx.x >= nb) {                   // extra workgroups: missile events + tombstones, sweep order
+        if ((int)blockIdx.x == nb && M.m > 0) missile_finish_entry(s_wave, M);
+        else build_order(s_wave, O);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1218,6 +1242,10 @@ struct zrk_ctx {
     int fused_max_blocks = 0;          // single-launch compaction up to this many workgroups (0: never)
     uint32_t epoch = 0;                // tag of the next single-launch compaction
     const void *fused_ws = nullptr;    // workspace whose control words this context has cleared
+    const void *order_ws = nullptr;    // workspace holding a sweep order built by the last tick of zrk_run_ticks ...
+    int order_nb = 0;                  // ... for this many row blocks
+    bool order_ready = false;
+    bool order_enabled = true;
     std::string err;
     const void *ring_key = nullptr;    // mask buffers zrk_run_ticks has been alternating between ...
     int64_t ring_age = 0;              // ... for this many consecutive ticks (>= 1: the next one starts cleared)
@@ -1243,18 +1271,23 @@ inline int nblocks(int64_t n, int per) { return (int)((n + per - 1) / per); }
 struct Workspace {
     int32_t *ctl;                  // single-launch compaction: ticket, done, error
     unsigned long long *agg;       // ... and its per-workgroup records
+    int32_t *cost, *order;         // per sweep row block: cost of this tick, dispatch order of the next
     int32_t *counts, *offs, *totals;
 };
 
 constexpr int64_t kFusedBytes = kFusedCtlInts * (int64_t)sizeof(int32_t) +
                                 (int64_t)kFusedMaxBlocks * kAggStride * (int64_t)sizeof(unsigned long long);
 
-Workspace carve(void *ws, int nb)
+inline int64_t order_ints(int64_t n) { return ((n + ZRK_BLOCK - 1) / ZRK_BLOCK + 64) & ~(int64_t)63; }
+
+Workspace carve(void *ws, int nb, int64_t n)
 {
     Workspace w;
     w.ctl = (int32_t *)ws;
     w.agg = (unsigned long long *)(w.ctl + kFusedCtlInts);
-    w.totals = (int32_t *)((char *)ws + kFusedBytes);   // [ZRK_MAX_RADARS + 1] (+ pad to 64 ints)
+    w.cost = (int32_t *)((char *)ws + kFusedBytes);
+    w.order = w.cost + order_ints(n);
+    w.totals = w.order + order_ints(n);                 // [ZRK_MAX_RADARS + 1] (+ pad to 64 ints)
     w.counts = w.totals + 64;
     w.offs = w.counts + (int64_t)(ZRK_MAX_RADARS + 1) * nb;
     return w;
@@ -1282,6 +1315,7 @@ ZRK_API int zrk_ctx_create(int device, zrk_ctx **out)
     c->device = device;
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = cus;
+    if (const char *v = std::getenv("ZRK_SWEEP_ORDER")) c->order_enabled = std::atoi(v) != 0;
     c->fused_max_blocks = kFusedMaxBlocks;
     if (const char *v = std::getenv("ZRK_COMPACT_FUSED_MAX_BLOCKS")) {     // 0 = always the three-launch path
         const long k = std::strtol(v, nullptr, 10);
@@ -1299,7 +1333,7 @@ ZRK_API int64_t zrk_workspace_bytes(int64_t n_max)
 {
     if (n_max < 0) return ZRK_E_INVALID;
     const int64_t nb = (n_max + kCompBlock - 1) / kCompBlock + 1;
-    return kFusedBytes + (64 + 2 * (int64_t)(ZRK_MAX_RADARS + 1) * nb) * (int64_t)sizeof(int32_t);
+    return kFusedBytes + (2 * order_ints(n_max) + 64 + 2 * (int64_t)(ZRK_MAX_RADARS + 1) * nb) * (int64_t)sizeof(int32_t);
 }
 
 namespace {
@@ -1328,7 +1362,7 @@ MissileArgs missile_args(const zrk_entities *e, int cur, const zrk_missiles *mis
 
 int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_t time_ms, const zrk_radar *radars,
                  int R, uint32_t flags, uint64_t seed, uint64_t tick, int64_t gid0, void *workspace, void *stream,
-                 const MissileArgs &M, uint32_t *vis = nullptr)
+                 const MissileArgs &M, uint32_t *vis = nullptr, int32_t *cost = nullptr, const int32_t *order = nullptr)
 {
     if (!ctx || !e || !workspace || (R > 0 && !radars)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
     if (R < 0 || R > ZRK_MAX_RADARS)
@@ -1338,6 +1372,7 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
     SweepParams P;
     P.sp = e->start_pos; P.vel = e->velocity; P.t0 = e->start_time; P.alive = e->alive; P.lidx = e->list_index;
     P.pos = e->pos[cur]; P.vis = vis ? vis : e->vis_mask;
+    P.cost = cost; P.order = order;
     P.n = n; P.cap = e->capacity;
     P.t = (double)time_ms / 1000.0;                 // to_seconds, modules/AirObject.py:5-7
     P.seed = seed; P.tick = tick; P.gid0 = gid0;
@@ -1356,22 +1391,9 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
         }
         std::memcpy(P.rb.prew[r], &pre, sizeof(pre));
     }
-    int wps = 0;                                            // persistent grid: waves per SIMD (0: one row per thread)
-    if (const char *v = std::getenv("ZRK_SWEEP_WAVES_PER_SIMD")) wps = std::min(8, std::max(0, std::atoi(v)));
-    if (wps > 0 && (flags & ZRK_F_ADVANCE) && n > 0) {
-        P.nb = std::min(P.nb, ctx->cus * wps);              // ZRK_BLOCK = 4 waves = one per SIMD
-        const int grid = P.nb + P.mb;
-        if (flags & ZRK_F_PHILOX)
-            hipLaunchKernelGGL(k_tick_sweep_pipe<true>, dim3(grid), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
-        else
-            hipLaunchKernelGGL(k_tick_sweep_pipe<false>, dim3(grid), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
-        return check_launch(ctx, "k_tick_sweep_pipe");
-    }
-    const int grid = P.nb + P.mb;                          // leading workgroups step the missiles
-    if (flags & ZRK_F_PHILOX)
-        hipLaunchKernelGGL(k_tick_sweep<true>, dim3(grid), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
-    else
-        hipLaunchKernelGGL(k_tick_sweep<false>, dim3(grid), dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
+    const dim3 grid(P.nb + P.mb);                           // leading workgroups step the missiles
+    if (flags & ZRK_F_PHILOX) hipLaunchKernelGGL((k_tick_sweep<true, 1>), grid, dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
+    else hipLaunchKernelGGL((k_tick_sweep<false, 1>), grid, dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
     return check_launch(ctx, "k_tick_sweep");
 }
 
@@ -1386,9 +1408,23 @@ ZRK_API int zrk_tick_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int c
 
 namespace {
 
+// Slots per thread of the single-launch compaction and its workgroup count (about one per compute unit).
+int fused_items(const zrk_ctx *ctx, int64_t n)
+{
+    int items = (int)std::min<int64_t>(kFusedMaxItems, std::max<int64_t>(1, (n + (int64_t)kCompBlock * ctx->cus - 1) / ((int64_t)kCompBlock * ctx->cus)));
+    if (const char *v = std::getenv("ZRK_COMPACT_ITEMS")) items = std::min(kFusedMaxItems, std::max(1, std::atoi(v)));
+    return items;
+}
+
+bool compacts_in_one_launch(const zrk_ctx *ctx, int64_t n)
+{
+    const int items = fused_items(ctx, n);
+    return n > 0 && (n + (int64_t)kCompBlock * items - 1) / ((int64_t)kCompBlock * items) <= ctx->fused_max_blocks;
+}
+
 int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int32_t base_index, void *workspace,
                    int32_t *det_idx, int64_t det_stride, int32_t *det_cnt, int64_t *packed, int64_t packed_capacity,
-                   int64_t gid0, void *stream, const MissileArgs &M, uint32_t *zero_next)
+                   int64_t gid0, void *stream, const MissileArgs &M, uint32_t *zero_next, const OrderArgs &O)
 {
     if (!ctx || !vis_mask || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_compact: null argument");
     if ((det_idx && !det_cnt) || (!det_idx && !packed)) return fail(ctx, ZRK_E_INVALID, "zrk_compact: no output requested");
@@ -1401,11 +1437,10 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         return 0;
     }
     // single launch: about one workgroup per compute unit, each thread holding up to kFusedMaxItems slots
-    int items = (int)std::min<int64_t>(kFusedMaxItems, std::max<int64_t>(1, (n + (int64_t)kCompBlock * ctx->cus - 1) / ((int64_t)kCompBlock * ctx->cus)));
-    if (const char *v = std::getenv("ZRK_COMPACT_ITEMS")) items = std::min(kFusedMaxItems, std::max(1, std::atoi(v)));
+    const int items = fused_items(ctx, n);
     const int64_t nbf = (n + (int64_t)kCompBlock * items - 1) / ((int64_t)kCompBlock * items);
-    if (nbf <= ctx->fused_max_blocks) {
-        Workspace w = carve(workspace, 0);
+    if (compacts_in_one_launch(ctx, n)) {
+        Workspace w = carve(workspace, 0, n);
         if (ctx->fused_ws != workspace) {          // first use by this context: no ticket, no record, no error
             if (hipMemsetAsync(workspace, 0, kFusedBytes, s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "memset workspace");
             ctx->fused_ws = workspace;
@@ -1417,13 +1452,13 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         // only tickets guarantee that whoever is waited for is already running.
         int by_ticket = nbf > 2 * (int64_t)ctx->cus;
         if (const char *v = std::getenv("ZRK_COMPACT_ORDER")) by_ticket = std::strcmp(v, "block") != 0;
-        hipLaunchKernelGGL(k_compact_fused, dim3((int)nbf + (M.m > 0 ? 1 : 0)), dim3(kCompBlock), 0, s, vis_mask, n, R, (int)nbf,
-                           items, lanes, by_ticket, ctx->epoch, w.ctl, w.agg, base_index, det_idx, det_stride, det_cnt, packed,
-                           packed_capacity, gid0, zero_next, M);
+        hipLaunchKernelGGL(k_compact_fused, dim3((int)nbf + (M.m > 0 ? 1 : 0) + (O.nb > 0 ? 1 : 0)), dim3(kCompBlock), 0, s,
+                           vis_mask, n, R, (int)nbf, items, lanes, by_ticket, ctx->epoch, w.ctl, w.agg, base_index, det_idx,
+                           det_stride, det_cnt, packed, packed_capacity, gid0, zero_next, M, O);
         return check_launch(ctx, "k_compact_fused");
     }
     const int nb = nblocks(n, kCompBlock);
-    Workspace w = carve(workspace, nb);
+    Workspace w = carve(workspace, nb, n);
     hipLaunchKernelGGL(k_count_blocks, dim3(nb), dim3(kCompBlock), 0, s, vis_mask, n, R, nb, w.counts);
     hipLaunchKernelGGL(k_scan_counts, dim3(R + 1 + (M.m > 0 ? 1 : 0)), dim3(kScanThreads), 0, s, w.counts, w.offs, w.totals,
                        nb, R + 1, M);
@@ -1439,7 +1474,7 @@ ZRK_API int zrk_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R
                         int64_t packed_capacity, int64_t gid0, void *stream)
 {
     return launch_compact(ctx, vis_mask, n, R, base_index, workspace, det_idx, det_stride, det_cnt, packed, packed_capacity,
-                          gid0, stream, no_missiles(), nullptr);
+                          gid0, stream, no_missiles(), nullptr, OrderArgs{nullptr, nullptr, 0, 0});
 }
 
 ZRK_API int zrk_compact_status(zrk_ctx *ctx, void *workspace, void *stream)
@@ -1622,12 +1657,24 @@ ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missile
         uint32_t *vis_next = two_vis ? (st->vis_cur ? e->vis_mask : e->vis_mask_alt) : nullptr;
         const uint32_t sparse = (two_vis && ctx->ring_age > 0) ? kSparseVis : 0u;
         if (two_vis) ctx->ring_age += 1;
+        // next tick's dispatch order: built by this tick's compaction from the costs this tick's sweep records
+        const int nbs = nblocks(st->n, ZRK_BLOCK);
+        const bool ordering = ctx->order_enabled && (det_idx || packed) && R > 0 && nbs > 1 && compacts_in_one_launch(ctx, st->n);
+        Workspace w = carve(workspace, 0, st->n);
+        if (ordering && (ctx->order_ws != workspace || ctx->order_nb != nbs)) {
+            if (hipMemsetAsync(w.cost, 0, sizeof(int32_t) * (size_t)nbs, s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset cost"); break; }
+            ctx->order_ws = workspace; ctx->order_nb = nbs; ctx->order_ready = false;
+        }
+        if (!ordering) ctx->order_ready = false;
         rc = launch_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse, st->seed,
-                          st->tick, st->gid0, workspace, stream, M, vis_now);
+                          st->tick, st->gid0, workspace, stream, M, vis_now, ordering ? w.cost : nullptr,
+                          (ordering && ctx->order_ready) ? w.order : nullptr);
         if (prof) (void)hipEventRecord(ev[2 * (k / stride) + 1], s);
         if (rc == 0 && (det_idx || packed))
             rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, packed,
-                                packed_capacity, st->gid0, stream, M, vis_next);
+                                packed_capacity, st->gid0, stream, M, vis_next,
+                                ordering ? OrderArgs{w.cost, w.order, nbs, 0} : OrderArgs{nullptr, nullptr, 0, 0});
+        if (rc == 0 && ordering) ctx->order_ready = true;
         if (rc == 0 && m > 0 && !fused) rc = zrk_missile_step(ctx, e, st->cur, mis, m, st->time_ms, st->dt_ms, 1, stream);
         zrk_scan_advance(radars, scan, R);                                   // Radar.py:205
         st->time_ms += st->dt_ms;                                            // Manager.py:140
