@@ -847,15 +847,26 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_fused(const uint32_t *__
     if (det_idx) {
         for (int r = wave; r < R; r += kWaves) {
             int run = s_pre[r];
-            for (int c = 0; c < found; c += 64) {
-                const int k = c + lane;
-                const bool bit = (k < found) && ((s_msk[k] >> r) & 1u);
-                const unsigned long long bb = __ballot(bit);
-                if (bit) {
-                    const int64_t dst = (int64_t)run + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u));
-                    if (dst < det_stride) det_idx[(int64_t)r * det_stride + dst] = base_index + (int32_t)(blk0 + s_idx[k]);
+            int32_t *out = det_idx + (int64_t)r * det_stride;
+            for (int c = 0; c < found; c += 256) {     // four steps of 64 entries, their LDS reads in flight together
+                uint32_t q[4];
+                unsigned short ix[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = c + u * 64 + lane;
+                    q[u] = (k < found) ? s_msk[k] : 0u;
+                    ix[u] = (k < found) ? s_idx[k] : (unsigned short)0;
                 }
-                run += (int)__popcll(bb);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool bit = (q[u] >> r) & 1u;
+                    const unsigned long long bb = __ballot(bit);
+                    if (bit) {
+                        const int64_t dst = (int64_t)run + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u));
+                        if (dst < det_stride) out[dst] = base_index + (int32_t)(blk0 + ix[u]);
+                    }
+                    run += (int)__popcll(bb);
+                }
             }
         }
     }
@@ -1659,7 +1670,9 @@ ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missile
         if (two_vis) ctx->ring_age += 1;
         // next tick's dispatch order: built by this tick's compaction from the costs this tick's sweep records
         const int nbs = nblocks(st->n, ZRK_BLOCK);
-        const bool ordering = ctx->order_enabled && (det_idx || packed) && R > 0 && nbs > 1 && compacts_in_one_launch(ctx, st->n);
+        // (a grid that is resident all at once has no "last": eight workgroups of four waves fit a compute unit)
+        const bool ordering = ctx->order_enabled && (det_idx || packed) && R > 0 && nbs > 8 * ctx->cus &&
+                              compacts_in_one_launch(ctx, st->n);
         Workspace w = carve(workspace, 0, st->n);
         if (ordering && (ctx->order_ws != workspace || ctx->order_nb != nbs)) {
             if (hipMemsetAsync(w.cost, 0, sizeof(int32_t) * (size_t)nbs, s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset cost"); break; }
