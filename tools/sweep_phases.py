@@ -56,3 +56,10 @@ k = nw // 8
 print("radar-loop median by start-time octile:", " ".join(f"{np.median((swept - loaded)[order[j * k:(j + 1) * k]]):6.2f}" for j in range(8)))
 print("row-wait   median by start-time octile:", " ".join(f"{np.median((loaded - start)[order[j * k:(j + 1) * k]]):6.2f}" for j in range(8)))
 print("start      median by start-time octile:", " ".join(f"{np.median(start[order[j * k:(j + 1) * k]]):6.2f}" for j in range(8)))
+print("t [us]   resident waves   rows arriving /us (x64)   waves in the radar loop   finishing /us")
+for tt in range(0, int(end.max()) + 2):
+    res = int(((start <= tt) & (end > tt)).sum())
+    arr = int(((loaded >= tt) & (loaded < tt + 1)).sum())
+    inloop = int(((loaded <= tt) & (swept > tt)).sum())
+    fin = int(((end >= tt) & (end < tt + 1)).sum())
+    print(f"{tt:5d} {res:12d} {arr:18d} {inloop:24d} {fin:18d}")

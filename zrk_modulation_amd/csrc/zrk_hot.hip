@@ -320,7 +320,7 @@ __device__ __forceinline__ int sweep_rows(const SweepParams &P, const RadarPre &
             blx = fminf(blx, live[j] ? fx0 : inf); bly = fminf(bly, live[j] ? fy0 : inf); blz = fminf(blz, live[j] ? fz0 : inf);
             bhx = fmaxf(bhx, live[j] ? fx0 : -inf); bhy = fmaxf(bhy, live[j] ? fy0 : -inf); bhz = fmaxf(bhz, live[j] ? fz0 : -inf);
         }
-        if (!__ballot(wild)) {
+        {
             wave_bbox(blx, bly, blz, bhx, bhy, bhz);
             const float ex_lo = blx - q.px, ex_hi = bhx - q.px, ey_lo = bly - q.py, ey_hi = bhy - q.py;
             const float ez_lo = blz - q.pz, ez_hi = bhz - q.pz;
@@ -335,7 +335,8 @@ __device__ __forceinline__ int sweep_rows(const SweepParams &P, const RadarPre &
             // m_az = az_sgn * min(cl, ch) is at most ...
             const float ub = (q.az_sgn > 0.f) ? fminf(cl_hi, ch_hi) : -fminf(cl_lo, ch_lo);
             const bool out = (d2min > q.d2_out) | (ub < -q.az_out);
-            cand &= (uint32_t)__ballot(!out);
+            // (no branch around the cull: the record's loads then sit with the row's and nobody waits twice)
+            cand &= __ballot(wild) ? 0xFFFFFFFFu : (uint32_t)__ballot(!out);
             if (!__ballot(any_live)) cand = 0;
         }
     }
@@ -426,7 +427,9 @@ __device__ __forceinline__ int sweep_rows(const SweepParams &P, const RadarPre &
 }
 
 // One pass over the table: NR * 64 consecutive rows per wave, row j of a lane 64 rows after row j-1.
-template <bool PHILOX, int NR>
+// ADVANCE / LIDX mirror ZRK_F_ADVANCE and list_index != NULL as template parameters so that the row's column
+// loads sit in one basic block and are all in flight before anything waits for one.
+template <bool PHILOX, int NR, bool ADVANCE, bool LIDX>
 __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, const MissileArgs M)
 {
     if ((int)blockIdx.x < P.mb) {              // leading workgroups: Missile.step for every in-flight row (a long
@@ -450,17 +453,22 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         i[j] = (wave * NR + j) * 64 + (tid & 63);
+        // every column load of the row is issued before anything waits for one: rows past the end read row 0
         const int64_t ic = (i[j] < P.n) ? i[j] : 0;
-        live[j] = (i[j] < P.n) && P.alive[ic];
-        li[j] = (P.lidx && i[j] < P.n) ? (int64_t)P.lidx[ic] : i[j];   // where this row sits in AirEnv's list
-        if (P.flags & ZRK_F_ADVANCE) {
+        const uint8_t al = P.alive[ic];
+        const int32_t lix = LIDX ? P.lidx[ic] : 0;
+        if (ADVANCE) {
             // Trajectory.get_pos: three separate roundings per axis
-            const double d = P.t - P.t0[ic];
-            const double sx = P.vel[ic] * d, sy = P.vel[cap + ic] * d, sz = P.vel[2 * cap + ic] * d;
-            x[j] = P.sp[ic] + sx; y[j] = P.sp[cap + ic] + sy; z[j] = P.sp[2 * cap + ic] + sz;
+            const double t0 = P.t0[ic], vx = P.vel[ic], vy = P.vel[cap + ic], vz = P.vel[2 * cap + ic];
+            const double sx0 = P.sp[ic], sy0 = P.sp[cap + ic], sz0 = P.sp[2 * cap + ic];
+            const double d = P.t - t0;
+            const double sx = vx * d, sy = vy * d, sz = vz * d;
+            x[j] = sx0 + sx; y[j] = sy0 + sy; z[j] = sz0 + sz;
         } else {
             x[j] = P.pos[ic]; y[j] = P.pos[cap + ic]; z[j] = P.pos[2 * cap + ic];
         }
+        live[j] = (i[j] < P.n) & (al != 0);
+        li[j] = (LIDX && i[j] < P.n) ? (int64_t)lix : i[j];     // where this row sits in AirEnv's list
     }
 #ifdef ZRK_PROBE_BUILD
     asm volatile("" ::"v"(x[NR - 1]), "v"(y[NR - 1]), "v"(z[NR - 1]) : "memory");
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     ZRK_WAVE_PROBE(wave, 4, (long long)__popcll(__ballot(mask[0] != 0)));
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        if (live[j] && (PHILOX || (P.flags & ZRK_F_ADVANCE))) {
+        if (live[j] && (PHILOX || ADVANCE)) {
             P.pos[i[j]] = x[j]; P.pos[cap + i[j]] = y[j]; P.pos[2 * cap + i[j]] = z[j];
         }
         // sparse mode: the buffer is known to be all zero (the previous tick's compaction cleared it), so only
@@ -1403,8 +1411,13 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
         std::memcpy(P.rb.prew[r], &pre, sizeof(pre));
     }
     const dim3 grid(P.nb + P.mb);                           // leading workgroups step the missiles
-    if (flags & ZRK_F_PHILOX) hipLaunchKernelGGL((k_tick_sweep<true, 1>), grid, dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
-    else hipLaunchKernelGGL((k_tick_sweep<false, 1>), grid, dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
+    using Kernel = void (*)(const SweepParams, const MissileArgs);
+    static const Kernel variants[8] = {
+        k_tick_sweep<false, 1, false, false>, k_tick_sweep<true, 1, false, false>, k_tick_sweep<false, 1, true, false>,
+        k_tick_sweep<true, 1, true, false>,   k_tick_sweep<false, 1, false, true>, k_tick_sweep<true, 1, false, true>,
+        k_tick_sweep<false, 1, true, true>,   k_tick_sweep<true, 1, true, true>};
+    const int which = ((flags & ZRK_F_PHILOX) ? 1 : 0) | ((flags & ZRK_F_ADVANCE) ? 2 : 0) | (P.lidx ? 4 : 0);
+    hipLaunchKernelGGL(variants[which], grid, dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
     return check_launch(ctx, "k_tick_sweep");
 }
 
