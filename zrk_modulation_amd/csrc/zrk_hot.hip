@@ -236,21 +236,20 @@ __device__ uint8_t missile_step_row(const double *__restrict__ sp, const double 
                                     const double *__restrict__ m_radius, double *__restrict__ m_period,
                                     uint8_t *__restrict__ m_status, int64_t row, double t, double dts);
 
-// Bounding box of the wave: three minima and three maxima over the 64 lanes, wave-uniform on return.
+// Horizontal bounding box of the wave: two minima and two maxima over the 64 lanes, wave-uniform on return.
 // min / max are idempotent, so rotations inside each row of 16 (by 1, 2, 4, 8) and the two row broadcasts
 // may overlap freely; lane 63 ends up with the result of all four rows.  One v_min/v_max with a DPP source
-// per step; the six reductions are interleaved, which also covers the two wait states a DPP read needs
-// after a VALU write of the same register.
-__device__ __forceinline__ void wave_bbox(float &lx, float &ly, float &lz, float &hx, float &hy, float &hz)
+// per step; the four reductions are interleaved, which also covers the wait states a DPP read needs after a
+// VALU write of the same register.
+__device__ __forceinline__ void wave_bbox(float &lx, float &ly, float &hx, float &hy)
 {
 #define ZRK_BBOX_STEP(ctrl)                                                                                \
-    asm volatile("v_min_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                        \
+    asm volatile("s_nop 0\n\t"                                                                            \
+                 "v_min_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                        \
                  "v_min_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                        \
-                 "v_min_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                        \
-                 "v_max_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                        \
-                 "v_max_f32_dpp %4, %4, %4 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                        \
-                 "v_max_f32_dpp %5, %5, %5 " ctrl " row_mask:0xf bank_mask:0xf"                             \
-                 : "+v"(lx), "+v"(ly), "+v"(lz), "+v"(hx), "+v"(hy), "+v"(hz))
+                 "v_max_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                        \
+                 "v_max_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf"                             \
+                 : "+v"(lx), "+v"(ly), "+v"(hx), "+v"(hy))
     asm volatile("s_nop 1" ::: );
     ZRK_BBOX_STEP("row_ror:1");
     ZRK_BBOX_STEP("row_ror:2");
@@ -261,10 +260,8 @@ __device__ __forceinline__ void wave_bbox(float &lx, float &ly, float &lz, float
 #undef ZRK_BBOX_STEP
     lx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lx), 63));
     ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ly), 63));
-    lz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lz), 63));
     hx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hx), 63));
     hy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hy), 63));
-    hz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hz), 63));
 }
 
 // Lane r's record for the wave-level cull of sweep_row, read as a vector load from the kernel-argument
@@ -300,7 +297,7 @@ __device__ __forceinline__ int sweep_rows(const SweepParams &P, const RadarPre &
     // Wave-level cull.  In spatial order the rows of a wave sit in a cell about a kilometre across, and
     // four waves in five are out of range or well outside the wedge of every radar -- yet walking the radars
     // one after the other costs them ~20 vector instructions per radar just to find that out.  Instead the
-    // wave takes the bounding box of its live rows (six DPP reductions) and lane r tests that box against
+    // wave takes the horizontal bounding box of its live rows (four DPP reductions) and lane r tests it against
     // radar r: closest approach to the range sphere, interval bounds of the two wedge cross products.  The
     // bounds (host: derive_pre) are widened by whatever this tick's noise can add before the radar looks,
     // so "no point of the box can be in the sector" implies "no lane will be".  One pass of ~50 vector
@@ -310,23 +307,25 @@ __device__ __forceinline__ int sweep_rows(const SweepParams &P, const RadarPre &
     uint32_t cand = (P.R >= 32) ? 0xFFFFFFFFu : ((1u << P.R) - 1u);
     {
         const float inf = __builtin_inff(), kBig = 1e30f;
-        float blx = inf, bly = inf, blz = inf, bhx = -inf, bhy = -inf, bhz = -inf;
+        float blx = 0.f, bly = 0.f, bhx = 0.f, bhy = 0.f;
         bool wild = false, any_live = false;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const float fx0 = (float)x[j], fy0 = (float)y[j], fz0 = (float)z[j];
             wild |= live[j] & !((fabsf(fx0) < kBig) & (fabsf(fy0) < kBig) & (fabsf(fz0) < kBig));
             any_live |= live[j];
-            blx = fminf(blx, live[j] ? fx0 : inf); bly = fminf(bly, live[j] ? fy0 : inf); blz = fminf(blz, live[j] ? fz0 : inf);
-            bhx = fmaxf(bhx, live[j] ? fx0 : -inf); bhy = fmaxf(bhy, live[j] ? fy0 : -inf); bhz = fmaxf(bhz, live[j] ? fz0 : -inf);
+            const float lox = live[j] ? fx0 : inf, loy = live[j] ? fy0 : inf;
+            const float hix = live[j] ? fx0 : -inf, hiy = live[j] ? fy0 : -inf;
+            blx = j ? fminf(blx, lox) : lox; bly = j ? fminf(bly, loy) : loy;
+            bhx = j ? fmaxf(bhx, hix) : hix; bhy = j ? fmaxf(bhy, hiy) : hiy;
         }
         {
-            wave_bbox(blx, bly, blz, bhx, bhy, bhz);
+            wave_bbox(blx, bly, bhx, bhy);
+            // the box is horizontal only: heights add little to the closest approach (a sector's range is
+            // several times any altitude) and nothing to the wedge test, and each extra extent costs a reduction
             const float ex_lo = blx - q.px, ex_hi = bhx - q.px, ey_lo = bly - q.py, ey_hi = bhy - q.py;
-            const float ez_lo = blz - q.pz, ez_hi = bhz - q.pz;
             const float gx = fmaxf(fmaxf(ex_lo, -ex_hi), 0.f), gy = fmaxf(fmaxf(ey_lo, -ey_hi), 0.f);
-            const float gz = fmaxf(fmaxf(ez_lo, -ez_hi), 0.f);
-            const float d2min = __builtin_fmaf(gz, gz, __builtin_fmaf(gy, gy, gx * gx));
+            const float d2min = __builtin_fmaf(gy, gy, gx * gx);
             // cl = elx * ey - ely * ex,  ch = ehy * ex - ehx * ey  over the box
             const float a1 = q.elx * ey_lo, a2 = q.elx * ey_hi, b1 = q.ely * ex_lo, b2 = q.ely * ex_hi;
             const float c1 = q.ehy * ex_lo, c2 = q.ehy * ex_hi, d1 = q.ehx * ey_lo, d2 = q.ehx * ey_hi;
