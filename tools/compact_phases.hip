@@ -5,7 +5,7 @@
 //   /tmp/compact_phases [n] [R] [items] [by_ticket]
 #include <hip/hip_runtime.h>
 __device__ long long *g_probe;
-#define ZRK_PROBE(slot) do { if (threadIdx.x == 0 && g_probe) g_probe[(long long)s_ticket * 8 + (slot)] = wall_clock64(); } while (0)
+#define ZRK_PROBE(slot) do { if (threadIdx.x == 0 && g_probe) g_probe[(long long)S.ticket * 8 + (slot)] = wall_clock64(); } while (0)
 #include "../zrk_modulation_amd/csrc/zrk_hot.hip"
 #include <random>
 #include <vector>
@@ -31,15 +31,18 @@ int main(int argc, char **argv)
     hipMalloc(&probe, (int64_t)nb * 8 * 8); hipMemset(probe, 0, (int64_t)nb * 8 * 8);
     hipMemcpy(dvis, vis.data(), n * 4, hipMemcpyHostToDevice);
     hipMemcpyToSymbol(HIP_SYMBOL(g_probe), &probe, sizeof(probe));
-    Workspace w = carve(ws, 0);
+    Workspace w = carve(ws, 0, n);
     int lanes = 1; while (lanes < R + 1) lanes <<= 1;
     MissileArgs M = no_missiles();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0;
     for (int rep = 0; rep < 30; ++rep) {
         if (rep == 29) hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(k_compact_fused, dim3(nb), dim3(kCompBlock), 0, 0, dvis, n, R, nb, items, lanes, by_ticket, (uint32_t)(rep + 1),
-                           w.ctl, w.agg, 0, det, n, cnt, packed, n + 1, (int64_t)0, dzero, M);
+        CompactArgs C;
+        C.vis = dvis; C.zero_next = dzero; C.n = n; C.R = R; C.nb = nb; C.items = items; C.lanes = lanes; C.epoch = (uint32_t)(rep + 1);
+        C.base_index = 0; C.ctl = w.ctl; C.agg = w.agg; C.det_idx = det; C.det_stride = n; C.det_cnt = cnt; C.packed = packed;
+        C.packed_capacity = n + 1; C.gid0 = 0;
+        hipLaunchKernelGGL(k_compact_fused, dim3(nb), dim3(kCompBlock), 0, 0, C, by_ticket, M, OrderArgs{nullptr, nullptr, 0, 0});
         if (rep == 29) hipEventRecord(e1, 0);
     }
     hipDeviceSynchronize();

@@ -710,59 +710,68 @@ __device__ __forceinline__ unsigned long long agg_load(const unsigned long long 
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(kCompBlock) void k_compact_fused(const uint32_t *__restrict__ vis, int64_t n, int R, int nb,
-                                                              int items, int lanes_per_rec, int by_ticket,
-                                                              uint32_t epoch, int32_t *ctl, unsigned long long *agg, int32_t base_index,
-                                                              int32_t *__restrict__ det_idx, int64_t det_stride,
-                                                              int32_t *__restrict__ det_cnt,
-                                                              int64_t *__restrict__ packed, int64_t packed_capacity,
-                                                              int64_t gid0, uint32_t *__restrict__ zero_next,
-                                                              const MissileArgs M, const OrderArgs O)
+struct CompactArgs {
+    const uint32_t *vis;           // NULL: nothing to compact
+    uint32_t *zero_next;
+    int64_t n;
+    int32_t R, nb, items, lanes;   // nb workgroups of `items` slots per thread; lanes: power of two >= R + 1
+    uint32_t epoch;
+    int32_t base_index;
+    int32_t *ctl;
+    unsigned long long *agg;
+    int32_t *det_idx;
+    int64_t det_stride;
+    int32_t *det_cnt;
+    int64_t *packed;
+    int64_t packed_capacity, gid0;
+};
+
+template <int THREADS>
+struct CompactShared {
+    int wcnt[kFusedMaxItems * (THREADS / 64)];
+    int cnt[ZRK_MAX_RADARS + 1];
+    int pre[ZRK_MAX_RADARS + 1];
+    int ticket, found;
+    unsigned short idx[kFusedMaxItems * THREADS];  // detected slots of this workgroup, in list order ...
+    uint32_t msk[kFusedMaxItems * THREADS];        // ... and their masks
+};
+
+// One workgroup of the single-launch compaction (THREADS threads, C.items slots each).  Runs as the stand-alone
+// kernel below (1024 threads) and as the leading workgroups of the next tick's sweep (ZRK_BLOCK threads).
+template <int THREADS>
+__device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const CompactArgs &C, int by_ticket)
 {
-    constexpr int kWaves = kCompBlock / 64;
-    __shared__ int s_wave[kWaves];
-    __shared__ int s_wcnt[kFusedMaxItems * kWaves];
-    __shared__ int s_cnt[ZRK_MAX_RADARS + 1];
-    __shared__ int s_pre[ZRK_MAX_RADARS + 1];
-    __shared__ int s_ticket, s_found;
-    __shared__ unsigned short s_idx[kFusedMaxItems * kCompBlock];
-    __shared__ uint32_t s_msk[kFusedMaxItems * kCompBlock];
-    if ((int)blockIdx.x >= nb) {                   // extra workgroups: missile events + tombstones, sweep order
-        if ((int)blockIdx.x == nb && M.m > 0) missile_finish_entry(s_wave, M);
-        else build_order(s_wave, O);
-        return;
-    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_ticket = by_ticket ? atomicAdd(&ctl[0], 1) : (int)blockIdx.x;
-    if (tid <= ZRK_MAX_RADARS) s_pre[tid] = 0;
+    if (tid == 0) S.ticket = by_ticket ? atomicAdd(&C.ctl[0], 1) : (int)blockIdx.x;
+    if (tid <= ZRK_MAX_RADARS) S.pre[tid] = 0;
     __syncthreads();
-    const int b = s_ticket;
-    if (b < 0 || b >= nb) {                        // a workspace that was not ours: refuse rather than scribble
-        if (tid == 0) atomicExch(&ctl[2], 1);
+    const int b = S.ticket;
+    if (b < 0 || b >= C.nb) {                        // a workspace that was not ours: refuse rather than scribble
+        if (tid == 0) atomicExch(&C.ctl[2], 1);
         return;
     }
-    const int64_t blk0 = (int64_t)b * items * kCompBlock;
+    const int64_t blk0 = (int64_t)b * C.items * THREADS;
     ZRK_PROBE(0);
     uint32_t mk[kFusedMaxItems];
 #pragma unroll
     for (int it = 0; it < kFusedMaxItems; ++it) {  // every load in flight before anything looks at one
-        const int64_t i = blk0 + (int64_t)it * kCompBlock + tid;
-        mk[it] = (it < items && i < n) ? vis[i] : 0u;
+        const int64_t i = blk0 + (int64_t)it * THREADS + tid;
+        mk[it] = (it < C.items && i < C.n) ? C.vis[i] : 0u;
     }
 #pragma unroll
     for (int it = 0; it < kFusedMaxItems; ++it) {
-        if (it < items) {
-            const int64_t i = blk0 + (int64_t)it * kCompBlock + tid;
-            if (zero_next && i < n) zero_next[i] = 0u;   // next tick's (other) mask buffer, cleared in passing
+        if (it < C.items) {
+            const int64_t i = blk0 + (int64_t)it * THREADS + tid;
+            if (C.zero_next && i < C.n) C.zero_next[i] = 0u;   // next tick's (other) mask buffer, cleared in passing
             const unsigned long long bu = __ballot(mk[it] != 0u);
-            if (lane == 0) s_wcnt[it * kWaves + wave] = (int)__popcll(bu);
+            if (lane == 0) S.wcnt[it * (THREADS / 64) + wave] = (int)__popcll(bu);
         }
     }
     ZRK_PROBE(1);
     __syncthreads();
     if (wave == 0) {                               // exclusive scan of the (item, wave) counts: list order
-        const int m2 = items * kWaves;
-        const int a0 = (2 * lane < m2) ? s_wcnt[2 * lane] : 0, a1 = (2 * lane + 1 < m2) ? s_wcnt[2 * lane + 1] : 0;
+        const int m2 = C.items * (THREADS / 64);
+        const int a0 = (2 * lane < m2) ? S.wcnt[2 * lane] : 0, a1 = (2 * lane + 1 < m2) ? S.wcnt[2 * lane + 1] : 0;
         int incl = a0 + a1;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -770,99 +779,99 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_fused(const uint32_t *__
             if (lane >= d) incl += up;
         }
         const int excl = incl - a0 - a1;
-        if (2 * lane < m2) s_wcnt[2 * lane] = excl;
-        if (2 * lane + 1 < m2) s_wcnt[2 * lane + 1] = excl + a0;
-        if (lane == 63) s_found = incl;
+        if (2 * lane < m2) S.wcnt[2 * lane] = excl;
+        if (2 * lane + 1 < m2) S.wcnt[2 * lane + 1] = excl + a0;
+        if (lane == 63) S.found = incl;
     }
     __syncthreads();
-    const int found = s_found;
+    const int found = S.found;
 #pragma unroll
     for (int it = 0; it < kFusedMaxItems; ++it) {
-        if (it < items) {
+        if (it < C.items) {
             const unsigned long long bu = __ballot(mk[it] != 0u);
             if (mk[it] != 0u) {
-                const int k = s_wcnt[it * kWaves + wave] +
+                const int k = S.wcnt[it * (THREADS / 64) + wave] +
                               (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bu >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bu, 0u));
-                s_idx[k] = (unsigned short)(it * kCompBlock + tid);
-                s_msk[k] = mk[it];
+                S.idx[k] = (unsigned short)(it * THREADS + tid);
+                S.msk[k] = mk[it];
             }
         }
     }
     __syncthreads();
     ZRK_PROBE(2);
-    for (int r = wave; r < R; r += kWaves) {       // per-radar counts over the short list
+    for (int r = wave; r < C.R; r += (THREADS / 64)) {       // per-radar counts over the short list
         int run = 0;
         for (int c = 0; c < found; c += 256) {
             uint32_t q[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k = c + u * 64 + lane;
-                q[u] = (k < found) ? s_msk[k] : 0u;
+                q[u] = (k < found) ? S.msk[k] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) run += (int)__popcll(__ballot((q[u] >> r) & 1u));
         }
-        if (lane == 0) s_cnt[r] = run;
+        if (lane == 0) S.cnt[r] = run;
     }
-    if (tid == 0) s_cnt[R] = found;
+    if (tid == 0) S.cnt[C.R] = found;
     __syncthreads();
     ZRK_PROBE(3);
-    if (tid <= R)
-        __hip_atomic_store(&agg[(int64_t)b * kAggStride + tid], ((unsigned long long)epoch << 32) | (uint32_t)s_cnt[tid],
+    if (tid <= C.R)
+        __hip_atomic_store(&C.agg[(int64_t)b * kAggStride + tid], ((unsigned long long)C.epoch << 32) | (uint32_t)S.cnt[tid],
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     {
-        // lower tickets: record p, counter c is word p * lanes_per_rec + c of a (p, c) grid dealt out to the
-        // threads kCompBlock apart (lanes_per_rec: a power of two >= R+1), kBatch loads in flight per thread
+        // lower tickets: record p, counter c is word p * C.lanes + c of a (p, c) grid dealt out to the
+        // threads THREADS apart (C.lanes: a power of two >= C.R+1), kBatch loads in flight per thread
         constexpr int kBatch = 8;
-        const int c = tid & (lanes_per_rec - 1);
-        const int p_first = tid / lanes_per_rec, p_step = kCompBlock / lanes_per_rec;
+        const int c = tid & (C.lanes - 1);
+        const int p_first = tid / C.lanes, p_step = THREADS / C.lanes;
         int acc = 0;
         bool timed_out = false;
-        if (c <= R) {
+        if (c <= C.R) {
             for (int p0 = p_first; p0 < b; p0 += p_step * kBatch) {
                 unsigned long long v[kBatch];
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u) {
                     const int p = p0 + u * p_step;
-                    v[u] = (p < b) ? agg_load(&agg[(int64_t)p * kAggStride + c]) : ((unsigned long long)epoch << 32);
+                    v[u] = (p < b) ? agg_load(&C.agg[(int64_t)p * kAggStride + c]) : ((unsigned long long)C.epoch << 32);
                 }
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u) {
                     const int p = p0 + u * p_step;
                     int spins = 0;
-                    while ((uint32_t)(v[u] >> 32) != epoch) {
+                    while ((uint32_t)(v[u] >> 32) != C.epoch) {
                         if (++spins > kSpinLimit) { timed_out = true; break; }
                         __builtin_amdgcn_s_sleep(1);
-                        v[u] = agg_load(&agg[(int64_t)p * kAggStride + c]);
+                        v[u] = agg_load(&C.agg[(int64_t)p * kAggStride + c]);
                     }
                     acc += (int)(uint32_t)v[u];
                 }
             }
-            if (acc) atomicAdd(&s_pre[c], acc);
-            if (timed_out) atomicExch(&ctl[2], 2);
+            if (acc) atomicAdd(&S.pre[c], acc);
+            if (timed_out) atomicExch(&C.ctl[2], 2);
         }
     }
     __syncthreads();
     ZRK_PROBE(4);
-    if (packed) {
-        const int64_t ubase = s_pre[R];
-        for (int k = tid; k < found; k += kCompBlock) {
+    if (C.packed) {
+        const int64_t ubase = S.pre[C.R];
+        for (int k = tid; k < found; k += THREADS) {
             const int64_t dst = ubase + k;
-            if (dst + 1 < packed_capacity) packed[dst + 1] = ((gid0 + blk0 + s_idx[k]) << 32) | (int64_t)s_msk[k];
+            if (dst + 1 < C.packed_capacity) C.packed[dst + 1] = ((C.gid0 + blk0 + S.idx[k]) << 32) | (int64_t)S.msk[k];
         }
     }
-    if (det_idx) {
-        for (int r = wave; r < R; r += kWaves) {
-            int run = s_pre[r];
-            int32_t *out = det_idx + (int64_t)r * det_stride;
+    if (C.det_idx) {
+        for (int r = wave; r < C.R; r += (THREADS / 64)) {
+            int run = S.pre[r];
+            int32_t *out = C.det_idx + (int64_t)r * C.det_stride;
             for (int c = 0; c < found; c += 256) {     // four steps of 64 entries, their LDS reads in flight together
                 uint32_t q[4];
                 unsigned short ix[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int k = c + u * 64 + lane;
-                    q[u] = (k < found) ? s_msk[k] : 0u;
-                    ix[u] = (k < found) ? s_idx[k] : (unsigned short)0;
+                    q[u] = (k < found) ? S.msk[k] : 0u;
+                    ix[u] = (k < found) ? S.idx[k] : (unsigned short)0;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -870,25 +879,38 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_fused(const uint32_t *__
                     const unsigned long long bb = __ballot(bit);
                     if (bit) {
                         const int64_t dst = (int64_t)run + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u));
-                        if (dst < det_stride) out[dst] = base_index + (int32_t)(blk0 + ix[u]);
+                        if (dst < C.det_stride) out[dst] = C.base_index + (int32_t)(blk0 + ix[u]);
                     }
                     run += (int)__popcll(bb);
                 }
             }
         }
     }
-    if (b == nb - 1 && tid <= R) {                 // the end of the list: totals
-        const int tot = s_pre[tid] + s_cnt[tid];
-        if (det_cnt) det_cnt[tid] = tot;
-        if (packed && tid == R) packed[0] = tot;
+    if (b == C.nb - 1 && tid <= C.R) {                 // the end of the list: totals
+        const int tot = S.pre[tid] + S.cnt[tid];
+        if (C.det_cnt) C.det_cnt[tid] = tot;
+        if (C.packed && tid == C.R) C.packed[0] = tot;
     }
     ZRK_PROBE(5);
     if (by_ticket && tid == 0) {
-        if (atomicAdd(&ctl[1], 1) == nb - 1) {     // everybody holds a ticket and is done with it
-            atomicExch(&ctl[0], 0);
-            atomicExch(&ctl[1], 0);
+        if (atomicAdd(&C.ctl[1], 1) == C.nb - 1) {     // everybody holds a ticket and is done with it
+            atomicExch(&C.ctl[0], 0);
+            atomicExch(&C.ctl[1], 0);
         }
     }
+}
+
+__global__ __launch_bounds__(kCompBlock) void k_compact_fused(const CompactArgs C, int by_ticket, const MissileArgs M,
+                                                              const OrderArgs O)
+{
+    __shared__ int s_wave[kCompBlock / 64];
+    __shared__ CompactShared<kCompBlock> S;
+    if ((int)blockIdx.x >= C.nb) {                 // extra workgroups: missile events + tombstones, sweep order
+        if ((int)blockIdx.x == C.nb && M.m > 0) missile_finish_entry(s_wave, M);
+        else build_order(s_wave, O);
+        return;
+    }
+    compact_block<kCompBlock>(S, C, by_ticket);
 }
 
 // SectorRadar.smooth_objects with supplied draws: pos[idx[j]] += noise[j].
@@ -1475,9 +1497,12 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         // only tickets guarantee that whoever is waited for is already running.
         int by_ticket = nbf > 2 * (int64_t)ctx->cus;
         if (const char *v = std::getenv("ZRK_COMPACT_ORDER")) by_ticket = std::strcmp(v, "block") != 0;
-        hipLaunchKernelGGL(k_compact_fused, dim3((int)nbf + (M.m > 0 ? 1 : 0) + (O.nb > 0 ? 1 : 0)), dim3(kCompBlock), 0, s,
-                           vis_mask, n, R, (int)nbf, items, lanes, by_ticket, ctx->epoch, w.ctl, w.agg, base_index, det_idx,
-                           det_stride, det_cnt, packed, packed_capacity, gid0, zero_next, M, O);
+        CompactArgs C;
+        C.vis = vis_mask; C.zero_next = zero_next; C.n = n; C.R = R; C.nb = (int)nbf; C.items = items; C.lanes = lanes;
+        C.epoch = ctx->epoch; C.base_index = base_index; C.ctl = w.ctl; C.agg = w.agg; C.det_idx = det_idx;
+        C.det_stride = det_stride; C.det_cnt = det_cnt; C.packed = packed; C.packed_capacity = packed_capacity; C.gid0 = gid0;
+        hipLaunchKernelGGL(k_compact_fused, dim3((int)nbf + (M.m > 0 ? 1 : 0) + (O.nb > 0 ? 1 : 0)), dim3(kCompBlock), 0, s, C,
+                           by_ticket, M, O);
         return check_launch(ctx, "k_compact_fused");
     }
     const int nb = nblocks(n, kCompBlock);
