@@ -31,7 +31,8 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PROF_STRIDE = 8                # sweep kernel timed with HIP events every 8th tick
+PROF_STRIDE = 8                # sweep kernel timed with HIP events every 8th tick (one call covers all ticks) ...
+PROF_STRIDE_RANKS = 64         # ... every 64th when ticks are driven one call at a time: reading the events drains the stream
 
 
 def build_engine(workload, rank, world, device, seed_off=0):
@@ -189,6 +190,8 @@ def main():
                 w.wait()
                 xchg["work"][k] = None
 
+    stride = PROF_STRIDE if world == 1 else PROF_STRIDE_RANKS
+
     def run_ticks(k, sweep_ms=None):
         if world == 1:
             eng.run(k, sweep_ms=sweep_ms, prof_stride=PROF_STRIDE)
@@ -198,12 +201,12 @@ def main():
             if xchg["work"][b] is not None:
                 xchg["work"][b].wait()
             eng.packed = xchg["buf"][b]
-            one = np.zeros(1, np.float32) if (sweep_ms is not None and j % PROF_STRIDE == 0) else None
+            one = np.zeros(1, np.float32) if (sweep_ms is not None and j % stride == 0) else None
             eng.run(1, sweep_ms=one, prof_stride=1)
             xchg["work"][b] = xchg["ex"][b].all_gather(eng.packed, async_op=True)
             xchg["tick"] += 1
             if one is not None:
-                sweep_ms[j // PROF_STRIDE] = one[0]
+                sweep_ms[j // stride] = one[0]
 
     if world > 1:
         size_exchange(eng.packed.numel() - 1)
@@ -224,7 +227,7 @@ def main():
         size_exchange(int(seen.item() * 1.5) + 1024)
     barrier()
     live0 = eng.alive_count()
-    sweep_ms = np.zeros((args.steps + PROF_STRIDE - 1) // PROF_STRIDE, np.float32)
+    sweep_ms = np.zeros((args.steps + stride - 1) // stride, np.float32)
     barrier()
     t0 = time.perf_counter()
     run_ticks(args.steps, sweep_ms)
