@@ -129,3 +129,41 @@ def test_many_launches_on_one_workspace(factory):
     st.compact_status()
     for vis, R, det, cnt, packed, _ in keep:
         _check(det.cpu().numpy(), cnt.cpu().numpy(), packed.cpu().numpy(), vis, R)
+
+
+@pytest.mark.parametrize("order", ["ticket", "block"])
+def test_both_waiting_orders(factory, monkeypatch, order):
+    """Workgroups ordered by atomic tickets (the rule beyond two workgroups per compute unit) and by blockIdx
+    give the same lists; the ticket counter rearms itself between launches."""
+    monkeypatch.setenv("ZRK_COMPACT_ORDER", order)
+    g = np.random.Generator(np.random.PCG64(77))
+    for n, R in [(300_000, 16), (5_000, 3), (1_000_000, 32)]:
+        vis = _masks(g, n, R, 0.2)
+        for items in (1, 2):
+            if n // (1024 * items) >= 1024:
+                continue
+            det, cnt, packed = _run(factory(items=items), vis, R)
+            _check(det, cnt, packed, vis, R)
+
+
+def test_status_reports_a_foreign_workspace(factory):
+    """Control words that are not as the library left them: the launch refuses to scribble, the status call says so,
+    and the next use starts from a cleared control area."""
+    import torch
+    from zrk_modulation_amd._lib import ZrkError
+    st = factory()()
+    g = np.random.Generator(np.random.PCG64(5))
+    vis = _masks(g, 10_000, 4, 0.3)
+    det, cnt, packed = _run(lambda: st, vis, 4)
+    _check(det, cnt, packed, vis, 4)
+    ws = st.workspace()
+    ws[:4] = torch.tensor([0x40, 0x42, 0x0F, 0x7F], dtype=torch.uint8, device=ws.device)    # a huge "ticket"
+    import os
+    os.environ["ZRK_COMPACT_ORDER"] = "ticket"
+    try:
+        with pytest.raises(ZrkError):
+            _run(lambda: st, vis, 4)
+    finally:
+        os.environ.pop("ZRK_COMPACT_ORDER", None)
+    det, cnt, packed = _run(lambda: st, vis, 4)               # cleared again on the next use
+    _check(det, cnt, packed, vis, 4)
