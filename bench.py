@@ -220,11 +220,12 @@ def main():
     run_ticks(args.warmup)
     overflow = False
     if world > 1:
-        # size the fixed exchange buffers from what the warm-up saw (1.5x the largest per-rank count)
+        # size the fixed exchange buffers from what the warm-up saw (1.25x the largest per-rank count: the count
+        # follows the sectors round their scan period, which the warm-up covers; an overflow is reported)
         drain_exchange()
         seen = torch.tensor([max(max(e.counts()) for e in xchg["ex"])], dtype=torch.int64, device=device)
         dist.all_reduce(seen, op=dist.ReduceOp.MAX)
-        size_exchange(int(seen.item() * 1.5) + 1024)
+        size_exchange(int(seen.item() * 1.25) + 1024)
     barrier()
     live0 = eng.alive_count()
     sweep_ms = np.zeros((args.steps + stride - 1) // stride, np.float32)
