@@ -65,6 +65,22 @@ def pmc_traffic(workload, world):
     return None
 
 
+def profiled_kernel_us(workload, world):
+    """Average duration of the sweep kernel in the committed rocprofv3 --kernel-trace --stats summary of this
+    command (profiles/r01_g_final_kernel_stats.csv), for cross-reference with the live HIP-event figure: the
+    event pair also brackets the dispatch latency on both sides of the kernel (about 3 us).  Recorded, not live."""
+    try:
+        if workload != "C3" or world != 1:
+            return None
+        import csv
+        for row in csv.DictReader(open(ROOT / "profiles" / "r01_g_final_kernel_stats.csv")):
+            if "k_tick_sweep" in row["Name"]:
+                return float(row["AverageNs"]) / 1e3
+    except Exception:
+        pass
+    return None
+
+
 def usable_cores():
     """Threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
     cores = os.cpu_count() or 1
@@ -268,7 +284,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, world),
                          "kernel": "k_tick_sweep",
-                         "avg_kernel_us": sweep_avg_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
+                         "avg_kernel_us": sweep_avg_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
+                         "profiled_kernel_us": profiled_kernel_us(args.workload, world)},
         }
         if world > 1:
             out["config"]["exchange_entries_per_rank"] = xchg["ex"][0].capacity
