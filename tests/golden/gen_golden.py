@@ -23,6 +23,8 @@ Per fixture (see `capture`):
     launch_ok[k,3] + launch_traj[k,7]   (t_ms, missile_id, target_id), (V, start_pos, start_time)
     launch_cancel[k,2] + reasons (t_ms, missile_id), str
     new_missile[k,2]             (t_ms, missile_id)                              NEW_MISSILE
+    draw_ids / draw_off / draw_vis / draw_pos / draw_type   DRAW_OBJECTS per tick, in message order (ragged):
+                                 obj_id, is_visible_by_radar, coordinates (float64), index into draw_types
     histogram                    JSON {MessageType.name: count}
 """
 import json
@@ -120,7 +122,9 @@ def capture(scene, sample_every=1):
         T = 0
         rec = dict(tick_ms=[], act_ids=[], act_off=[0], pos=[], prev=[], prev_valid=[], samp_tick=[],
                    samp_off=[0], pos_digest=[], found_ids=[], found_off=[0], radar_state=[], detonations=[],
-                   launch_cmd=[], launch_ok=[], launch_traj=[], launch_cancel=[], reasons=[], new_missile=[])
+                   launch_cmd=[], launch_ok=[], launch_traj=[], launch_cancel=[], reasons=[], new_missile=[],
+                   draw_ids=[], draw_off=[0], draw_vis=[], draw_pos=[], draw_type=[])
+        draw_types = []
         hist = {}
         t = 0
         while t < duration:
@@ -161,6 +165,14 @@ def capture(scene, sample_every=1):
                     rec["launch_cancel"].append([t, m.missile.id]); rec["reasons"].append(m.reason)
                 elif m.type == MessageType.NEW_MISSILE:
                     rec["new_missile"].append([t, m.missile.id])
+                elif m.type == MessageType.DRAW_OBJECTS:
+                    name = getattr(m.target_type, "name", None) or str(m.target_type)
+                    if name not in draw_types:
+                        draw_types.append(name)
+                    rec["draw_ids"].append(m.obj_id); rec["draw_vis"].append(int(bool(m.is_visible_by_radar)))
+                    rec["draw_pos"].append(np.asarray(m.coordinates, dtype=np.float64).copy())
+                    rec["draw_type"].append(draw_types.index(name))
+            rec["draw_off"].append(len(rec["draw_ids"]))
             t += dt; T += 1
     finally:
         np.random.normal = real_normal
@@ -182,6 +194,9 @@ def capture(scene, sample_every=1):
         launch_traj=np.array(rec["launch_traj"], np.float64).reshape(-1, 7),
         launch_cancel=np.array(rec["launch_cancel"], np.int64).reshape(-1, 2),
         new_missile=np.array(rec["new_missile"], np.int64).reshape(-1, 2),
+        draw_ids=np.array(rec["draw_ids"], np.int64), draw_off=np.array(rec["draw_off"], np.int64),
+        draw_vis=np.array(rec["draw_vis"], np.uint8), draw_type=np.array(rec["draw_type"], np.int32),
+        draw_pos=np.array(rec["draw_pos"], np.float64).reshape(-1, 3), draw_types=json.dumps(draw_types),
     )
     return out
 

@@ -31,12 +31,19 @@ class Fixture:
         self.histogram = json.loads(str(z["histogram"]))
         self.reasons = json.loads(str(z["reasons"]))
         for k in z.files:
-            if k not in ("scene", "histogram", "reasons"):
+            if k not in ("scene", "histogram", "reasons", "draw_types"):
                 setattr(self, k, z[k])
+        self.draw_types = json.loads(str(z["draw_types"]))
         self.dt = self.cfg["simulation"]["time_step"]
         self.n_ticks = len(self.tick_ms)
         self.R = self.radar_state.shape[1]
         self.samp_index = {int(t): k for k, t in enumerate(self.samp_tick)}
+
+    def draw(self, T):
+        """DRAW_OBJECTS messages of tick T, message order: (ids, type names, positions, visible)."""
+        lo, hi = self.draw_off[T], self.draw_off[T + 1]
+        return (self.draw_ids[lo:hi], [self.draw_types[c] for c in self.draw_type[lo:hi]], self.draw_pos[lo:hi],
+                self.draw_vis[lo:hi].astype(bool))
 
     def active_ids(self, T):
         return self.act_ids[self.act_off[T]:self.act_off[T + 1]]

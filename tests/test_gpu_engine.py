@@ -358,3 +358,27 @@ def test_random_scenes_match_oracle(seed):
         for r, want in enumerate(mir.lists()):
             assert np.array_equal(lists[r], want), f"seed {seed} tick {k} radar {r}"
         assert eng.radar_state() == [(r["caz"], r["cel"]) for r in mir.rs]
+
+
+def test_replay_frame_from_a_headless_tick():
+    """ReplayLog.record_store after a fused tick on a spatially sorted table: live objects in list order, their
+    positions, seen = any radar's bit -- against the oracle mirror of the same tick."""
+    from zrk_modulation_amd.replay import ReplayLog
+    eng, scene, launched = _engine(9000, 5, 120, seed=5, noise="off")
+    mir = OracleMirror(eng, scene[4])
+    log = ReplayLog(max_steps=2)
+    for k in range(12):
+        events = mir.tick(k * 500, 500, 0, None)
+        eng.run(1)
+        log.record_store(k * 500, eng.store)
+    ids, kinds, pos, seen = log.frame(11 * 500)
+    live = mir.alive.astype(bool)
+    for ms, ts in mir.pending:                         # the oracle applies the last tick's removals lazily
+        live[ms] = False
+        if ts >= 0:
+            live[ts] = False
+    all_ids = eng.list_view(eng.store.h_ids[:mir.n])
+    assert np.array_equal(ids, all_ids[live]) and len(log.steps()) == 2
+    assert np.array_equal(pos, mir.pos.reshape(3, mir.n).T[live])
+    assert np.array_equal(seen, (mir.vis != 0)[live])
+    assert set(kinds.tolist()) <= {0, 1} and (kinds == 1).sum() <= launched

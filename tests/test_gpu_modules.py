@@ -38,12 +38,12 @@ def _scripted_commander(mod):
     return CombatControlPoint
 
 
-def build(fx):
+def build(fx, replay=None):
     import zrk_modulation_amd.main as M
     from zrk_modulation_amd.modules.Radar import SectorRadar
     cfg = fx.cfg
     if fx.scene.get("script") is None:
-        manager, objs = M.create_objects_from_config(cfg)
+        manager, objs = M.create_objects_from_config(cfg, replay=replay)
         return manager, [o for o in objs.values() if isinstance(o, SectorRadar)]
     cfg2 = dict(cfg)
     cfg2["combat_control_point"] = {}
@@ -98,6 +98,12 @@ def test_module_stack_reproduces_reference_run(name):
             det = [[t, m.missile_id, -1 if m.target_id is None else m.target_id, int(m.self_detonation)]
                    for m in msgs if m.type == MessageType.MISSILE_DETONATE]
             assert det == fx.rows_at(fx.detonations, t).tolist(), f"detonations differ at t={t}"
+            draw = [m for m in msgs if m.type == MessageType.DRAW_OBJECTS]
+            ids, types, pos, vis = fx.draw(T)
+            assert [m.obj_id for m in draw] == ids.tolist(), f"objects sent to the GUI differ at t={t}"
+            assert [getattr(m.target_type, "name", None) or str(m.target_type) for m in draw] == types
+            assert [bool(m.is_visible_by_radar) for m in draw] == vis.tolist(), f"visibility flags differ at t={t}"
+            assert np.array_equal(np.array([m.coordinates for m in draw]).reshape(len(draw), 3), pos), f"GUI coordinates differ at t={t}"
             for m in msgs:
                 hist[m.type.name] = hist.get(m.type.name, 0) + 1
                 if m.type == MessageType.LAUNCH_SUCCESSFUL:
@@ -136,3 +142,35 @@ def test_handles_keep_identity_and_freeze_after_removal():
                     frozen[oid] = (o.pos.copy(), None if o.prev_pos is None else o.prev_pos.copy())
                 assert np.array_equal(o.pos, frozen[oid][0])
     assert frozen, "scene should remove at least one object"
+
+
+@pytest.mark.parametrize("name", ["stock_config_seed0", "stock_simulation_config_seed1"])
+def test_columnar_replay_log_holds_what_the_gui_replays(name):
+    """The same run with Manager(replay=ReplayLog(max_steps=...)): DRAW_OBJECTS messages never enter the per-tick
+    lists, the log answers the GUI's query with the reference's contents for the steps it still holds, and it
+    holds no more than it was told to."""
+    from zrk_modulation_amd.modules.constants import MessageType
+    from zrk_modulation_amd.replay import ReplayLog
+    fx = Fixture(name)
+    np.random.seed(fx.scene["seed"])
+    keep = 7
+    log = ReplayLog(max_steps=keep)
+    manager, _ = build(fx, replay=log)
+    for T in range(fx.n_ticks):
+        t = int(fx.tick_ms[T])
+        manager.run_simulation(t + fx.dt)
+        assert not [m for m in manager.messages.get(t, []) if m.type == MessageType.DRAW_OBJECTS]
+        assert len(log.steps()) <= keep
+    sent = [T for T in range(fx.n_ticks) if fx.draw_off[T + 1] > fx.draw_off[T]]
+    assert log.steps() == [int(fx.tick_ms[T]) for T in sent[-keep:]]
+    for T in sent[-keep:]:
+        t = int(fx.tick_ms[T])
+        ids, types, pos, vis = fx.draw(T)
+        got = manager.give_messages_by_type(MessageType.DRAW_OBJECTS, step_time=t)      # what UI/PolygonEditor.py:631 calls
+        assert [m.obj_id for m in got] == ids.tolist()
+        assert [getattr(m.target_type, "name", None) or str(m.target_type) for m in got] == types
+        assert [m.is_visible_by_radar for m in got] == vis.tolist()
+        assert np.array_equal(np.array([m.coordinates for m in got]).reshape(len(got), 3), pos)
+        f_ids, f_types, f_pos, f_vis = log.frame(t)
+        assert np.array_equal(f_ids, ids) and np.array_equal(f_pos, pos) and np.array_equal(f_vis, vis)
+    assert log.dropped_steps == len(sent) - min(keep, len(sent))

@@ -157,3 +157,33 @@ def test_synthetic_scenario_is_seeded_and_matches_the_survey_definition():
     assert rs[2]["position"] == [2000.0, 0.0, 0.0] and rs[0]["azimuth_range"] == 90.0
     assert S.missile_targets(100000, 1000)[:3].tolist() == [0, 100, 200]
     assert S.WORKLOADS["C2"] == (100_000, 4, 1_000) and S.WORKLOADS["C3"] == (1_000_000, 16, 10_000)
+
+
+def test_replay_log_round_trip_and_bound():
+    """ReplayLog alone (no device): frames come back in message order with the reference's field values, old steps
+    fall off the end, and the log is columnar (bytes, not objects)."""
+    from tests.helpers import Fixture
+    from zrk_modulation_amd.modules.Messages import CPPDrawerObjectsMessage
+    from zrk_modulation_amd.replay import ReplayLog
+    fx = Fixture("stock_config_seed0")
+    log = ReplayLog(max_steps=5)
+    sent = []
+    for T in range(fx.n_ticks):
+        ids, types, pos, vis = fx.draw(T)
+        t = int(fx.tick_ms[T])
+        for k in range(len(ids)):
+            p = pos[k].copy()
+            log.add_message(t, CPPDrawerObjectsMessage(sender_id=1, obj_id=int(ids[k]), target_type=types[k], coordinates=p,
+                                                       is_visible_by_radar=bool(vis[k]), time=t, receiver_id=0))
+            p += 1e9                                   # the sender's array moves on; the log holds values
+        if len(ids):
+            sent.append(T)
+    assert log.steps() == [int(fx.tick_ms[T]) for T in sent[-5:]] and log.dropped_steps == len(sent) - 5
+    for T in sent[-5:]:
+        ids, types, pos, vis = fx.draw(T)
+        msgs = log.messages(int(fx.tick_ms[T]))
+        assert [m.obj_id for m in msgs] == ids.tolist() and [m.target_type for m in msgs] == types
+        assert [m.is_visible_by_radar for m in msgs] == vis.tolist()
+        assert np.array_equal(np.array([m.coordinates for m in msgs]).reshape(-1, 3), pos)
+        assert all(m.send_time == int(fx.tick_ms[T]) and m.sender_id == 1 and m.receiver_id == 0 for m in msgs)
+    assert log.messages(int(fx.tick_ms[sent[0]])) == [] and log.nbytes() < 64 * 1024

@@ -28,10 +28,11 @@ def load_config(config_path: str) -> Dict[str, Any]:
         return yaml.safe_load(f)
 
 
-def create_objects_from_config(config: Dict[str, Any], device=None) -> Tuple[Manager, Dict[int, object]]:
+def create_objects_from_config(config: Dict[str, Any], device=None, replay=None) -> Tuple[Manager, Dict[int, object]]:
     """Same construction order as the reference (it fixes module scheduling ties and list order):
-    AirEnv, radars, launchers with their missiles, command post, then the targets."""
-    manager = Manager()
+    AirEnv, radars, launchers with their missiles, command post, then the targets.
+    replay: optional zrk_modulation_amd.replay.ReplayLog for bounded columnar retention of what the GUI replays."""
+    manager = Manager(replay=replay)
     by_id: Dict[int, object] = {}
 
     timer = Timer()

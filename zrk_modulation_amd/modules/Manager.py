@@ -23,10 +23,15 @@ def _rank(module) -> int:
 
 
 class Manager:
-    def __init__(self):
+    def __init__(self, replay=None):
+        """replay: an optional zrk_modulation_amd.replay.ReplayLog.  With one, DRAW_OBJECTS messages (the only
+        thing the GUI's replay reads, one per object per tick) are kept there as bounded columnar frames and
+        `give_messages_by_type(DRAW_OBJECTS, step_time=...)` is answered from it; without, everything is kept
+        as the reference does."""
         self.time = Timer()
         self.messages: Dict[int, List[BaseMessage]] = {}     # tick time -> messages (never pruned)
         self.modules: List = []
+        self.replay = replay
 
     # modules -----------------------------------------------------------------------------------
     def add_module(self, module) -> None:
@@ -54,6 +59,9 @@ class Manager:
         when = self.time.get_time() if step_time is None else step_time
         if msg.send_time is None:
             msg.send_time = when
+        if self.replay is not None and getattr(msg, "type", None) == MessageType.DRAW_OBJECTS:
+            self.replay.add_message(when, msg)
+            return
         bucket = self.messages.setdefault(when, [])
         bucket.append(msg)
         bucket.sort(key=lambda m: -m.relevance)               # stable: insertion order within a relevance
@@ -67,6 +75,9 @@ class Manager:
 
     def give_messages_by_type(self, msg_type: MessageType, receiver_id: Optional[int] = None,
                               step_time: Optional[int] = None) -> List[BaseMessage]:
+        if self.replay is not None and msg_type == MessageType.DRAW_OBJECTS:
+            when = self.time.get_time() if step_time is None else step_time
+            return [m for m in self.replay.messages(when) if receiver_id is None or m.receiver_id == receiver_id]
         out = []
         for m in self.give_messages(step_time):
             if getattr(m, "type", None) == msg_type and (receiver_id is None or m.receiver_id == receiver_id):
