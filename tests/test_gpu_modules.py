@@ -174,3 +174,38 @@ def test_columnar_replay_log_holds_what_the_gui_replays(name):
         f_ids, f_types, f_pos, f_vis = log.frame(t)
         assert np.array_equal(f_ids, ids) and np.array_equal(f_pos, pos) and np.array_equal(f_vis, vis)
     assert log.dropped_steps == len(sent) - min(keep, len(sent))
+
+
+def test_gui_schema_scene_runs_the_same_through_modules_and_headless():
+    """One synthetic scene, twice: as a configuration in the GUI's schema through create_objects_from_config and the
+    module stack (noise draws patched to zero), and as arrays through the headless engine with noise off -- same
+    detections per radar, every tick."""
+    import zrk_modulation_amd.main as M
+    from zrk_modulation_amd import scenario as S
+    from zrk_modulation_amd.engine import HotPathEngine
+    from zrk_modulation_amd.modules.constants import MessageType
+    from zrk_modulation_amd.modules.Radar import SectorRadar
+    n, R, seed, dt, ticks = 400, 3, 12, 500, 12
+    cfg = S.synthetic_config(n, R, seed, launchers=0, time_step=dt, duration=dt * ticks)
+    cfg["combat_control_point"] = {}                         # no command post: nothing launches, nothing is drawn
+    real_normal = np.random.normal
+    np.random.normal = lambda loc, scale, size=None: np.zeros(size)
+    try:
+        manager, objs = M.create_objects_from_config(cfg)
+        radars = [o for o in objs.values() if isinstance(o, SectorRadar)]
+        ids, sp, vel, t0 = S.synthetic_targets(n, seed)
+        eng = HotPathEngine(device="cuda:0", dt_ms=dt, seed=0, noise="off")
+        eng.load(ids, sp, vel, t0, S.synthetic_radars(R)).enable_lists()
+        total = 0
+        for T in range(ticks):
+            manager.run_simulation((T + 1) * dt)
+            eng.run(1)
+            found = [m for m in manager.messages.get(T * dt, []) if m.type == MessageType.FOUND_OBJECTS]
+            assert [m.sender_id for m in found] == [r.id for r in radars]
+            lists = eng.detections()
+            for r, m in enumerate(found):
+                assert [o.id for o in m.visible_objects] == ids[lists[r]].tolist(), f"radar {r} tick {T}"
+                total += len(lists[r])
+        assert total > 50
+    finally:
+        np.random.normal = real_normal

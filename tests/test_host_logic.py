@@ -187,3 +187,25 @@ def test_replay_log_round_trip_and_bound():
         assert np.array_equal(np.array([m.coordinates for m in msgs]).reshape(-1, 3), pos)
         assert all(m.send_time == int(fx.tick_ms[T]) and m.sender_id == 1 and m.receiver_id == 0 for m in msgs)
     assert log.messages(int(fx.tick_ms[sent[0]])) == [] and log.nbytes() < 64 * 1024
+
+
+def test_synthetic_config_is_in_the_gui_schema():
+    """scenario.synthetic_config speaks the schema the reference's GUI saves and its loader reads: same sections
+    in the same order as a GUI-saved stock file, same keys per entry, YAML round trip intact."""
+    import yaml
+    from tests.helpers import Fixture
+    from zrk_modulation_amd import scenario as S
+    cfg = S.synthetic_config(50, 3, seed=4, launchers=2, missiles_per_launcher=3)
+    stock = Fixture("stock_config_seed0").cfg                      # a file the GUI wrote
+    assert list(cfg) == list(stock)
+    for section in ("simulation", "air_environment", "combat_control_point"):
+        assert list(cfg[section]) == list(stock[section])
+    assert list(cfg["air_environment"]["targets"][0]) == ["id", "type", "position", "velocity"]      # the GUI's order
+    assert set(cfg["air_environment"]["targets"][0]) == set(stock["air_environment"]["targets"][0])
+    assert list(cfg["radars"][0]) == list(stock["radars"][0])
+    assert list(cfg["missile_launchers"][0]) == list(stock["missile_launchers"][0])
+    assert set(stock["missile_launchers"][0]["missiles"][0]) <= set(cfg["missile_launchers"][0]["missiles"][0])
+    assert yaml.safe_load(yaml.dump(cfg, allow_unicode=True, sort_keys=False)) == cfg
+    ids, sp, vel, _ = S.synthetic_targets(50, 4)
+    assert [t["id"] for t in cfg["air_environment"]["targets"]] == ids.tolist()
+    assert np.array_equal(np.array([t["position"] for t in cfg["air_environment"]["targets"]]), sp)

@@ -36,3 +36,29 @@ def missile_targets(n, m):
     if m <= 0:
         return np.zeros(0, np.int32)
     return (np.arange(m, dtype=np.int64) * (n // m)).astype(np.int32)
+
+
+def synthetic_config(n, R, seed, launchers=1, missiles_per_launcher=0, time_step=10, duration=1000, first_id=1000):
+    """The same synthetic scene as a configuration in the schema the reference's GUI saves and its main.py loads
+    (UI/PolygonEditor.py:522-573, main.py:35-149): feed it to either side's `create_objects_from_config`.
+    Key order is the GUI's (`yaml.dump(..., sort_keys=False)`)."""
+    ids, sp, vel, _ = synthetic_targets(n, seed, first_id)
+    radars = synthetic_radars(R)
+    launcher_ids = [20_000 + k for k in range(launchers)]
+    return {
+        "simulation": {"time_step": int(time_step), "duration": int(duration)},
+        "air_environment": {
+            "id": 1, "position": [0.0, 0.0, 0.0],
+            "targets": [{"id": int(ids[k]), "type": "AIR_PLANE", "position": [float(v) for v in sp[k]],
+                         "velocity": [float(v) for v in vel[k]]} for k in range(n)],
+        },
+        "combat_control_point": {"id": 2, "missile_launcher_ids": launcher_ids, "radar_ids": [r["id"] for r in radars]},
+        "missile_launchers": [{
+            "id": lid, "position": [0.0, 0.0, 0.0], "max_missiles": int(missiles_per_launcher),
+            "missiles": [{"id": 30_000 + 1000 * k + j, "position": [0.0, 0.0, 0.0], "velocity": 1000,
+                          "explosion_radius": 150, "life_time": 60} for j in range(missiles_per_launcher)],
+        } for k, lid in enumerate(launcher_ids)],
+        "radars": [{key: r[key] for key in ("id", "position", "azimuth_start", "elevation_start", "max_distance",
+                                            "azimuth_range", "elevation_range", "azimuth_speed", "elevation_speed",
+                                            "scan_mode")} for r in radars],
+    }
