@@ -164,6 +164,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own HIP runtime; whichever copy enters the process first is the one everybody binds
+    # to, and a process where this library pulled in the system's copy before torch initialised its own has
+    # been seen to end up with no usable device.  The device memory handed across the ABI is torch's anyway.
+    import torch  # noqa: F401
     if not LIB_PATH.exists():
         raise HotPathUnavailable(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
