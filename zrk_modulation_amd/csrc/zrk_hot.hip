@@ -78,11 +78,6 @@ struct RadarCold {
     double el_lo, el_hi;
 };
 
-struct RadarDev {               // host-side scratch while deriving
-    RadarHot h;
-    RadarCold c;
-};
-
 struct RadarBlock {                                 // lives in the kernel-argument segment (by value)
     uint32_t prew[ZRK_MAX_RADARS][12];              // pre-pass records (RadarPre) as dwords, see sweep_row
     uint32_t hotw[ZRK_MAX_RADARS][20];              // RadarHot records as dwords (indexed, never addressed)
@@ -109,7 +104,7 @@ struct SweepParams {
 
 // The missile phase rides along in other kernels' grids (its own launches would cost more in kernel
 // boundaries than in work): the per-row step as extra workgroups of the sweep, the ordered event list
-// and the tombstones as an extra workgroup of the count scan.  m == 0: nothing to do.
+// and the tombstones as an extra workgroup of the compaction.  m == 0: nothing to do.
 struct MissileArgs {
     const double *sp, *vel, *t0;
     uint8_t *alive;
