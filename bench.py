@@ -43,7 +43,8 @@ def build_engine(workload, rank, world, device, seed_off=0):
     radars = S.synthetic_radars(R)
     stride = n + m                                   # global index space: shard g starts at g * stride
     eng = HotPathEngine(device=device, dt_ms=10, seed=S.SEEDS[workload], noise="philox", gid0=rank * stride)
-    eng.load(ids, sp, vel, t0, radars, missile_capacity=m, union_capacity=(n + m) if world > 1 else None)
+    eng.load(ids, sp, vel, t0, radars, missile_capacity=m, union_capacity=(n + m) if world > 1 else None,
+             union_format="bits")
     # (the exchange buffers are re-sized to the observed detection count after warm-up, see main)
     if world == 1:
         eng.enable_lists()
@@ -194,11 +195,19 @@ def main():
     # overlaps the sweep of tick t+1; a buffer is reused only after its collective has been waited for
     xchg = {"ex": [], "buf": [], "work": [None, None], "tick": 0}
 
-    def size_exchange(capacity):
-        from zrk_modulation_amd.exchange import DetectionExchange
-        xchg["ex"] = [DetectionExchange(capacity, device) for _ in range(2)]
-        xchg["buf"] = [torch.zeros(capacity + 1, dtype=torch.int64, device=device) for _ in range(2)]
+    def size_exchange(entries):
+        """Buffers for up to `entries` seen objects per rank, in the wire format of zrk_compact_bits (count, n, one
+        bit per slot, 16-bit masks): a quarter of the bytes of (index, mask) pairs."""
+        from zrk_modulation_amd.exchange import DetectionExchange, union_bits_words
+        n_slots = torch.tensor([int(eng.loop.n)], dtype=torch.int64, device=device)
+        dist.all_reduce(n_slots, op=dist.ReduceOp.MAX)                 # launch counts differ a little between ranks
+        words = union_bits_words(int(n_slots.item()), info["R"], entries)
+        stride = info["n"] + info["m"]
+        xchg["ex"] = [DetectionExchange(words, device, fmt="bits", offsets=[g * stride for g in range(world)], R=info["R"])
+                      for _ in range(2)]
+        xchg["buf"] = [torch.zeros(words, dtype=torch.int64, device=device) for _ in range(2)]
         xchg["work"] = [None, None]
+        xchg["entries"], xchg["words"] = int(entries), int(words)
 
     def drain_exchange():
         for k, w in enumerate(xchg["work"]):
@@ -225,7 +234,7 @@ def main():
                 sweep_ms[j // stride] = one[0]
 
     if world > 1:
-        size_exchange(eng.packed.numel() - 1)
+        size_exchange(info["n"] + info["m"])
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -278,7 +287,7 @@ def main():
             "config": {"workload": f"{args.workload}: {info['n']} AirObjects, {info['R']} SectorRadars, "
                                    f"{info['launched']}/{info['m']} missiles in flight per GPU, dt=10 ms, "
                                    f"Philox measurement noise, "
-                                   + ("packed union compaction + per-tick RCCL all-gather of the detection list, "
+                                   + ("union compaction in the bitmap wire format + per-tick RCCL all-gather of the detection list, "
                                       "overlapped with the next sweep" if world > 1 else "per-radar compaction"),
                        "entities_per_gpu": n_slots, "live_per_gpu": int(live1), "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -288,7 +297,8 @@ def main():
                          "profiled_kernel_us": profiled_kernel_us(args.workload, world)},
         }
         if world > 1:
-            out["config"]["exchange_entries_per_rank"] = xchg["ex"][0].capacity
+            out["config"]["exchange_entries_per_rank"] = xchg["entries"]
+            out["config"]["exchange_bytes_per_rank"] = 8 * xchg["words"]
             out["config"]["exchange_overflow"] = bool(overflow)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(info, eng, args.cpu_budget)

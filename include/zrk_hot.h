@@ -45,6 +45,7 @@ extern "C" {
 #define ZRK_F_ADVANCE 1u            /* recompute pos from the trajectory before sweeping */
 #define ZRK_F_PHILOX 2u             /* counter-based measurement noise inside the sweep */
 #define ZRK_F_EXACT_ONLY 4u         /* diagnostics: skip the float32 pre-classification */
+#define ZRK_F_UNION_BITS 8u         /* zrk_run_ticks: write `packed` in the bitmap wire format (zrk_compact_bits) */
 
 typedef struct zrk_ctx zrk_ctx;
 
@@ -152,6 +153,21 @@ int zrk_compact(zrk_ctx *ctx, const uint32_t *vis_mask /* DEVICE */, int64_t n, 
                 int64_t det_stride, int32_t *det_cnt /* DEVICE [R+1] */,
                 int64_t *packed /* DEVICE, may be NULL */, int64_t packed_capacity, int64_t gid0,
                 void *stream);
+
+/*
+ * zrk_compact with the union list in its WIRE format, for the per-tick all-gather between GPUs: word 0 = number
+ * of slots seen by at least one radar, word 1 = n, words 2 .. 1 + ceil(n/64) = one bit per slot (bit i%64 of word
+ * 2 + i/64), then the masks of the seen slots in ascending slot order, packed 16 bits each when R <= 16, else 32.  About a quarter
+ * of the bytes of the (index, mask) pairs; indices are implicit (the receiver knows each shard's offset).
+ * `union_words` is the size of `union_bits` in 64-bit words (zrk_union_bits_words(n, R, entries) for `entries`
+ * masks); masks beyond it are dropped, word 0 stays exact.  zrk_run_ticks writes this format into `packed` when
+ * zrk_loop.flags has ZRK_F_UNION_BITS.
+ */
+int zrk_compact_bits(zrk_ctx *ctx, const uint32_t *vis_mask /* DEVICE */, int64_t n, int R, int32_t base_index,
+                     void *workspace, int32_t *det_idx /* DEVICE [R][det_stride], may be NULL */, int64_t det_stride,
+                     int32_t *det_cnt /* DEVICE [R+1] */, int64_t *union_bits /* DEVICE */, int64_t union_words,
+                     void *stream);
+int64_t zrk_union_bits_words(int64_t n, int R, int64_t entries);
 
 /* Synchronises `stream` and reports whether every compaction on `workspace` so far ran to completion:
  * 0, or ZRK_E_STATE if a workgroup found control words it did not expect (a workspace shared between

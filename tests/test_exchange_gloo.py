@@ -51,7 +51,7 @@ def _pack(vis, gid0, cap):
     return out
 
 
-def _worker(rank, world, port, n, R, q):
+def _worker(rank, world, port, n, R, q, fmt="pairs"):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -62,8 +62,14 @@ def _worker(rank, world, port, n, R, q):
     lo, hi = rank * shard, (rank + 1) * shard
     vis = _masks(sp[lo:hi], radars)
     cap = shard
-    ex = DetectionExchange(cap, torch.device("cpu"))
-    ex.all_gather(torch.from_numpy(_pack(vis, lo, cap)))
+    if fmt == "pairs":
+        ex = DetectionExchange(cap, torch.device("cpu"))
+        ex.all_gather(torch.from_numpy(_pack(vis, lo, cap)))
+    else:
+        from zrk_modulation_amd.exchange import encode_union_bits, union_bits_words
+        words = union_bits_words(shard, R, cap)
+        ex = DetectionExchange(words, torch.device("cpu"), fmt="bits", offsets=[g * shard for g in range(world)], R=R)
+        ex.all_gather(torch.from_numpy(encode_union_bits(vis, R, words)))
     idx, mask = ex.merged()
     lists = [ex.radar_list(r).numpy() for r in range(R)]
     if rank == 0:
@@ -72,12 +78,13 @@ def _worker(rank, world, port, n, R, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_exchange_reproduces_single_process_order():
+@pytest.mark.parametrize("fmt", ["pairs", "bits"])
+def test_two_rank_exchange_reproduces_single_process_order(fmt):
     n, R, world = 4000, 5, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, R, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, R, q, fmt)) for r in range(world)]
     for p in procs:
         p.start()
     idx, mask, lists, counts, overflow = q.get(timeout=120)

@@ -167,3 +167,34 @@ def test_status_reports_a_foreign_workspace(factory):
         os.environ.pop("ZRK_COMPACT_ORDER", None)
     det, cnt, packed = _run(lambda: st, vis, 4)               # cleared again on the next use
     _check(det, cnt, packed, vis, 4)
+
+
+@pytest.mark.parametrize("n,R,density", [(1, 1, 1.0), (63, 3, 0.5), (1025, 16, 0.2), (70_001, 17, 0.3), (1_048_577, 16, 0.17),
+                                         (300_000, 32, 1.0), (5_000, 8, 0.0)])
+def test_union_in_the_wire_format(factory, n, R, density):
+    """zrk_compact_bits: count, n, one bit per slot, then the masks of the seen slots (16 or 32 bits wide) -- against
+    the host encoder, on the single-launch and the three-launch path, with room for all masks and for too few."""
+    import torch
+    from zrk_modulation_amd.exchange import encode_union_bits, union_bits_words
+    g = np.random.Generator(np.random.PCG64(n + 7 * R))
+    vis = _masks(g, n, R, density)
+    seen = int(np.count_nonzero(vis))
+    for mb in (None, 0):
+        st = factory(max_blocks=mb)()
+        for entries in (seen, seen // 2):
+            words = union_bits_words(n, R, entries)
+            assert words == st.lib.zrk_union_bits_words(n, R, entries)
+            dvis = torch.as_tensor(vis.view(np.int32), device=st.device)
+            out = torch.full((words,), -7, dtype=torch.int64, device=st.device)
+            det = torch.zeros(n * R, dtype=torch.int32, device=st.device)
+            cnt = torch.zeros(R + 1, dtype=torch.int32, device=st.device)
+            st.ctx.check(st.lib.zrk_compact_bits(st.ctx.handle, dvis.data_ptr(), n, R, 0, st.workspace().data_ptr(), det.data_ptr(),
+                                                 n, cnt.data_ptr(), out.data_ptr(), words, None), "compact_bits")
+            st.compact_status()
+            got, want = out.cpu().numpy(), encode_union_bits(vis, R, words)
+            nb = (n + 63) // 64
+            assert got[0] == seen and got[1] == n and np.array_equal(got[2:2 + nb], want[2:2 + nb])
+            dt = np.uint16 if R <= 16 else np.uint32
+            k = min(seen, len(want[2 + nb:].view(dt)))
+            assert np.array_equal(got[2 + nb:].view(dt)[:k], want[2 + nb:].view(dt)[:k])
+            assert cnt.cpu().tolist()[R] == seen

@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, R, ticks, q):
+def _worker(rank, world, port, n, R, ticks, q, fmt="pairs"):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -36,9 +36,13 @@ def _worker(rank, world, port, n, R, ticks, q):
     per = n // world
     lo, hi = rank * per, (rank + 1) * per
     eng = HotPathEngine(device=dev, dt_ms=100, seed=21, noise="philox", gid0=lo)
-    eng.load(ids[lo:hi], sp[lo:hi], vel[lo:hi], t0[lo:hi], radars, union_capacity=per)
-    ex = [DetectionExchange(per, dev) for _ in range(2)]
-    bufs = [torch.zeros(per + 1, dtype=torch.int64, device=dev) for _ in range(2)]
+    eng.load(ids[lo:hi], sp[lo:hi], vel[lo:hi], t0[lo:hi], radars, union_capacity=per, union_format=fmt)
+    words = eng.packed.numel()
+    if fmt == "pairs":
+        ex = [DetectionExchange(per, dev) for _ in range(2)]
+    else:
+        ex = [DetectionExchange(words, dev, fmt="bits", offsets=[g * per for g in range(world)], R=R) for _ in range(2)]
+    bufs = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(2)]
     work = [None, None]
     for k in range(ticks):                     # the double-buffered, asynchronous loop of bench.py
         b = k & 1
@@ -58,7 +62,8 @@ def _worker(rank, world, port, n, R, ticks, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_single_table():
+@pytest.mark.parametrize("fmt", ["pairs", "bits"])
+def test_two_ranks_on_one_gpu_match_single_table(fmt):
     import torch.multiprocessing as mp
     from zrk_modulation_amd import scenario as S
     from zrk_modulation_amd.engine import HotPathEngine
@@ -66,7 +71,7 @@ def test_two_ranks_on_one_gpu_match_single_table():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, R, ticks, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, R, ticks, q, fmt)) for r in range(world)]
     for p in procs:
         p.start()
     idx, mask, counts, overflow = q.get(timeout=300)

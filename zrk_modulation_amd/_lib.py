@@ -17,7 +17,7 @@ LIB_PATH = CSRC / "libzrk_hot.so"
 ZRK_ABI_VERSION = 2
 ZRK_MAX_RADARS = 32
 ZRK_BLOCK = 256
-F_ADVANCE, F_PHILOX, F_EXACT_ONLY = 1, 2, 4
+F_ADVANCE, F_PHILOX, F_EXACT_ONLY, F_UNION_BITS = 1, 2, 4, 8
 
 
 class HotPathUnavailable(RuntimeError):
@@ -121,6 +121,9 @@ _PROTOTYPES = {
                                  C.c_int64, C.c_void_p, C.c_void_p]),
     "zrk_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int32, C.c_void_p, C.c_void_p,
                               C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "zrk_compact_bits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "zrk_union_bits_words": (C.c_int64, [C.c_int64, C.c_int, C.c_int64]),
     "zrk_compact_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "zrk_scan_advance": (C.c_int, [C.POINTER(ZrkRadar), C.POINTER(ZrkScan), C.c_int]),
     "zrk_run_ticks": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.POINTER(ZrkMissiles), C.c_int64,

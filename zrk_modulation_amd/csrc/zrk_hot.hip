@@ -569,6 +569,23 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_counts(const int32_t *__r
     if (tid == 0) totals[r] = s_carry;
 }
 
+// The union list in its wire format (ZRK_F_UNION_BITS / zrk_compact_bits): word 0 = number of slots seen by any
+// radar, word 1 = n, then one bit per slot (ceil(n / 64) words), then the masks of the seen slots in ascending
+// order, 16 bits each when R <= 16, else 32.  A quarter of the bytes of the (index, mask) pairs at the usual 1-in-6 density --
+// what crosses xGMI every tick.
+struct UnionBits {
+    int64_t words;               // bitmap words (0: the pairs format)
+    int64_t mask_cap;            // masks that fit behind the bitmap
+    int32_t mask_bytes, _pad;
+};
+
+__device__ __forceinline__ void union_bits_mask(int64_t *packed, const UnionBits &U, int64_t rank, uint32_t mask)
+{
+    if (rank >= U.mask_cap) return;
+    if (U.mask_bytes == 2) ((uint16_t *)(packed + 2 + U.words))[rank] = (uint16_t)mask;
+    else ((uint32_t *)(packed + 2 + U.words))[rank] = mask;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Compaction, phase 3: stable scatter.  Lane order == slot order inside a wave, so
 // popcount(ballot & lanes-below) is the rank; waves and workgroups are ordered by the scans.
@@ -579,7 +596,7 @@ __global__ __launch_bounds__(kCompBlock) void k_scatter(const uint32_t *__restri
                                                         int32_t *__restrict__ det_idx, int64_t det_stride,
                                                         int32_t *__restrict__ det_cnt, int64_t *__restrict__ packed,
                                                         int64_t packed_capacity, int64_t gid0,
-                                                        uint32_t *__restrict__ zero_next)
+                                                        uint32_t *__restrict__ zero_next, const UnionBits U)
 {
     constexpr int kWaves = kCompBlock / 64;
     __shared__ int s_wcnt[kWaves];
@@ -600,7 +617,11 @@ __global__ __launch_bounds__(kCompBlock) void k_scatter(const uint32_t *__restri
     // Only ~15 % of the slots carry a detection: squeeze those into LDS first (stable), then each wave
     // walks the short list for "its" radars instead of every wave walking every radar over all slots.
     const unsigned long long bu = __ballot(m != 0u);
-    if (lane == 0) s_wcnt[wave] = (int)__popcll(bu);
+    if (lane == 0) {
+        s_wcnt[wave] = (int)__popcll(bu);
+        const int64_t word = (blk0 + wave * 64) >> 6;
+        if (packed && U.words && word < U.words) packed[2 + word] = (int64_t)bu;
+    }
     __syncthreads();
     int woff = 0, found = 0;
 #pragma unroll
@@ -617,11 +638,15 @@ __global__ __launch_bounds__(kCompBlock) void k_scatter(const uint32_t *__restri
     __syncthreads();
     if (packed) {
         // union list for the multi-GPU exchange: packed[0] = count, then (global index << 32 | mask)
-        if (blockIdx.x == 0 && tid == 0) packed[0] = totals[R];
+        if (blockIdx.x == 0 && tid == 0) {
+            packed[0] = totals[R];
+            if (U.words) packed[1] = n;
+        }
         const int64_t ubase = s_base[R];
         for (int k = tid; k < found; k += kCompBlock) {
             const int64_t dst = ubase + k;
-            if (dst + 1 < packed_capacity) packed[dst + 1] = ((gid0 + blk0 + s_idx[k]) << 32) | (int64_t)s_msk[k];
+            if (U.words) union_bits_mask(packed, U, dst, s_msk[k]);
+            else if (dst + 1 < packed_capacity) packed[dst + 1] = ((gid0 + blk0 + s_idx[k]) << 32) | (int64_t)s_msk[k];
         }
     }
     if (det_idx) {
@@ -719,6 +744,7 @@ struct CompactArgs {
     int32_t *det_cnt;
     int64_t *packed;
     int64_t packed_capacity, gid0;
+    UnionBits bits;
 };
 
 template <int THREADS>
@@ -759,7 +785,11 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
             const int64_t i = blk0 + (int64_t)it * THREADS + tid;
             if (C.zero_next && i < C.n) C.zero_next[i] = 0u;   // next tick's (other) mask buffer, cleared in passing
             const unsigned long long bu = __ballot(mk[it] != 0u);
-            if (lane == 0) S.wcnt[it * (THREADS / 64) + wave] = (int)__popcll(bu);
+            if (lane == 0) {
+                S.wcnt[it * (THREADS / 64) + wave] = (int)__popcll(bu);
+                const int64_t word = (blk0 + (int64_t)it * THREADS + wave * 64) >> 6;      // 64 consecutive slots
+                if (C.packed && C.bits.words && word < C.bits.words) C.packed[2 + word] = (int64_t)bu;
+            }
         }
     }
     ZRK_PROBE(1);
@@ -852,7 +882,8 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
         const int64_t ubase = S.pre[C.R];
         for (int k = tid; k < found; k += THREADS) {
             const int64_t dst = ubase + k;
-            if (dst + 1 < C.packed_capacity) C.packed[dst + 1] = ((C.gid0 + blk0 + S.idx[k]) << 32) | (int64_t)S.msk[k];
+            if (C.bits.words) union_bits_mask(C.packed, C.bits, dst, S.msk[k]);
+            else if (dst + 1 < C.packed_capacity) C.packed[dst + 1] = ((C.gid0 + blk0 + S.idx[k]) << 32) | (int64_t)S.msk[k];
         }
     }
     if (C.det_idx) {
@@ -884,7 +915,10 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
     if (b == C.nb - 1 && tid <= C.R) {                 // the end of the list: totals
         const int tot = S.pre[tid] + S.cnt[tid];
         if (C.det_cnt) C.det_cnt[tid] = tot;
-        if (C.packed && tid == C.R) C.packed[0] = tot;
+        if (C.packed && tid == C.R) {
+            C.packed[0] = tot;
+            if (C.bits.words) C.packed[1] = C.n;
+        }
     }
     ZRK_PROBE(5);
     if (by_ticket && tid == 0) {
@@ -1464,16 +1498,26 @@ bool compacts_in_one_launch(const zrk_ctx *ctx, int64_t n)
 
 int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int32_t base_index, void *workspace,
                    int32_t *det_idx, int64_t det_stride, int32_t *det_cnt, int64_t *packed, int64_t packed_capacity,
-                   int64_t gid0, void *stream, const MissileArgs &M, uint32_t *zero_next, const OrderArgs &O)
+                   int64_t gid0, void *stream, const MissileArgs &M, uint32_t *zero_next, const OrderArgs &O,
+                   bool union_bits = false)
 {
     if (!ctx || !vis_mask || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_compact: null argument");
     if ((det_idx && !det_cnt) || (!det_idx && !packed)) return fail(ctx, ZRK_E_INVALID, "zrk_compact: no output requested");
     if (R < 0 || R > ZRK_MAX_RADARS || n < 0 || det_stride < 0 || (packed && packed_capacity < 1))
         return fail(ctx, ZRK_E_INVALID, "zrk_compact: size out of range");
     hipStream_t s = (hipStream_t)stream;
+    UnionBits U{0, 0, 0, 0};
+    if (packed && union_bits) {
+        U.words = (n + 63) / 64;
+        U.mask_bytes = R <= 16 ? 2 : 4;
+        U.mask_cap = (packed_capacity - 2 - U.words) * (8 / U.mask_bytes);
+        if (U.mask_cap < 0) return fail(ctx, ZRK_E_CAPACITY, "zrk_compact: the union buffer does not hold the bitmap");
+        if (U.words == 0) U.words = 1;               // n == 0 never gets here with work to do; keep the format flag
+    }
     if (n == 0) {
         if (det_idx && hipMemsetAsync(det_cnt, 0, sizeof(int32_t) * (R + 1), s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "memset det_cnt");
-        if (packed && hipMemsetAsync(packed, 0, sizeof(int64_t), s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "memset packed");
+        if (packed && hipMemsetAsync(packed, 0, sizeof(int64_t) * (union_bits && packed_capacity > 1 ? 2 : 1), s) != hipSuccess)
+            return fail(ctx, ZRK_E_HIP, "memset packed");
         return 0;
     }
     // single launch: about one workgroup per compute unit, each thread holding up to kFusedMaxItems slots
@@ -1496,6 +1540,7 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         C.vis = vis_mask; C.zero_next = zero_next; C.n = n; C.R = R; C.nb = (int)nbf; C.items = items; C.lanes = lanes;
         C.epoch = ctx->epoch; C.base_index = base_index; C.ctl = w.ctl; C.agg = w.agg; C.det_idx = det_idx;
         C.det_stride = det_stride; C.det_cnt = det_cnt; C.packed = packed; C.packed_capacity = packed_capacity; C.gid0 = gid0;
+        C.bits = U;
         hipLaunchKernelGGL(k_compact_fused, dim3((int)nbf + (M.m > 0 ? 1 : 0) + (O.nb > 0 ? 1 : 0)), dim3(kCompBlock), 0, s, C,
                            by_ticket, M, O);
         return check_launch(ctx, "k_compact_fused");
@@ -1506,7 +1551,7 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
     hipLaunchKernelGGL(k_scan_counts, dim3(R + 1 + (M.m > 0 ? 1 : 0)), dim3(kScanThreads), 0, s, w.counts, w.offs, w.totals,
                        nb, R + 1, M);
     hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(kCompBlock), 0, s, vis_mask, n, R, nb, w.offs, w.totals, base_index,
-                       det_idx, det_stride, det_cnt, packed, packed_capacity, gid0, zero_next);
+                       det_idx, det_stride, det_cnt, packed, packed_capacity, gid0, zero_next, U);
     return check_launch(ctx, "zrk_compact");
 }
 
@@ -1518,6 +1563,21 @@ ZRK_API int zrk_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R
 {
     return launch_compact(ctx, vis_mask, n, R, base_index, workspace, det_idx, det_stride, det_cnt, packed, packed_capacity,
                           gid0, stream, no_missiles(), nullptr, OrderArgs{nullptr, nullptr, 0, 0});
+}
+
+ZRK_API int zrk_compact_bits(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int32_t base_index,
+                             void *workspace, int32_t *det_idx, int64_t det_stride, int32_t *det_cnt, int64_t *union_bits,
+                             int64_t union_words, void *stream)
+{
+    return launch_compact(ctx, vis_mask, n, R, base_index, workspace, det_idx, det_stride, det_cnt, union_bits, union_words,
+                          0, stream, no_missiles(), nullptr, OrderArgs{nullptr, nullptr, 0, 0}, true);
+}
+
+ZRK_API int64_t zrk_union_bits_words(int64_t n, int R, int64_t entries)
+{
+    if (n < 0 || R < 0 || R > ZRK_MAX_RADARS || entries < 0) return ZRK_E_INVALID;
+    const int64_t mb = R <= 16 ? 2 : 4;
+    return 2 + (n + 63) / 64 + (entries * mb + 7) / 8;
 }
 
 ZRK_API int zrk_compact_status(zrk_ctx *ctx, void *workspace, void *stream)
@@ -1718,7 +1778,8 @@ ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missile
         if (rc == 0 && (det_idx || packed))
             rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, packed,
                                 packed_capacity, st->gid0, stream, M, vis_next,
-                                ordering ? OrderArgs{w.cost, w.order, nbs, 0} : OrderArgs{nullptr, nullptr, 0, 0});
+                                ordering ? OrderArgs{w.cost, w.order, nbs, 0} : OrderArgs{nullptr, nullptr, 0, 0},
+                                (st->flags & ZRK_F_UNION_BITS) != 0);
         if (rc == 0 && ordering) ctx->order_ready = true;
         if (rc == 0 && m > 0 && !fused) rc = zrk_missile_step(ctx, e, st->cur, mis, m, st->time_ms, st->dt_ms, 1, stream);
         zrk_scan_advance(radars, scan, R);                                   // Radar.py:205

@@ -178,7 +178,7 @@ class HotPathEngine:
         self.R = 0
 
     def load(self, ids, start_pos, velocity, start_time, radars, missile_capacity=0, det_stride=None,
-             union_capacity=None, sort=True):
+             union_capacity=None, sort=True, union_format="pairs"):
         """ids/start_pos/velocity/start_time: target columns in LIST order; radars: list of dicts with
         the SectorRadar constructor fields (reference modules/Radar.py:13-42).
 
@@ -228,8 +228,14 @@ class HotPathEngine:
         self.det_idx = None
         self.det_cnt = torch.zeros(_lib.ZRK_MAX_RADARS + 1, dtype=torch.int32, device=st.device)
         self.packed = None
+        self.union_format = union_format
         if union_capacity:
-            self.packed = torch.zeros(int(union_capacity) + 1, dtype=torch.int64, device=st.device)
+            # "pairs": [count, (global index << 32 | mask) ...]; "bits": the wire format of zrk_compact_bits
+            words = (int(union_capacity) + 1 if union_format == "pairs"
+                     else int(st.lib.zrk_union_bits_words(st.cap, self.R, int(union_capacity))))
+            self.packed = torch.zeros(words, dtype=torch.int64, device=st.device)
+            if union_format == "bits":
+                self.loop.flags |= _lib.F_UNION_BITS
         return self
 
     def enable_lists(self, det_stride=None):

@@ -15,13 +15,46 @@ import torch
 import torch.distributed as dist
 
 
+def union_bits_words(n, R, entries):
+    """64-bit words of the wire format for n slots and up to `entries` seen ones (zrk_union_bits_words)."""
+    return 2 + (int(n) + 63) // 64 + (int(entries) * (2 if R <= 16 else 4) + 7) // 8
+
+
+def encode_union_bits(vis, R, words):
+    """The wire format zrk_compact_bits writes, from a mask array on the host (tests, CPU ranks): word 0 = count,
+    word 1 = n, one bit per slot, then the masks of the seen slots (16 bits each when R <= 16, else 32)."""
+    import numpy as np
+    vis = np.asarray(vis, np.uint32)
+    n = len(vis)
+    out = np.zeros(int(words), np.int64)
+    seen = np.nonzero(vis)[0]
+    nbits = (n + 63) // 64
+    bits = np.zeros(nbits * 64, np.uint8)
+    bits[seen] = 1
+    out[0], out[1] = len(seen), n
+    out[2:2 + nbits] = np.packbits(bits.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).reshape(-1).view(np.int64)
+    dt = np.uint16 if R <= 16 else np.uint32
+    room = out[2 + nbits:].view(dt)
+    k = min(len(seen), len(room))
+    room[:k] = vis[seen[:k]].astype(dt)
+    return out
+
+
 class DetectionExchange:
-    def __init__(self, capacity, device, group=None):
+    def __init__(self, capacity, device, group=None, fmt="pairs", offsets=None, R=None):
+        """fmt "pairs": buffers of capacity + 1 words, [count, (global index << 32 | mask) ...].
+        fmt "bits": buffers of `capacity` WORDS in the wire format of zrk_compact_bits (union_bits_words); the slot
+        numbers are local to each rank, `offsets[g]` is added to rank g's when the lists are merged, `R` tells the
+        width of the masks."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.capacity = int(capacity)
-        self.gathered = torch.zeros(self.world, self.capacity + 1, dtype=torch.int64, device=device)
+        self.fmt = fmt
+        self.offsets = list(offsets) if offsets is not None else [0] * self.world
+        self.R = R
+        words = self.capacity + 1 if fmt == "pairs" else self.capacity
+        self.gathered = torch.zeros(self.world, words, dtype=torch.int64, device=device)
         backend = dist.get_backend(group) if dist.is_initialized() else "none"
         self._flat = backend == "nccl" or torch.device(device).type == "cpu"
 
@@ -30,7 +63,7 @@ class DetectionExchange:
         int64[world, capacity+1]; with async_op=True returns the work handle instead (wait() on it
         before reading `gathered` or overwriting `packed`), so the exchange of tick t overlaps the
         sweep of tick t+1."""
-        assert packed.numel() == self.capacity + 1
+        assert packed.numel() == self.gathered.shape[1]
         if self.world == 1:
             self.gathered[0].copy_(packed)
             return None if async_op else self.gathered
@@ -45,15 +78,37 @@ class DetectionExchange:
         """Per-rank detection counts (synchronises)."""
         return self.gathered[:, 0].cpu().tolist()
 
+    def _room(self, g):
+        """Masks rank g's buffer has room for (bits format)."""
+        n = int(self.gathered[g, 1].item())
+        return (self.gathered.shape[1] - 2 - (n + 63) // 64) * (4 if self.R <= 16 else 2)
+
     def overflowed(self):
-        return any(c > self.capacity for c in self.counts())
+        if self.fmt == "pairs":
+            return any(c > self.capacity for c in self.counts())
+        return any(c > self._room(g) for g, c in enumerate(self.counts()))
 
     def merged(self):
         """Global union list in index order: (indices int64, masks int64).  Synchronises."""
         cnt = self.counts()
-        parts = [self.gathered[g, 1:1 + min(c, self.capacity)] for g, c in enumerate(cnt)]
-        allp = torch.cat(parts) if parts else self.gathered.new_zeros(0)
-        return allp >> 32, allp & 0xFFFFFFFF
+        if self.fmt == "pairs":
+            parts = [self.gathered[g, 1:1 + min(c, self.capacity)] for g, c in enumerate(cnt)]
+            allp = torch.cat(parts) if parts else self.gathered.new_zeros(0)
+            return allp >> 32, allp & 0xFFFFFFFF
+        idx, msk = [], []
+        shifts = torch.arange(64, dtype=torch.int64, device=self.gathered.device)
+        for g, c in enumerate(cnt):
+            n = int(self.gathered[g, 1].item())
+            nw = (n + 63) // 64
+            words = self.gathered[g, 2:2 + nw]
+            bits = ((words.unsqueeze(1) >> shifts) & 1).reshape(-1)[:n]
+            slots = torch.nonzero(bits).reshape(-1)
+            k = min(c, self._room(g))
+            tail = self.gathered[g, 2 + nw:]
+            masks = (tail.view(torch.int16)[:k].to(torch.int64) & 0xFFFF) if self.R <= 16 else (tail.view(torch.int32)[:k].to(torch.int64) & 0xFFFFFFFF)
+            idx.append(slots[:k] + self.offsets[g])
+            msk.append(masks)
+        return (torch.cat(idx) if idx else self.gathered.new_zeros(0)), (torch.cat(msk) if msk else self.gathered.new_zeros(0))
 
     def radar_list(self, r):
         """FoundObjectsMessage order for radar r over the whole population (global indices)."""
