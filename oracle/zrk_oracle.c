@@ -259,8 +259,9 @@ static inline void zo_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint3
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* Noise stream of one (entity, tick): Philox block -> xoshiro128++ state; each detection draws two
- * words = four 16-bit uniforms = two Box-Muller pairs in binary32, three values used. */
+/* Noise stream of one (entity, tick): Philox block -> xoshiro128 state; each detection advances the state once
+ * and takes two scrambled words from it = four 16-bit uniforms = two Box-Muller pairs in binary32, three values
+ * used.  r = 5 sqrt(-2 ln((h + 0.5) / 65536)) written as sqrt(C1 * log2(h + 0.5) + C0), as the device evaluates it. */
 typedef struct { uint32_t s[4]; } zo_noise_state;
 
 static inline zo_noise_state zo_noise_init(uint64_t seed, uint64_t tick, uint64_t entity)
@@ -273,25 +274,27 @@ static inline zo_noise_state zo_noise_init(uint64_t seed, uint64_t tick, uint64_
 
 static inline uint32_t zo_rotl(uint32_t v, int k) { return (v << k) | (v >> (32 - k)); }
 
-static inline uint32_t zo_noise_next(zo_noise_state *st)     /* xoshiro128++ */
+static inline void zo_noise_next2(zo_noise_state *st, uint32_t *a, uint32_t *b)
 {
     uint32_t *s = st->s;
-    uint32_t result = zo_rotl(s[0] + s[3], 7) + s[0];
+    *a = zo_rotl(s[0] + s[3], 7) + s[0];
+    *b = zo_rotl(s[1] + s[2], 13) + s[2];
     uint32_t t = s[1] << 9;
     s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
     s[2] ^= t;
     s[3] = zo_rotl(s[3], 11);
-    return result;
 }
 
-static inline void zo_noise_draw3(zo_noise_state *st, float sigma, double out[3])
+static inline void zo_noise_draw3(zo_noise_state *st, double out[3])
 {
-    uint32_t a = zo_noise_next(st), b = zo_noise_next(st);
+    uint32_t a, b;
+    zo_noise_next2(st, &a, &b);
     const float k16 = 1.52587890625e-5f;
-    float u0 = ((float)(a >> 16) + 0.5f) * k16, u1 = (float)(a & 0xFFFFu) * k16;
-    float u2 = ((float)(b >> 16) + 0.5f) * k16, u3 = (float)(b & 0xFFFFu) * k16;
-    float r0 = sigma * sqrtf(-1.3862943611198906f * log2f(u0));
-    float r1 = sigma * sqrtf(-1.3862943611198906f * log2f(u2));
+    const float c1 = -34.657359027997266f, c0 = 554.51774444795626f;
+    float l0 = log2f((float)(a >> 16) + 0.5f), u1 = (float)(a & 0xFFFFu) * k16;
+    float l1 = log2f((float)(b >> 16) + 0.5f), u3 = (float)(b & 0xFFFFu) * k16;
+    float r0 = sqrtf(fmaf(l0, c1, c0));
+    float r1 = sqrtf(fmaf(l1, c1, c0));
     const float two_pi = 6.283185307179586f;
     out[0] = (double)(r0 * cosf(two_pi * u1));
     out[1] = (double)(r0 * sinf(two_pi * u1));
@@ -303,7 +306,7 @@ ZO_API void zo_philox_noise(uint64_t seed, uint64_t tick, uint32_t ordinal, uint
 {
     zo_noise_state st = zo_noise_init(seed, tick, entity);
     out[0] = out[1] = out[2] = 0.0;
-    for (uint32_t k = 0; k <= ordinal; ++k) zo_noise_draw3(&st, 5.0f, out);
+    for (uint32_t k = 0; k <= ordinal; ++k) zo_noise_draw3(&st, out);
 }
 
 /*
@@ -338,7 +341,7 @@ ZO_API void zo_radar_phase_fused(int64_t n, int64_t cap, double *pos, const uint
             m |= 1u << r;
             if (mode == 1) {
                 double nz[3];
-                zo_noise_draw3(&ns, 5.0f, nz);
+                zo_noise_draw3(&ns, nz);
                 x += nz[0]; y += nz[1]; z += nz[2];
             } else if (mode == 2) {
                 const double *nz = table + ((int64_t)ordinal * n + i) * 3;

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""The bench's C3 tick loop (lists + missiles + Philox noise) for profiling:
+    rocprofv3 --kernel-trace --stats --output-format csv -d out -- python3 tools/prof_run.py [ticks] [n] [R] [m]"""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from zrk_modulation_amd import scenario as S
+from zrk_modulation_amd.engine import HotPathEngine
+import torch
+
+import os
+ticks = int(sys.argv[1]) if len(sys.argv) > 1 else int(os.environ.get("PROF_TICKS", 300))
+n = int(sys.argv[2]) if len(sys.argv) > 2 else int(os.environ.get("PROF_N", 1_000_000))
+R = int(sys.argv[3]) if len(sys.argv) > 3 else int(os.environ.get("PROF_R", 16))
+m = int(sys.argv[4]) if len(sys.argv) > 4 else int(os.environ.get("PROF_M", 10_000))
+ids, sp, vel, t0 = S.synthetic_targets(n, 1237)
+eng = HotPathEngine(device="cuda:0", dt_ms=10, seed=1237, noise="philox")
+eng.load(ids, sp, vel, t0, S.synthetic_radars(R), missile_capacity=m).enable_lists()
+if m:
+    eng.launch_missiles(S.missile_targets(n, m))
+eng.run(ticks)
+torch.cuda.synchronize()
+eng.store.compact_status()

@@ -42,6 +42,8 @@ __device__ long long *g_wave_probe;
 constexpr double kRad2Deg = 180.0 / 3.14159265358979323846;   // numpy.degrees factor
 constexpr int kCompBlock = 1024;          // list slots per compaction workgroup (count / scan / scatter unit)
 constexpr uint32_t kSparseVis = 1u << 16;  // internal sweep flag: write only non-zero masks
+constexpr uint32_t kNoInside = 1u << 21;   // diagnostics (ZRK_DIAG bit 0): no wave-level "certainly visible" shortcut
+constexpr uint32_t kNoBoxCache = 1u << 22; // diagnostics (ZRK_DIAG bit 1): every wave takes its box from the rows it has just computed
 constexpr float kGuard = 3e-5f;                               // relative half-width of the "ambiguous" band
 
 // Device-side radar records.  Hot: what every (radar, entity) pair touches -- the float32
@@ -68,9 +70,18 @@ struct RadarPre {
     float elx, ely, ehx, ehy;   // azimuth edges as in RadarHot
     float az_sgn;
     float az_out;               // farther than this outside the wedge: certainly outside
-    uint32_t pad[2];
+    // "every row of the box is certainly visible, whatever this tick's noise did to it before":
+    float d2_in;                // farthest corner of the box closer than this: certainly in range (-1: never)
+    float t_in;                 // margin [m] the box must keep from every face of the sector
+    float s_lo_up, s_hi_up;     // elevation bounds as in RadarHot
+    float s_lo_dn, s_hi_dn;
+    float z_in;                 // rows higher than this above the radar's plane stay above it (below: mirrored)
+    uint32_t pad;
+    double pz64;                // the radar's height in binary64, for the per-row side-of-the-plane test
 };
-static_assert(sizeof(RadarPre) == 48, "RadarPre must be 12 dwords");
+static_assert(sizeof(RadarPre) == 80, "RadarPre must be 20 dwords");
+constexpr int kPreVec = (int)(ZRK_MAX_RADARS * sizeof(RadarPre) / 16);      // 16-byte pieces of the table
+static_assert(kPreVec <= ZRK_BLOCK, "one piece per thread");
 
 struct RadarCold {
     double d2_max;              // largest d2 with sqrt(d2) <= max_distance  (== `dist > max` gate)
@@ -79,10 +90,12 @@ struct RadarCold {
 };
 
 struct RadarBlock {                                 // lives in the kernel-argument segment (by value)
-    uint32_t prew[ZRK_MAX_RADARS][12];              // pre-pass records (RadarPre) as dwords, see sweep_row
+    uint32_t prew[ZRK_MAX_RADARS][20];              // pre-pass records (RadarPre) as dwords, see sweep_rows
     uint32_t hotw[ZRK_MAX_RADARS][20];              // RadarHot records as dwords (indexed, never addressed)
     RadarCold cold[ZRK_MAX_RADARS];
 };
+
+struct WaveBox;
 
 struct SweepParams {
     const double *sp, *vel, *t0;
@@ -98,6 +111,7 @@ struct SweepParams {
     int64_t gid0;
     int32_t R, nb;              // nb: sweep workgroups, behind the mb leading workgroups that step the missiles
     int32_t mb, _pad0;
+    WaveBox *boxes;             // per-wave box records (NULL: none kept), see WaveBox
     uint32_t flags;
     RadarBlock rb;
 };
@@ -194,24 +208,31 @@ __device__ __forceinline__ NoiseState noise_init(uint64_t seed, uint64_t tick, u
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t v, int k) { return (v << k) | (v >> (32 - k)); }
 
-__device__ __forceinline__ uint32_t noise_next(NoiseState &st)       // xoshiro128++ (Blackman & Vigna)
+// One step of the xoshiro128 state (Blackman & Vigna), two 32-bit outputs per step: the "++" scrambler on
+// (s0, s3) and the same scrambler on the other half of the state, (s1, s2).
+__device__ __forceinline__ void noise_next2(NoiseState &st, uint32_t &a, uint32_t &b)
 {
-    const uint32_t result = rotl32(st.s0 + st.s3, 7) + st.s0;
+    a = rotl32(st.s0 + st.s3, 7) + st.s0;
+    b = rotl32(st.s1 + st.s2, 13) + st.s2;
     const uint32_t t = st.s1 << 9;
     st.s2 ^= st.s0; st.s3 ^= st.s1; st.s1 ^= st.s2; st.s0 ^= st.s3;
     st.s2 ^= t;
     st.s3 = rotl32(st.s3, 11);
-    return result;
 }
 
-__device__ __forceinline__ void noise_draw3(NoiseState &st, float sigma, float out[3])
+// Three N(0, 5^2) values: two Box-Muller pairs from four 16-bit uniforms, on the hardware log2 / sqrt / sin / cos
+// (v_sin / v_cos take revolutions).  r = 5 sqrt(-2 ln((h + 0.5) / 65536)) = sqrt(kC1 * log2(h + 0.5) + kC0).
+__device__ __forceinline__ void noise_draw3(NoiseState &st, float out[3])
 {
-    const uint32_t a = noise_next(st), b = noise_next(st);
+    constexpr float kC1 = -34.657359027997266f;                       // -2 * 25 * ln 2
+    constexpr float kC0 = 554.51774444795626f;                        // 32 * 25 * ln 2
+    uint32_t a, b;
+    noise_next2(st, a, b);
     const float k16 = 1.52587890625e-5f;                              // 2^-16
-    const float u0 = ((float)(a >> 16) + 0.5f) * k16, u1 = (float)(a & 0xFFFFu) * k16;
-    const float u2 = ((float)(b >> 16) + 0.5f) * k16, u3 = (float)(b & 0xFFFFu) * k16;
-    const float r0 = sigma * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
-    const float r1 = sigma * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+    const float l0 = __builtin_amdgcn_logf((float)(a >> 16) + 0.5f), u1 = (float)(a & 0xFFFFu) * k16;
+    const float l1 = __builtin_amdgcn_logf((float)(b >> 16) + 0.5f), u3 = (float)(b & 0xFFFFu) * k16;
+    const float r0 = __builtin_amdgcn_sqrtf(__builtin_fmaf(l0, kC1, kC0));
+    const float r1 = __builtin_amdgcn_sqrtf(__builtin_fmaf(l1, kC1, kC0));
     out[0] = r0 * __builtin_amdgcn_cosf(u1);
     out[1] = r0 * __builtin_amdgcn_sinf(u1);
     out[2] = r1 * __builtin_amdgcn_cosf(u3);
@@ -259,84 +280,184 @@ __device__ __forceinline__ void wave_bbox(float &lx, float &ly, float &hx, float
     hy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hy), 63));
 }
 
-// Lane r's record for the wave-level cull of sweep_row, read as a vector load from the kernel-argument
-// segment (the sweep parameters are its first bytes).  Issued before the row loads: nobody waits for it.
-__device__ __forceinline__ RadarPre load_pre_record()
+// One minimum and one maximum over the wave, same scheme (the vertical extent of the box, taken only by waves
+// some radar may see).
+__device__ __forceinline__ void wave_minmax(float &lo, float &hi)
 {
-    const RadarPre *tab = (const RadarPre *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SweepParams, rb.prew));
-    return tab[threadIdx.x & (ZRK_MAX_RADARS - 1)];
+#define ZRK_MM_STEP(ctrl)                                                                                  \
+    asm volatile("s_nop 1\n\t"                                                                            \
+                 "v_min_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                        \
+                 "v_max_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf"                             \
+                 : "+v"(lo), "+v"(hi))
+    asm volatile("s_nop 1" ::: );
+    ZRK_MM_STEP("row_ror:1");
+    ZRK_MM_STEP("row_ror:2");
+    ZRK_MM_STEP("row_ror:4");
+    ZRK_MM_STEP("row_ror:8");
+    ZRK_MM_STEP("row_bcast:15");
+    ZRK_MM_STEP("row_bcast:31");
+#undef ZRK_MM_STEP
+    lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lo), 63));
+    hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hi), 63));
 }
 
-// Radars 0..R-1 in order over the NR rows each lane holds, at (x, y, z)[j]; leaves the visibility masks in
-// mask[j] and the (perturbed) positions in place.  Called with the whole wave converged (the early-outs are
-// wave-level votes).  The rows of a lane are independent of each other: NR > 1 gives the vector pipe NR
-// interleaved dependency chains per radar, one scalar-load burst and one wave-level cull for NR * 64 rows.
-template <bool PHILOX, int NR>
-__device__ __forceinline__ int sweep_rows(const SweepParams &P, const RadarPre &q, const int64_t (&li)[NR],
-                                           const bool (&live)[NR], double (&x)[NR], double (&y)[NR], double (&z)[NR],
-                                           uint32_t (&mask)[NR])
+// The pre-pass table of the workgroup: 32 records of 80 bytes in LDS, staged once per workgroup from the
+// kernel-argument segment (the sweep parameters are its first bytes) -- one 16-byte piece per thread, issued
+// before the row loads so that nobody waits for it -- instead of every wave fetching lane r's record with
+// vector loads of its own (8.5 MB per launch at C3, PMC).  Lane r then reads record r with ds_read_b128
+// (80-byte stride: conflict-free within each group of 16 lanes).
+struct PreTable {
+    uint4 v[kPreVec];
+};
+
+// Issued as the wave's first vector load and waited for by count (stage_pre_table: all but the `younger` loads
+// issued since), so that the row loads behind it stay in flight; the compiler does not see the load and would
+// otherwise sink it below them and wait for everything.
+__device__ __forceinline__ uint4 pre_table_fetch()
+{
+    const char *tab = (const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SweepParams, rb.prew);
+    const uint32_t off = (threadIdx.x < kPreVec ? threadIdx.x : 0u) * 16u;
+    uint4 piece;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(piece) : "v"(off), "s"(tab) : "memory");
+    return piece;
+}
+
+template <int YOUNGER>
+__device__ __forceinline__ void stage_pre_table(PreTable &T, uint4 &piece)
+{
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(piece.x), "+v"(piece.y), "+v"(piece.z), "+v"(piece.w) : "n"(YOUNGER) : "memory");
+    if (threadIdx.x < kPreVec) T.v[threadIdx.x] = piece;
+    __syncthreads();
+}
+
+// Box cache.  What a wave needs to know before its rows arrive is where they can be, not where they are: every
+// row moves along a straight line (modules/AirObject.py:23-25), so the bounding box of the wave's live rows taken
+// at some earlier time, grown by the wave's largest speed per axis times the time since, still holds them.  A
+// wave with such a record (48 bytes in the workspace, fetched with scalar loads) runs the whole wave-level
+// classification below -- which radars can see any of its rows, which certainly see all of them -- while its row
+// loads are in flight, and a wave no radar can reach (four in five at C3) has nothing left to do once they land
+// but the three roundings of the advance and the stores.  A wave without a usable record (first tick, rows appended
+// since, record older than kBoxMaxAge seconds of growth) takes the box of the positions it has just computed
+// (DPP reductions), classifies late, and leaves a fresh record behind.  Conservative by construction: the
+// classification only ever uses "no point of the box can be in the sector" / "every point of the box is".
+struct WaveBox {
+    float lo[3], hi[3];          // box of the live rows' positions at time t_ref (before any measurement noise)
+    float vmax[3];               // largest |velocity component| over the wave's rows [m/s]
+    uint32_t state;              // 0: none, 1: valid, 2: valid but some live row is not finite (never culled), 3: no live row
+    double t_ref;
+};
+static_assert(sizeof(WaveBox) == 48, "WaveBox must be 12 dwords");
+constexpr float kBoxMaxGrow = 192.f;                   // metres a cached box may have grown per side before it is retaken
+constexpr uint32_t kBoxOk = 1u, kBoxWild = 2u, kBoxEmpty = 3u;
+
+struct Cull {
+    uint32_t cand;               // radars that may see some row of the wave
+    uint32_t inside;             // ... that certainly see every live row
+    uint32_t plane;              // ... that certainly see every live row above their own horizontal plane, none below
+    uint32_t pz_lo, pz_hi;       // lane r: radar r's height (binary64 halves), for the plane test
+};
+
+// Lane r puts the wave's box to radar r.  Out: closest approach beyond the range sphere, or the whole box
+// beyond an edge of the azimuth wedge by more than noise can bridge.  In: farthest corner in range, lower bounds of
+// the wedge cross products and of the elevation margins dz - s_lo * dist, s_hi * dist - dz above every guard band
+// plus what this tick's noise can add before radar r looks (host: derive_pre), box wholly above or wholly
+// below the radar.  The commonest sector floor is the radar's own horizontal plane (elevation from 0 degrees,
+// nothing visible below): rows may sit arbitrarily close to that face, so there it is left to a per-row test -- the
+// sign of dz in binary64, which is all the reference's arcsin decides -- while range, wedge and the upper cone are
+// settled for the part of the box above the plane.
+__device__ __forceinline__ Cull cull_box(const PreTable &T, int R, bool shortcuts, float blx, float bly, float blz,
+                                         float bhx, float bhy, float bhz)
+{
+    Cull c;
+    const int rl = (int)(threadIdx.x & (ZRK_MAX_RADARS - 1)) * (int)(sizeof(RadarPre) / 16);
+    const uint4 w0 = T.v[rl], w1 = T.v[rl + 1], w2 = T.v[rl + 2], w3 = T.v[rl + 3], w4 = T.v[rl + 4];
+    const float qpx = __builtin_bit_cast(float, w0.x), qpy = __builtin_bit_cast(float, w0.y);
+    const float qpz = __builtin_bit_cast(float, w0.z), qd2_out = __builtin_bit_cast(float, w0.w);
+    const float qelx = __builtin_bit_cast(float, w1.x), qely = __builtin_bit_cast(float, w1.y);
+    const float qehx = __builtin_bit_cast(float, w1.z), qehy = __builtin_bit_cast(float, w1.w);
+    const float qaz_sgn = __builtin_bit_cast(float, w2.x), qaz_out = __builtin_bit_cast(float, w2.y);
+    const float qd2_in = __builtin_bit_cast(float, w2.z), qt_in = __builtin_bit_cast(float, w2.w);
+    const float s_lo_up = __builtin_bit_cast(float, w3.x), s_hi_up = __builtin_bit_cast(float, w3.y);
+    const float s_lo_dn = __builtin_bit_cast(float, w3.z), s_hi_dn = __builtin_bit_cast(float, w3.w);
+    const float qz_in = __builtin_bit_cast(float, w4.x);
+    c.pz_lo = w4.z; c.pz_hi = w4.w;
+    const float ex_lo = blx - qpx, ex_hi = bhx - qpx, ey_lo = bly - qpy, ey_hi = bhy - qpy;
+    const float ez_lo = blz - qpz, ez_hi = bhz - qpz;
+    const float gx = fmaxf(fmaxf(ex_lo, -ex_hi), 0.f), gy = fmaxf(fmaxf(ey_lo, -ey_hi), 0.f);
+    const float gz = fmaxf(fmaxf(ez_lo, -ez_hi), 0.f);
+    // the cull's closest approach is horizontal only: the thresholds of derive_pre are horizontal distances
+    const float d2min = __builtin_fmaf(gy, gy, gx * gx);
+    // cl = elx * ey - ely * ex,  ch = ehy * ex - ehx * ey  over the box
+    const float a1 = qelx * ey_lo, a2 = qelx * ey_hi, b1 = qely * ex_lo, b2 = qely * ex_hi;
+    const float c1 = qehy * ex_lo, c2 = qehy * ex_hi, d1 = qehx * ey_lo, d2 = qehx * ey_hi;
+    const float cl_hi = fmaxf(a1, a2) - fminf(b1, b2), cl_lo = fminf(a1, a2) - fmaxf(b1, b2);
+    const float ch_hi = fmaxf(c1, c2) - fminf(d1, d2), ch_lo = fminf(c1, c2) - fmaxf(d1, d2);
+    // m_az = az_sgn * min(cl, ch) is at most ub and at least lb over the box
+    const bool narrow = qaz_sgn > 0.f;
+    const float ub = narrow ? fminf(cl_hi, ch_hi) : -fminf(cl_lo, ch_lo);
+    const float lb = narrow ? fminf(cl_lo, ch_lo) : -fminf(cl_hi, ch_hi);
+    const bool out = (d2min > qd2_out) | (ub < -qaz_out);
+    const uint32_t all = (R >= 32) ? 0xFFFFFFFFu : ((1u << R) - 1u);
+    c.cand = (uint32_t)__ballot(!out) & all;
+    c.inside = 0u; c.plane = 0u;
+    if (c.cand && shortcuts) {                            // wave-uniform
+        const float mx = fmaxf(fabsf(ex_lo), fabsf(ex_hi)), my = fmaxf(fabsf(ey_lo), fabsf(ey_hi));
+        const float mz = fmaxf(fabsf(ez_lo), fabsf(ez_hi));
+        const float d2max = __builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx));
+        const float dmin = __builtin_amdgcn_sqrtf(__builtin_fmaf(gz, gz, d2min));
+        const float dmax = __builtin_amdgcn_sqrtf(d2max);
+        const bool up = ez_lo > qz_in, dn = ez_hi < -qz_in;           // wholly above / below the radar
+        const float s_lo = up ? s_lo_up : s_lo_dn, s_hi = up ? s_hi_up : s_hi_dn;
+        // a = dz - s_lo * dist, b = s_hi * dist - dz over the box, from below
+        const float a_min = ez_lo - s_lo * ((s_lo >= 0.f) ? dmax : dmin);
+        const float b_min = s_hi * ((s_hi >= 0.f) ? dmin : dmax) - ez_hi;
+        const float t_box = fminf(lb, fminf(a_min, b_min));
+        const bool ranged = d2max < qd2_in;
+        const bool sure = (up | dn) & ranged & (t_box > qt_in);
+        const float b_up = s_hi_up * ((s_hi_up >= 0.f) ? dmin : dmax) - ez_hi;
+        const bool floor_is_plane = (s_lo_up == -2.f) & (s_lo_dn == 2.f) & (s_hi_dn == -2.f);
+        const bool sure_but_plane = floor_is_plane & ranged & (fminf(lb, b_up) > qt_in);
+        c.inside = (uint32_t)__ballot(sure) & c.cand;
+        c.plane = (uint32_t)__ballot(sure_but_plane) & c.cand & ~c.inside;
+    }
+    return c;
+}
+
+// Radars in `c.cand`, in order, over the wave's rows at (x, y, z); leaves the visibility mask in `mask` and the
+// (perturbed) position in place.  Called with the whole wave converged (the early-outs are wave-level votes).
+template <bool PHILOX>
+__device__ __forceinline__ void sweep_rows(const SweepParams &P, const Cull &c, int64_t li, bool live, double &x, double &y,
+                                           double &z, uint32_t &mask, int64_t probe_wave)
 {
     // keyed by list index: layout-independent.  Seeded when the first lane of the wave is detected -- in
     // spatial order most waves never are, and the ten Philox rounds are a fifth of a quiet wave's work.
-    NoiseState ns[NR];
-    bool seeded[NR];
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        mask[j] = 0u;
-        ns[j] = NoiseState{0u, 0u, 0u, 0u};
-        seeded[j] = false;
-    }
+    NoiseState ns = NoiseState{0u, 0u, 0u, 0u};
+    bool seeded = false;
+    mask = 0u;
 #ifdef ZRK_PROBE_BUILD
     int probe_deep = 0;
 #endif
-    // Wave-level cull.  In spatial order the rows of a wave sit in a cell about a kilometre across, and
-    // four waves in five are out of range or well outside the wedge of every radar -- yet walking the radars
-    // one after the other costs them ~20 vector instructions per radar just to find that out.  Instead the
-    // wave takes the horizontal bounding box of its live rows (four DPP reductions) and lane r tests it against
-    // radar r: closest approach to the range sphere, interval bounds of the two wedge cross products.  The
-    // bounds (host: derive_pre) are widened by whatever this tick's noise can add before the radar looks,
-    // so "no point of the box can be in the sector" implies "no lane will be".  One pass of ~50 vector
-    // instructions settles all radars; only the radars the box may reach enter the sequential loop, which
-    // repeats its own votes on the true positions.  Conservative, never decisive; rows with non-finite
-    // coordinates (which min/max would drop from the box) switch the cull off for their wave.
-    uint32_t cand = (P.R >= 32) ? 0xFFFFFFFFu : ((1u << P.R) - 1u);
-    {
-        const float inf = __builtin_inff(), kBig = 1e30f;
-        float blx = 0.f, bly = 0.f, bhx = 0.f, bhy = 0.f;
-        bool wild = false, any_live = false;
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            const float fx0 = (float)x[j], fy0 = (float)y[j], fz0 = (float)z[j];
-            wild |= live[j] & !((fabsf(fx0) < kBig) & (fabsf(fy0) < kBig) & (fabsf(fz0) < kBig));
-            any_live |= live[j];
-            const float lox = live[j] ? fx0 : inf, loy = live[j] ? fy0 : inf;
-            const float hix = live[j] ? fx0 : -inf, hiy = live[j] ? fy0 : -inf;
-            blx = j ? fminf(blx, lox) : lox; bly = j ? fminf(bly, loy) : loy;
-            bhx = j ? fmaxf(bhx, hix) : hix; bhy = j ? fmaxf(bhy, hiy) : hiy;
-        }
-        {
-            wave_bbox(blx, bly, bhx, bhy);
-            // the box is horizontal only: heights add little to the closest approach (a sector's range is
-            // several times any altitude) and nothing to the wedge test, and each extra extent costs a reduction
-            const float ex_lo = blx - q.px, ex_hi = bhx - q.px, ey_lo = bly - q.py, ey_hi = bhy - q.py;
-            const float gx = fmaxf(fmaxf(ex_lo, -ex_hi), 0.f), gy = fmaxf(fmaxf(ey_lo, -ey_hi), 0.f);
-            const float d2min = __builtin_fmaf(gy, gy, gx * gx);
-            // cl = elx * ey - ely * ex,  ch = ehy * ex - ehx * ey  over the box
-            const float a1 = q.elx * ey_lo, a2 = q.elx * ey_hi, b1 = q.ely * ex_lo, b2 = q.ely * ex_hi;
-            const float c1 = q.ehy * ex_lo, c2 = q.ehy * ex_hi, d1 = q.ehx * ey_lo, d2 = q.ehx * ey_hi;
-            const float cl_hi = fmaxf(a1, a2) - fminf(b1, b2), cl_lo = fminf(a1, a2) - fmaxf(b1, b2);
-            const float ch_hi = fmaxf(c1, c2) - fminf(d1, d2), ch_lo = fminf(c1, c2) - fmaxf(d1, d2);
-            // m_az = az_sgn * min(cl, ch) is at most ...
-            const float ub = (q.az_sgn > 0.f) ? fminf(cl_hi, ch_hi) : -fminf(cl_lo, ch_lo);
-            const bool out = (d2min > q.d2_out) | (ub < -q.az_out);
-            // (no branch around the cull: the record's loads then sit with the row's and nobody waits twice)
-            cand &= __ballot(wild) ? 0xFFFFFFFFu : (uint32_t)__ballot(!out);
-            if (!__ballot(any_live)) cand = 0;
-        }
-    }
-    const int walked = __builtin_popcount(cand);      // wave-uniform: what this wave costs, for next tick's order
-    for (; cand; cand &= cand - 1) {
+    for (uint32_t cand = c.cand; cand; cand &= cand - 1) {
         const int r = __builtin_ctz(cand);
+        if (((c.inside | c.plane) >> r) & 1u) {       // every live row (above the radar's plane) is visible: no geometry
+            const bool by_plane = (c.plane >> r) & 1u;
+            const double rpz = __builtin_bit_cast(double, ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)c.pz_hi, r) << 32) |
+                                                               (uint32_t)__builtin_amdgcn_readlane((int)c.pz_lo, r));
+            const bool vis = live & (!by_plane | (z - rpz >= 0.0));
+            if (PHILOX && !seeded && __ballot(vis)) {
+                ns = noise_init(P.seed, P.tick, (uint64_t)(P.gid0 + li));
+                seeded = true;
+            }
+            if (vis) {
+                mask |= 1u << r;
+                if (PHILOX) {
+                    float nz[3];
+                    noise_draw3(ns, nz);
+                    x += (double)nz[0]; y += (double)nz[1]; z += (double)nz[2];               // modules/Radar.py:142
+                }
+            }
+            continue;
+        }
         // one scalar-load burst for the whole hot record, resident in SGPRs before any use
         uint32_t w[18];
 #pragma unroll
@@ -354,76 +475,59 @@ __device__ __forceinline__ int sweep_rows(const SweepParams &P, const RadarPre &
         const float s_lo_dn = __builtin_bit_cast(float, w[14]), s_hi_dn = __builtin_bit_cast(float, w[15]);
         const float az_guard = __builtin_bit_cast(float, w[16]), az_sgn = __builtin_bit_cast(float, w[17]);
 
-        double dx[NR], dy[NR], dz[NR];
-        float fx[NR], fy[NR], fz[NR], d2f[NR], m_az[NR];
-        bool in_range[NR];
-        bool any = false;
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            dx[j] = x[j] - rpx; dy[j] = y[j] - rpy; dz[j] = z[j] - rpz;
-            fx[j] = (float)dx[j]; fy[j] = (float)dy[j]; fz[j] = (float)dz[j];
-            d2f[j] = __builtin_fmaf(fz[j], fz[j], __builtin_fmaf(fy[j], fy[j], fx[j] * fx[j]));
-            in_range[j] = live[j] & (d2f[j] <= d2f_out);
-            any |= in_range[j];
-        }
+        const double dx = x - rpx, dy = y - rpy, dz = z - rpz;
+        const float fx = (float)dx, fy = (float)dy, fz = (float)dz;
+        const float d2f = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+        const bool in_range = live & (d2f <= d2f_out);
         // float32 range gate.  With rows stored in spatial order the lanes of a wave mostly agree,
         // so a wave none of whose lanes is in range (or, below, anywhere near the azimuth wedge)
         // leaves the radar here instead of paying for the rest of the classification.
-        if (!__ballot(any)) continue;
-        any = false;
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            const float cl = __builtin_fmaf(elx, fy[j], -(ely * fx[j]));     // az_sgn * cross(e_lo, p)
-            const float ch = __builtin_fmaf(fx[j], ehy, -(fy[j] * ehx));     // az_sgn * cross(p, e_hi)
-            m_az[j] = az_sgn * fminf(cl, ch);                                // > 0 inside the azimuth sector [m]
-            any |= in_range[j] & !(m_az[j] < -az_guard);
-        }
-        if (!__ballot(any)) continue;                                        // every lane certainly outside the wedge
+        if (!__ballot(in_range)) continue;
+        const float cl = __builtin_fmaf(elx, fy, -(ely * fx));               // az_sgn * cross(e_lo, p)
+        const float ch = __builtin_fmaf(fx, ehy, -(fy * ehx));               // az_sgn * cross(p, e_hi)
+        const float m_az = az_sgn * fminf(cl, ch);                           // > 0 inside the azimuth sector [m]
+        if (!__ballot(in_range & !(m_az < -az_guard))) continue;             // every lane certainly outside the wedge
 #ifdef ZRK_PROBE_BUILD
         ++probe_deep;
 #endif
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            const float dist = __builtin_amdgcn_sqrtf(d2f[j]);
-            // elevation: el = theta for dz >= 0, 180 + theta for dz < 0 (sign taken in binary64, so a
-            // tiny negative dz that rounds to -0.0f still selects the lower-hemisphere bounds)
-            const float a_up = __builtin_fmaf(-s_lo_up, dist, fz[j]), b_up = __builtin_fmaf(s_hi_up, dist, -fz[j]);
-            const float a_dn = __builtin_fmaf(-s_lo_dn, dist, fz[j]), b_dn = __builtin_fmaf(s_hi_dn, dist, -fz[j]);
-            const bool up = dz[j] >= 0.0;
-            const float a = up ? a_up : a_dn, b = up ? b_up : b_dn;
-            // t: signed distance [m] to the nearest sector face (> 0 inside).  Pairs with |t| within
-            // kGuard * dist of a face, and pairs in the thin shell around the range sphere, are decided
-            // in binary64; everything else is settled here.  NaN / overflow fall out as "not in range"
-            // (degenerate ranges are encoded by the host as d2f_out = inf, d2f_in = -1 -> always exact).
-            const float t = fminf(fminf(m_az[j], a), b);
-            const float gd = kGuard * dist;
-            bool vis = in_range[j] & (t > gd);
-            const bool amb = in_range[j] & ((fabsf(t) <= gd) | !(d2f[j] < d2f_in));
-            if (amb) vis = visible_exact(P.rb.cold[r], dx[j], dy[j], dz[j]);
-            if (PHILOX && !seeded[j] && __ballot(vis)) {
-                ns[j] = noise_init(P.seed, P.tick, (uint64_t)(P.gid0 + li[j]));
-                seeded[j] = true;
-            }
-            if (vis) {
-                mask[j] |= 1u << r;
-                if (PHILOX) {
-                    float nz[3];
-                    noise_draw3(ns[j], 5.0f, nz);
-                    x[j] += (double)nz[0]; y[j] += (double)nz[1]; z[j] += (double)nz[2];   // modules/Radar.py:142
-                }
+        const float dist = __builtin_amdgcn_sqrtf(d2f);
+        // elevation: el = theta for dz >= 0, 180 + theta for dz < 0 (sign taken in binary64, so a
+        // tiny negative dz that rounds to -0.0f still selects the lower-hemisphere bounds)
+        const float a_up = __builtin_fmaf(-s_lo_up, dist, fz), b_up = __builtin_fmaf(s_hi_up, dist, -fz);
+        const float a_dn = __builtin_fmaf(-s_lo_dn, dist, fz), b_dn = __builtin_fmaf(s_hi_dn, dist, -fz);
+        const bool up = dz >= 0.0;
+        const float a = up ? a_up : a_dn, b = up ? b_up : b_dn;
+        // t: signed distance [m] to the nearest sector face (> 0 inside).  Pairs with |t| within
+        // kGuard * dist of a face, and pairs in the thin shell around the range sphere, are decided
+        // in binary64; everything else is settled here.  NaN / overflow fall out as "not in range"
+        // (degenerate ranges are encoded by the host as d2f_out = inf, d2f_in = -1 -> always exact).
+        const float t = fminf(fminf(m_az, a), b);
+        const float gd = kGuard * dist;
+        bool vis = in_range & (t > gd);
+        const bool amb = in_range & ((fabsf(t) <= gd) | !(d2f < d2f_in));
+        if (amb) vis = visible_exact(P.rb.cold[r], dx, dy, dz);
+        if (PHILOX && !seeded && __ballot(vis)) {
+            ns = noise_init(P.seed, P.tick, (uint64_t)(P.gid0 + li));
+            seeded = true;
+        }
+        if (vis) {
+            mask |= 1u << r;
+            if (PHILOX) {
+                float nz[3];
+                noise_draw3(ns, nz);
+                x += (double)nz[0]; y += (double)nz[1]; z += (double)nz[2];                   // modules/Radar.py:142
             }
         }
     }
 #ifdef ZRK_PROBE_BUILD
-    ZRK_WAVE_PROBE((int64_t)(((int)blockIdx.x - P.mb) * (ZRK_BLOCK / 64) + (threadIdx.x >> 6)), 5, (long long)probe_deep);
+    ZRK_WAVE_PROBE(probe_wave, 5, (long long)probe_deep);
 #endif
-    return walked;
 }
 
-// One pass over the table: NR * 64 consecutive rows per wave, row j of a lane 64 rows after row j-1.
-// ADVANCE / LIDX mirror ZRK_F_ADVANCE and list_index != NULL as template parameters so that the row's column
-// loads sit in one basic block and are all in flight before anything waits for one.
-template <bool PHILOX, int NR, bool ADVANCE, bool LIDX>
+// One pass over the table: 64 consecutive rows per wave.  ADVANCE / LIDX mirror ZRK_F_ADVANCE and
+// list_index != NULL as template parameters so that the row's column loads sit in one basic block and are all in
+// flight before anything waits for one.
+template <bool PHILOX, bool ADVANCE, bool LIDX>
 __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, const MissileArgs M)
 {
     if ((int)blockIdx.x < P.mb) {              // leading workgroups: Missile.step for every in-flight row (a long
@@ -436,52 +540,140 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     }
     const int tid = threadIdx.x;
     const int bid = (int)blockIdx.x - P.mb;
-    const int blk = P.order ? P.order[bid] : bid;
+    // (scalar loads by hand: the compiler cannot prove these words read-only and would fetch a wave-uniform word
+    // with a vector load, whose full latency then sits in front of every row load of the wave)
+    int blk = bid;
+    if (P.order) {
+        const int32_t *po = P.order + bid;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk) : "s"(po) : "memory");
+    }
     const int64_t wave = (int64_t)blk * (ZRK_BLOCK / 64) + (tid >> 6);
     const int64_t cap = P.cap;
-    const RadarPre pre = load_pre_record();
+    __shared__ PreTable s_pre;
+    uint4 pre_piece = pre_table_fetch();
     ZRK_WAVE_PROBE(wave, 0, wall_clock64());
-    int64_t i[NR], li[NR];
-    bool live[NR];
-    double x[NR], y[NR], z[NR];
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        i[j] = (wave * NR + j) * 64 + (tid & 63);
-        // every column load of the row is issued before anything waits for one: rows past the end read row 0
-        const int64_t ic = (i[j] < P.n) ? i[j] : 0;
-        const uint8_t al = P.alive[ic];
-        const int32_t lix = LIDX ? P.lidx[ic] : 0;
-        if (ADVANCE) {
-            // Trajectory.get_pos: three separate roundings per axis
-            const double t0 = P.t0[ic], vx = P.vel[ic], vy = P.vel[cap + ic], vz = P.vel[2 * cap + ic];
-            const double sx0 = P.sp[ic], sy0 = P.sp[cap + ic], sz0 = P.sp[2 * cap + ic];
-            const double d = P.t - t0;
-            const double sx = vx * d, sy = vy * d, sz = vz * d;
-            x[j] = sx0 + sx; y[j] = sy0 + sy; z[j] = sz0 + sz;
-        } else {
-            x[j] = P.pos[ic]; y[j] = P.pos[cap + ic]; z[j] = P.pos[2 * cap + ic];
+    // where the wave runs: HW_REG_HW_ID (wave / simd / cu / sh / se) and HW_REG_XCC_ID
+    ZRK_WAVE_PROBE(wave, 6, (long long)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                ((long long)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32));
+    const int64_t i = wave * 64 + (tid & 63);
+    // every column load of the row is issued before anything waits for one: rows past the end read row 0
+    const int64_t ic = (i < P.n) ? i : 0;
+    const uint8_t al = P.alive[ic];
+    const int32_t lix = LIDX ? P.lidx[ic] : 0;
+    // (only the loads here: the arithmetic waits for them and comes after everything that does not)
+    double t0 = 0.0, vx = 0.0, vy = 0.0, vz = 0.0, sx0, sy0, sz0;
+    if (ADVANCE) {
+        t0 = P.t0[ic];
+        vx = P.vel[ic]; vy = P.vel[cap + ic]; vz = P.vel[2 * cap + ic];
+        sx0 = P.sp[ic]; sy0 = P.sp[cap + ic]; sz0 = P.sp[2 * cap + ic];
+    } else {
+        sx0 = P.pos[ic]; sy0 = P.pos[cap + ic]; sz0 = P.pos[2 * cap + ic];
+    }
+    const bool live = (i < P.n) & (al != 0);
+    const int64_t li = (LIDX && i < P.n) ? (int64_t)lix : i;     // where this row sits in AirEnv's list
+    // the wave's box record, if the caller keeps any (zrk_run_ticks does): twelve scalar words
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 b0 = {0u, 0u, 0u, 0u}, b1 = {0u, 0u, 0u, 0u}, bv = {0u, 0u, 0u, 0u};     // lo[3] hi[0] | hi[1..2] vmax[0..1] | vmax[2] state t_ref
+    const bool cached = ADVANCE && P.boxes != nullptr;
+    if (cached) {
+        const int64_t wave_s = (int64_t)blk * (ZRK_BLOCK / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);   // the same, in SGPRs
+        const WaveBox *pb = P.boxes + wave_s;
+        asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(b0), "=&s"(b1), "=&s"(bv) : "s"(pb) : "memory");
+    }
+    const uint32_t bw[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    stage_pre_table<1 + (LIDX ? 1 : 0) + (ADVANCE ? 7 : 3)>(s_pre, pre_piece);
+    const bool shortcuts = !(P.flags & kNoInside);
+    Cull c;
+    c.cand = 0u; c.inside = 0u; c.plane = 0u; c.pz_lo = 0u; c.pz_hi = 0u;
+    bool have = false;                                   // classified from the record, before the rows are here
+    const uint32_t bstate = bv[1];
+    if (cached && bstate != 0u && !(P.flags & kNoBoxCache)) {
+        const double t_ref = __builtin_bit_cast(double, ((uint64_t)bv[3] << 32) | bv[2]);
+        const float age = fabsf((float)(P.t - t_ref)) * 1.000001f + 1e-6f;      // seconds, rounded up
+        const float g0 = __builtin_bit_cast(float, bw[6]) * age, g1 = __builtin_bit_cast(float, bw[7]) * age;
+        const float g2 = __builtin_bit_cast(float, bv[0]) * age;
+        const float grow = fmaxf(fmaxf(g0, g1), g2);
+        if (bstate == kBoxEmpty) {                      // nobody alive at t_ref, nobody is revived: nothing to sweep
+            have = true;
+        } else if (bstate == kBoxOk && grow <= kBoxMaxGrow) {
+            // (the 1e-3 m covers the rounding of the grown bounds; derive_pre's slack has a metre for the rest)
+            c = cull_box(s_pre, P.R, shortcuts,
+                         __builtin_bit_cast(float, bw[0]) - g0 - 1e-3f, __builtin_bit_cast(float, bw[1]) - g1 - 1e-3f,
+                         __builtin_bit_cast(float, bw[2]) - g2 - 1e-3f, __builtin_bit_cast(float, bw[3]) + g0 + 1e-3f,
+                         __builtin_bit_cast(float, bw[4]) + g1 + 1e-3f, __builtin_bit_cast(float, bw[5]) + g2 + 1e-3f);
+            have = true;
         }
-        live[j] = (i[j] < P.n) & (al != 0);
-        li[j] = (LIDX && i[j] < P.n) ? (int64_t)lix : i[j];     // where this row sits in AirEnv's list
+    }
+    double x = sx0, y = sy0, z = sz0;
+    if (ADVANCE) {
+        // Trajectory.get_pos: three separate roundings per axis
+        const double d = P.t - t0;
+        const double sx = vx * d, sy = vy * d, sz = vz * d;
+        x = sx0 + sx; y = sy0 + sy; z = sz0 + sz;
     }
 #ifdef ZRK_PROBE_BUILD
-    asm volatile("" ::"v"(x[NR - 1]), "v"(y[NR - 1]), "v"(z[NR - 1]) : "memory");
+    asm volatile("" ::"v"(x), "v"(y), "v"(z) : "memory");
 #endif
     ZRK_WAVE_PROBE(wave, 1, wall_clock64());
-    uint32_t mask[NR];
-    const int walked = sweep_rows<PHILOX, NR>(P, pre, li, live, x, y, z, mask);
+    if (!have) {
+        // no usable record: the box of the positions just computed (wave-uniform after the reductions)
+        const float inf = __builtin_inff(), kBig = 1e30f;
+        const float fx0 = (float)x, fy0 = (float)y, fz0 = (float)z;
+        const bool wild = live & !((fabsf(fx0) < kBig) & (fabsf(fy0) < kBig) & (fabsf(fz0) < kBig));
+        float blx = live ? fx0 : inf, bly = live ? fy0 : inf, blz = live ? fz0 : inf;
+        float bhx = live ? fx0 : -inf, bhy = live ? fy0 : -inf, bhz = live ? fz0 : -inf;
+        wave_bbox(blx, bly, bhx, bhy);
+        wave_minmax(blz, bhz);
+        const bool any_wild = __ballot(wild) != 0ull, any_live = __ballot(live) != 0ull;
+        const uint32_t all = (P.R >= 32) ? 0xFFFFFFFFu : ((1u << P.R) - 1u);
+        if (!any_live) { c.cand = 0u; c.inside = 0u; c.plane = 0u; }
+        else if (any_wild) { c.cand = all; c.inside = 0u; c.plane = 0u; }   // min / max drop NaNs: never cull such a wave
+        else c = cull_box(s_pre, P.R, shortcuts, blx, bly, blz, bhx, bhy, bhz);
+        if (cached) {
+            // leave a record behind: lanes 0..11 store one word each.  The speeds are taken over every row of the
+            // wave, live or not (rows past the end read row 0's: harmless, it only widens), once per record's life.
+            float m0 = __builtin_bit_cast(float, bw[6]), m1 = __builtin_bit_cast(float, bw[7]), m2 = __builtin_bit_cast(float, bv[0]);
+            if (bstate == 0u) {
+                float n0 = fabsf((float)vx) * 1.000001f, n1 = fabsf((float)vy) * 1.000001f, n2 = fabsf((float)vz) * 1.000001f;
+                float lo_unused = 0.f;
+                wave_minmax(lo_unused, n0);
+                lo_unused = 0.f; wave_minmax(lo_unused, n1);
+                lo_unused = 0.f; wave_minmax(lo_unused, n2);
+                const bool vfin = (n0 < kBig) & (n1 < kBig) & (n2 < kBig);      // NaN / inf speeds: the record never holds
+                m0 = vfin ? n0 : inf; m1 = vfin ? n1 : inf; m2 = vfin ? n2 : inf;
+            }
+            const uint32_t st = !any_live ? kBoxEmpty : (any_wild ? kBoxWild : kBoxOk);
+            const uint64_t tb = __builtin_bit_cast(uint64_t, P.t);
+            const int lane = tid & 63;
+            uint32_t word = __builtin_bit_cast(uint32_t, blx);
+            word = lane == 1 ? __builtin_bit_cast(uint32_t, bly) : word;
+            word = lane == 2 ? __builtin_bit_cast(uint32_t, blz) : word;
+            word = lane == 3 ? __builtin_bit_cast(uint32_t, bhx) : word;
+            word = lane == 4 ? __builtin_bit_cast(uint32_t, bhy) : word;
+            word = lane == 5 ? __builtin_bit_cast(uint32_t, bhz) : word;
+            word = lane == 6 ? __builtin_bit_cast(uint32_t, m0) : word;
+            word = lane == 7 ? __builtin_bit_cast(uint32_t, m1) : word;
+            word = lane == 8 ? __builtin_bit_cast(uint32_t, m2) : word;
+            word = lane == 9 ? st : word;
+            word = lane == 10 ? (uint32_t)tb : word;
+            word = lane == 11 ? (uint32_t)(tb >> 32) : word;
+            if (lane < 12) ((uint32_t *)(P.boxes + wave))[lane] = word;
+        }
+    }
+    const int walked = __builtin_popcount(c.cand);     // wave-uniform: what this wave costs, for next tick's order
+    ZRK_WAVE_PROBE(wave, 7, (long long)(walked | (__builtin_popcount(c.inside) << 8) | (__builtin_popcount(c.plane) << 16) | ((int)have << 24)));
+    uint32_t mask = 0u;
+    if (walked) sweep_rows<PHILOX>(P, c, li, live, x, y, z, mask, wave);
     if (P.cost && walked && (tid & 63) == 0) atomicAdd(&P.cost[blk], walked);
     ZRK_WAVE_PROBE(wave, 2, wall_clock64());
-    ZRK_WAVE_PROBE(wave, 4, (long long)__popcll(__ballot(mask[0] != 0)));
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        if (live[j] && (PHILOX || ADVANCE)) {
-            P.pos[i[j]] = x[j]; P.pos[cap + i[j]] = y[j]; P.pos[2 * cap + i[j]] = z[j];
-        }
-        // sparse mode: the buffer is known to be all zero (the previous tick's compaction cleared it), so only
-        // detections are written -- list-indexed stores are scattered when the table is spatially sorted
-        if (i[j] < P.n && (mask[j] || !(P.flags & kSparseVis))) P.vis[li[j]] = mask[j];
+    ZRK_WAVE_PROBE(wave, 4, (long long)__popcll(__ballot(mask != 0)));
+    if (live && (PHILOX || ADVANCE)) {
+        P.pos[i] = x; P.pos[cap + i] = y; P.pos[2 * cap + i] = z;
     }
+    // sparse mode: the buffer is known to be all zero (the previous tick's compaction cleared it), so only
+    // detections are written -- list-indexed stores are scattered when the table is spatially sorted
+    if (i < P.n && (mask || !(P.flags & kSparseVis))) P.vis[li] = mask;
     ZRK_WAVE_PROBE(wave, 3, wall_clock64());
 }
 
@@ -1211,7 +1403,7 @@ __global__ void k_selftest_noise(uint64_t seed, uint64_t tick, uint32_t ordinal,
     if (i >= n) return;
     NoiseState ns = noise_init(seed, tick, (uint64_t)(entity0 + i));
     float nz[3] = {0.f, 0.f, 0.f};
-    for (uint32_t k = 0; k <= ordinal; ++k) noise_draw3(ns, 5.0f, nz);
+    for (uint32_t k = 0; k <= ordinal; ++k) noise_draw3(ns, nz);
     out[3 * i] = (double)nz[0]; out[3 * i + 1] = (double)nz[1]; out[3 * i + 2] = (double)nz[2];
 }
 
@@ -1275,32 +1467,47 @@ void derive_radar(const zrk_radar &hr, bool exact_only, RadarHot &h, RadarCold &
     }
 }
 
-// Bounds of the pre-pass: a row that, seen from its position BEFORE this tick's noise, is farther than
+// Bounds of the pre-pass.  Outside: a row that, seen from its position BEFORE this tick's noise, is farther than
 // d2_out from the radar or more than az_out outside the azimuth wedge cannot be in the sector whatever
-// happens earlier in the tick.  Slack: every detection moves a row by at most kNoiseReach (Box-Muller on
-// 16-bit uniforms: radius <= 5 * sqrt(-2 ln(2^-17)) = 24.3 m in the x-y plane and along z, 34.4 m in space),
-// at most R - 1 times before a radar looks; the distance to a wedge face and to the range sphere are
-// 1-Lipschitz in the position.  Binary32 coordinates are off by 2^-24 relative per axis: covered by
+// happens earlier in the tick.  Inside: a box that keeps t_in metres from every face of the sector and whose
+// farthest corner is closer than sqrt(d2_in) holds only rows the radar certainly sees.  Slack: every detection
+// moves a row by at most kNoiseReach (Box-Muller on 16-bit uniforms: radius <= 5 * sqrt(-2 ln(2^-17)) = 24.3 m in
+// the x-y plane and along z, 34.4 m in space), and radar number `index` looks after at most `index` of them;
+// the distance to a wedge face and to the range sphere are 1-Lipschitz in the position, the elevation margins
+// dz -+ s * dist 2-Lipschitz.  Binary32 coordinates are off by 2^-24 relative per axis: covered by
 // 4e-6 * (|radar| + reach) + 1 m and the factor on the square.  Degenerate radars keep the encoding of their
-// hot record (d2f_out < 0: never visible; infinite: every row is a candidate).
-void derive_pre(const zrk_radar &hr, const RadarHot &h, bool philox, int R, RadarPre &p)
+// hot record (d2f_out < 0: never visible; infinite: every row is a candidate) and are never "certainly inside".
+void derive_pre(const zrk_radar &hr, const RadarHot &h, bool philox, int index, RadarPre &p)
 {
     constexpr double kNoiseReach = 34.4;
     std::memset(&p, 0, sizeof(p));
     p.px = (float)hr.pos[0]; p.py = (float)hr.pos[1]; p.pz = (float)hr.pos[2];
     p.elx = h.elx; p.ely = h.ely; p.ehx = h.ehx; p.ehy = h.ehy; p.az_sgn = h.az_sgn;
+    p.s_lo_up = h.s_lo_up; p.s_hi_up = h.s_hi_up; p.s_lo_dn = h.s_lo_dn; p.s_hi_dn = h.s_hi_dn;
     p.az_out = INFINITY;
+    p.d2_in = -1.f; p.t_in = INFINITY; p.z_in = INFINITY; p.pz64 = hr.pos[2];
     if (h.d2f_out < 0.f) { p.d2_out = -1.f; return; }
     p.d2_out = INFINITY;
     if (std::isinf(h.d2f_out) || std::isnan(h.d2f_out)) return;
     const double reach = std::sqrt((double)h.d2f_out);
     const double centre = std::fabs(hr.pos[0]) + std::fabs(hr.pos[1]) + std::fabs(hr.pos[2]);
     if (!std::isfinite(centre)) return;
-    const double slack = (philox ? kNoiseReach * std::max(R - 1, 0) : 0.0) + 4e-6 * (centre + reach) + 1.0;
+    const double slack = (philox ? kNoiseReach * std::max(index, 0) : 0.0) + 4e-6 * (centre + reach) + 1.0;
     const double b = (reach + slack) * (reach + slack) * (1.0 + 1e-5);
     if (b < 3e38) p.d2_out = (float)b;
     const double a = ((double)h.az_guard + slack) * (1.0 + 1e-5);
     if (std::isfinite(a) && a < 3e38) p.az_out = (float)a;
+    // inside: only for radars whose every in-range pair may be settled in binary32 (d2f_in > 0)
+    if (h.d2f_in > 0.f) {
+        const double inner = std::sqrt((double)h.d2f_in) - slack;
+        const double t = ((double)h.az_guard + 2.0 * slack) * (1.0 + 1e-5);
+        if (inner > 0.0 && std::isfinite(t) && t < 3e38) {
+            p.d2_in = (float)(inner * inner * (1.0 - 1e-5));
+            p.t_in = (float)t;
+            // along z a draw moves a row by at most 24.3 m
+            p.z_in = (float)(((philox ? 24.3 * std::max(index, 0) : 0.0) + 4e-6 * (centre + reach) + 1.0) * (1.0 + 1e-5));
+        }
+    }
 }
 
 }  // namespace
@@ -1315,6 +1522,10 @@ struct zrk_ctx {
     int order_nb = 0;                  // ... for this many row blocks
     bool order_ready = false;
     bool order_enabled = true;
+    uint32_t diag = 0;                 // ZRK_DIAG: bit 0 no "certainly visible" shortcut, bit 1 no box records
+    const void *box_ws = nullptr;      // workspace whose box records belong to ...
+    const void *box_key = nullptr;     // ... this table (its start_pos column) ...
+    int64_t box_n = 0;                 // ... up to this many rows
     std::string err;
     const void *ring_key = nullptr;    // mask buffers zrk_run_ticks has been alternating between ...
     int64_t ring_age = 0;              // ... for this many consecutive ticks (>= 1: the next one starts cleared)
@@ -1341,6 +1552,7 @@ struct Workspace {
     int32_t *ctl;                  // single-launch compaction: ticket, done, error
     unsigned long long *agg;       // ... and its per-workgroup records
     int32_t *cost, *order;         // per sweep row block: cost of this tick, dispatch order of the next
+    WaveBox *boxes;                // per sweep wave: box record
     int32_t *counts, *offs, *totals;
 };
 
@@ -1348,17 +1560,25 @@ constexpr int64_t kFusedBytes = kFusedCtlInts * (int64_t)sizeof(int32_t) +
                                 (int64_t)kFusedMaxBlocks * kAggStride * (int64_t)sizeof(unsigned long long);
 
 inline int64_t order_ints(int64_t n) { return ((n + ZRK_BLOCK - 1) / ZRK_BLOCK + 64) & ~(int64_t)63; }
+inline int64_t box_ints(int64_t n) { return ((((n + 63) / 64 + 4) * (int64_t)(sizeof(WaveBox) / 4)) + 63) & ~(int64_t)63; }
 
-Workspace carve(void *ws, int nb, int64_t n)
+// Layout: [single-launch control words and records][totals][three-launch counts, offsets: sized for n_max]
+// [cost][order][box records].  The first three parts start at fixed offsets and are all a stand-alone compaction
+// touches (its n may be anything up to n_max); the loop's arrays behind them are found from the table's capacity,
+// which zrk_run_ticks knows and which must be the n_max the workspace was sized for.
+inline int64_t comp_blocks(int64_t n_max) { return (n_max + kCompBlock - 1) / kCompBlock + 1; }
+
+Workspace carve(void *ws, int nb, int64_t n_max)
 {
     Workspace w;
     w.ctl = (int32_t *)ws;
     w.agg = (unsigned long long *)(w.ctl + kFusedCtlInts);
-    w.cost = (int32_t *)((char *)ws + kFusedBytes);
-    w.order = w.cost + order_ints(n);
-    w.totals = w.order + order_ints(n);                 // [ZRK_MAX_RADARS + 1] (+ pad to 64 ints)
+    w.totals = (int32_t *)((char *)ws + kFusedBytes);   // [ZRK_MAX_RADARS + 1] (+ pad to 64 ints)
     w.counts = w.totals + 64;
     w.offs = w.counts + (int64_t)(ZRK_MAX_RADARS + 1) * nb;
+    w.cost = w.counts + ((2 * (int64_t)(ZRK_MAX_RADARS + 1) * comp_blocks(n_max) + 63) & ~(int64_t)63);
+    w.order = w.cost + order_ints(n_max);
+    w.boxes = (WaveBox *)(w.order + order_ints(n_max));
     return w;
 }
 
@@ -1385,6 +1605,7 @@ ZRK_API int zrk_ctx_create(int device, zrk_ctx **out)
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = cus;
     if (const char *v = std::getenv("ZRK_SWEEP_ORDER")) c->order_enabled = std::atoi(v) != 0;
+    if (const char *v = std::getenv("ZRK_DIAG")) c->diag = (uint32_t)std::strtoul(v, nullptr, 0);
     c->fused_max_blocks = kFusedMaxBlocks;
     if (const char *v = std::getenv("ZRK_COMPACT_FUSED_MAX_BLOCKS")) {     // 0 = always the three-launch path
         const long k = std::strtol(v, nullptr, 10);
@@ -1401,8 +1622,8 @@ ZRK_API const char *zrk_last_error(zrk_ctx *ctx) { return ctx ? ctx->err.c_str()
 ZRK_API int64_t zrk_workspace_bytes(int64_t n_max)
 {
     if (n_max < 0) return ZRK_E_INVALID;
-    const int64_t nb = (n_max + kCompBlock - 1) / kCompBlock + 1;
-    return kFusedBytes + (2 * order_ints(n_max) + 64 + 2 * (int64_t)(ZRK_MAX_RADARS + 1) * nb) * (int64_t)sizeof(int32_t);
+    return kFusedBytes + (2 * order_ints(n_max) + box_ints(n_max) + 64 + 64 + 2 * (int64_t)(ZRK_MAX_RADARS + 1) * comp_blocks(n_max)) *
+                             (int64_t)sizeof(int32_t);
 }
 
 namespace {
@@ -1431,7 +1652,8 @@ MissileArgs missile_args(const zrk_entities *e, int cur, const zrk_missiles *mis
 
 int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_t time_ms, const zrk_radar *radars,
                  int R, uint32_t flags, uint64_t seed, uint64_t tick, int64_t gid0, void *workspace, void *stream,
-                 const MissileArgs &M, uint32_t *vis = nullptr, int32_t *cost = nullptr, const int32_t *order = nullptr)
+                 const MissileArgs &M, uint32_t *vis = nullptr, int32_t *cost = nullptr, const int32_t *order = nullptr,
+                 WaveBox *boxes = nullptr)
 {
     if (!ctx || !e || !workspace || (R > 0 && !radars)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
     if (R < 0 || R > ZRK_MAX_RADARS)
@@ -1447,6 +1669,9 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
     P.seed = seed; P.tick = tick; P.gid0 = gid0;
     P.R = R; P.nb = nblocks(n, ZRK_BLOCK); P.flags = flags;
     P.mb = nblocks(M.m, ZRK_BLOCK); P._pad0 = 0;
+    P.boxes = boxes;
+    if (ctx->diag & 1u) P.flags |= kNoInside;
+    if (ctx->diag & 2u) P.flags |= kNoBoxCache;
     std::memset(&P.rb, 0, sizeof(P.rb));
     for (int r = 0; r < ZRK_MAX_RADARS; ++r) {
         RadarPre pre;
@@ -1456,16 +1681,16 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
             RadarHot hot;
             derive_radar(radars[r], (flags & ZRK_F_EXACT_ONLY) != 0, hot, P.rb.cold[r]);
             std::memcpy(P.rb.hotw[r], &hot, sizeof(hot));
-            derive_pre(radars[r], hot, (flags & ZRK_F_PHILOX) != 0, R, pre);
+            derive_pre(radars[r], hot, (flags & ZRK_F_PHILOX) != 0, r, pre);
         }
         std::memcpy(P.rb.prew[r], &pre, sizeof(pre));
     }
     const dim3 grid(P.nb + P.mb);                           // leading workgroups step the missiles
     using Kernel = void (*)(const SweepParams, const MissileArgs);
     static const Kernel variants[8] = {
-        k_tick_sweep<false, 1, false, false>, k_tick_sweep<true, 1, false, false>, k_tick_sweep<false, 1, true, false>,
-        k_tick_sweep<true, 1, true, false>,   k_tick_sweep<false, 1, false, true>, k_tick_sweep<true, 1, false, true>,
-        k_tick_sweep<false, 1, true, true>,   k_tick_sweep<true, 1, true, true>};
+        k_tick_sweep<false, false, false>, k_tick_sweep<true, false, false>, k_tick_sweep<false, true, false>,
+        k_tick_sweep<true, true, false>,   k_tick_sweep<false, false, true>, k_tick_sweep<true, false, true>,
+        k_tick_sweep<false, true, true>,   k_tick_sweep<true, true, true>};
     const int which = ((flags & ZRK_F_PHILOX) ? 1 : 0) | ((flags & ZRK_F_ADVANCE) ? 2 : 0) | (P.lidx ? 4 : 0);
     hipLaunchKernelGGL(variants[which], grid, dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
     return check_launch(ctx, "k_tick_sweep");
@@ -1765,7 +1990,16 @@ ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missile
         // (a grid that is resident all at once has no "last": eight workgroups of four waves fit a compute unit)
         const bool ordering = ctx->order_enabled && (det_idx || packed) && R > 0 && nbs > 8 * ctx->cus &&
                               compacts_in_one_launch(ctx, st->n);
-        Workspace w = carve(workspace, 0, st->n);
+        Workspace w = carve(workspace, 0, e->capacity);
+        // box records: none for rows the loop has not swept yet on this table (new table, new workspace, rows appended)
+        if (ctx->box_ws != workspace || ctx->box_key != (const void *)e->start_pos || st->n < ctx->box_n) {
+            ctx->box_ws = workspace; ctx->box_key = e->start_pos; ctx->box_n = 0;
+        }
+        if (st->n != ctx->box_n) {
+            const int64_t w0 = ctx->box_n / 64, w1 = (st->n + 63) / 64;
+            if (hipMemsetAsync(w.boxes + w0, 0, sizeof(WaveBox) * (size_t)(w1 - w0), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset boxes"); break; }
+            ctx->box_n = st->n;
+        }
         if (ordering && (ctx->order_ws != workspace || ctx->order_nb != nbs)) {
             if (hipMemsetAsync(w.cost, 0, sizeof(int32_t) * (size_t)nbs, s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset cost"); break; }
             ctx->order_ws = workspace; ctx->order_nb = nbs; ctx->order_ready = false;
@@ -1773,7 +2007,7 @@ ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missile
         if (!ordering) ctx->order_ready = false;
         rc = launch_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse, st->seed,
                           st->tick, st->gid0, workspace, stream, M, vis_now, ordering ? w.cost : nullptr,
-                          (ordering && ctx->order_ready) ? w.order : nullptr);
+                          (ordering && ctx->order_ready) ? w.order : nullptr, w.boxes);
         if (prof) (void)hipEventRecord(ev[2 * (k / stride) + 1], s);
         if (rc == 0 && (det_idx || packed))
             rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, packed,
