@@ -20,7 +20,7 @@ R = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 ids, sp, vel, t0 = S.synthetic_targets(n, 1237)
 eng = HotPathEngine(device="cuda:0", dt_ms=10, seed=1, noise="philox")
 eng.load(ids, sp, vel, t0, S.synthetic_radars(R)).enable_lists()
-eng.run(20)
+eng.run(int(sys.argv[3]) if len(sys.argv) > 3 else 20)
 torch.cuda.synchronize()
 nw = (n + 63) // 64
 buf = torch.zeros(nw * 8, dtype=torch.int64, device="cuda:0")
@@ -63,3 +63,12 @@ for tt in range(0, int(end.max()) + 2):
     inloop = int(((loaded <= tt) & (swept > tt)).sum())
     fin = int(((end >= tt) & (end < tt + 1)).sum())
     print(f"{tt:5d} {res:12d} {arr:18d} {inloop:24d} {fin:18d}")
+# the slowest waves: who are they?
+st = eng.store
+slow = np.argsort(swept - loaded)[-8:]
+hp = st.host_pos("cur")
+for w in slow:
+    rows = np.arange(w * 64, min(w * 64 + 64, st.n_uploaded))
+    p = hp[rows]
+    print(f"slow wave {w}: loop {float((swept - loaded)[w]):6.2f} us start {float(start[w]):5.2f} deep {int(deep[w])} det lanes {int(det[w])} probe7 {int(t[w,7]) & 0xFF} in {(int(t[w,7])>>8)&0xFF} pl {(int(t[w,7])>>16)&0xFF} "
+          f"box x [{p[:,0].min():9.1f},{p[:,0].max():9.1f}] y [{p[:,1].min():9.1f},{p[:,1].max():9.1f}] kinds {np.bincount(st.h_kind[rows], minlength=2).tolist()}")

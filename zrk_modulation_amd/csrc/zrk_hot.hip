@@ -87,6 +87,10 @@ struct RadarCold {
     double d2_max;              // largest d2 with sqrt(d2) <= max_distance  (== `dist > max` gate)
     double az_lo, az_hi;        // current_azimuth, current_azimuth + azimuth_range
     double el_lo, el_hi;
+    // the sector's faces once more in binary64 (same construction as RadarHot's): the middle tier of the decision
+    double elx, ely, ehx, ehy;  // unit vectors of the (clamped) azimuth edges, times az_sgn
+    double s_lo_up, s_hi_up, s_lo_dn, s_hi_dn;
+    double az_sgn;              // 0: no middle tier for this radar (degenerate sector: always the reference formula)
 };
 
 struct RadarBlock {                                 // lives in the kernel-argument segment (by value)
@@ -115,6 +119,7 @@ struct SweepParams {
     uint32_t flags;
     RadarBlock rb;
 };
+constexpr size_t kColdOffset = offsetof(SweepParams, rb.cold);   // where the cold records sit in the kernel-argument segment
 
 // The missile phase rides along in other kernels' grids (its own launches would cost more in kernel
 // boundaries than in work): the per-row step as extra workgroups of the sweep, the ordered event list
@@ -164,12 +169,40 @@ __device__ __forceinline__ double floormod_small(double a, double b)
     return m;
 }
 
-// modules/Radar.py:56-70 in binary64: the decision every guard-band pair falls back to.
-__device__ __noinline__ bool visible_exact(const RadarCold c, double dx, double dy, double dz)
+// modules/Radar.py:56-70 in binary64: the decision every guard-band pair falls back to.  Two tiers.  The reference
+// compares angles that numpy's arctan2 / arcsin return, which costs a few thousand cycles per call here -- and a
+// row that lies within the binary32 guard band of a face shared by several radars (sixteen radars in a line with
+// parallel sectors share the line itself) pays it once per radar, with its whole wave waiting.  So first the
+// same signed distance to the nearest face as the fast path, in binary64: edge vectors and cone sines rounded from
+// the exact bounds (relative error ~1e-16), sqrt correctly rounded, everything else a handful of roundings --
+// whatever is farther than 1e-11 of the distance from every face is on the side it appears to be on, also for the
+// angles (their own rounding is ~1e-15 relative).  Only rows inside that band (nanometres) take the angle formula.
+__device__ __noinline__ bool visible_exact(uint64_t cold_record, double dx, double dy, double dz)
 {
+    // radar r's cold record in the kernel-argument segment, by address (a by-value copy of the record would travel
+    // through scratch memory); the address is wave-uniform, so the fourteen words come in through scalar loads
+    typedef const double __attribute__((address_space(4))) *ConstDoubles;
+    const uint64_t addr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(cold_record >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cold_record);
+    const ConstDoubles q = (ConstDoubles)addr;
+    static_assert(sizeof(RadarCold) == 14 * sizeof(double), "RadarCold is fourteen doubles");
+    RadarCold c;
+    c.d2_max = q[0]; c.az_lo = q[1]; c.az_hi = q[2]; c.el_lo = q[3]; c.el_hi = q[4];
+    c.elx = q[5]; c.ely = q[6]; c.ehx = q[7]; c.ehy = q[8];
+    c.s_lo_up = q[9]; c.s_hi_up = q[10]; c.s_lo_dn = q[11]; c.s_hi_dn = q[12]; c.az_sgn = q[13];
     const double d2 = dot3(dx, dy, dz, dx, dy, dz);
     if (d2 > c.d2_max) return false;                           // == `distance > max_distance`
     const double dist = sqrt(d2);
+    if (c.az_sgn != 0.0) {
+        const double cl = c.elx * dy - c.ely * dx, ch = dx * c.ehy - dy * c.ehx;
+        const double m_az = c.az_sgn * fmin(cl, ch);                  // az_sgn is +-1 here
+        const bool up = dz >= 0.0;
+        const double a = dz - (up ? c.s_lo_up : c.s_lo_dn) * dist, b = (up ? c.s_hi_up : c.s_hi_dn) * dist - dz;
+        const double t = fmin(fmin(m_az, a), b);
+        const double g = 1e-11 * dist;
+        if (t > g) return true;
+        if (t < -g) return false;
+    }
     const double az = floormod_small(atan2(dy, dx) * kRad2Deg, 360.0);
     const double el = floormod_small(asin(dz / dist) * kRad2Deg, 180.0);
     return (c.az_lo <= az) && (az <= c.az_hi) && (c.el_lo <= el) && (el <= c.el_hi);
@@ -330,19 +363,20 @@ __device__ __forceinline__ void stage_pre_table(PreTable &T, uint4 &piece)
     __syncthreads();
 }
 
-// Box cache.  What a wave needs to know before its rows arrive is where they can be, not where they are: every
-// row moves along a straight line (modules/AirObject.py:23-25), so the bounding box of the wave's live rows taken
-// at some earlier time, grown by the wave's largest speed per axis times the time since, still holds them.  A
-// wave with such a record (48 bytes in the workspace, fetched with scalar loads) runs the whole wave-level
-// classification below -- which radars can see any of its rows, which certainly see all of them -- while its row
-// loads are in flight, and a wave no radar can reach (four in five at C3) has nothing left to do once they land
-// but the three roundings of the advance and the stores.  A wave without a usable record (first tick, rows appended
-// since, record older than kBoxMaxAge seconds of growth) takes the box of the positions it has just computed
-// (DPP reductions), classifies late, and leaves a fresh record behind.  Conservative by construction: the
+// Box cache.  What a workgroup needs to know before its rows arrive is where they can be, not where they are:
+// every row moves along a straight line (modules/AirObject.py:23-25), so the bounding box of the row block's live
+// rows taken at some earlier time, grown by the block's largest speed per axis times the time since, still holds
+// them.  A workgroup whose block has such a record (48 bytes in the workspace, fetched with scalar loads) lets
+// its first wave run the whole box-level classification below -- which radars can see any of the block's rows, which
+// certainly see all of them -- while the row loads are in flight and hands the three masks to the others through
+// LDS; a block no radar can reach (four in five at C3) has nothing left to do once its rows land but the three
+// roundings of the advance and the stores.  A block without a usable record (first tick, rows appended since,
+// record grown by more than kBoxMaxGrow) has each wave take the box of the positions it has just computed (DPP
+// reductions) and classify late, and leaves a fresh record behind.  Conservative by construction: the
 // classification only ever uses "no point of the box can be in the sector" / "every point of the box is".
 struct WaveBox {
     float lo[3], hi[3];          // box of the live rows' positions at time t_ref (before any measurement noise)
-    float vmax[3];               // largest |velocity component| over the wave's rows [m/s]
+    float vmax[3];               // largest |velocity component| over the block's rows [m/s]
     uint32_t state;              // 0: none, 1: valid, 2: valid but some live row is not finite (never culled), 3: no live row
     double t_ref;
 };
@@ -505,7 +539,7 @@ __device__ __forceinline__ void sweep_rows(const SweepParams &P, const Cull &c, 
         const float gd = kGuard * dist;
         bool vis = in_range & (t > gd);
         const bool amb = in_range & ((fabsf(t) <= gd) | !(d2f < d2f_in));
-        if (amb) vis = visible_exact(P.rb.cold[r], dx, dy, dz);
+        if (amb) vis = visible_exact((uint64_t)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + kColdOffset + (size_t)r * sizeof(RadarCold)), dx, dy, dz);
         if (PHILOX && !seeded && __ballot(vis)) {
             ns = noise_init(P.seed, P.tick, (uint64_t)(P.gid0 + li));
             seeded = true;
@@ -576,8 +610,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     u32x4 b0 = {0u, 0u, 0u, 0u}, b1 = {0u, 0u, 0u, 0u}, bv = {0u, 0u, 0u, 0u};     // lo[3] hi[0] | hi[1..2] vmax[0..1] | vmax[2] state t_ref
     const bool cached = ADVANCE && P.boxes != nullptr;
     if (cached) {
-        const int64_t wave_s = (int64_t)blk * (ZRK_BLOCK / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);   // the same, in SGPRs
-        const WaveBox *pb = P.boxes + wave_s;
+        const WaveBox *pb = P.boxes + blk;
         asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(b0), "=&s"(b1), "=&s"(bv) : "s"(pb) : "memory");
     }
@@ -588,6 +621,10 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     c.cand = 0u; c.inside = 0u; c.plane = 0u; c.pz_lo = 0u; c.pz_hi = 0u;
     bool have = false;                                   // classified from the record, before the rows are here
     const uint32_t bstate = bv[1];
+    __shared__ struct { uint32_t cand, inside, plane, pad; uint32_t pz_lo[ZRK_MAX_RADARS], pz_hi[ZRK_MAX_RADARS]; } s_cull;
+    __shared__ float s_wbox[ZRK_BLOCK / 64][12];
+    const int wv = tid >> 6, lane = tid & 63;
+    // (every wave of the workgroup reads the same record, so all of them take the same way through here)
     if (cached && bstate != 0u && !(P.flags & kNoBoxCache)) {
         const double t_ref = __builtin_bit_cast(double, ((uint64_t)bv[3] << 32) | bv[2]);
         const float age = fabsf((float)(P.t - t_ref)) * 1.000001f + 1e-6f;      // seconds, rounded up
@@ -597,11 +634,18 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
         if (bstate == kBoxEmpty) {                      // nobody alive at t_ref, nobody is revived: nothing to sweep
             have = true;
         } else if (bstate == kBoxOk && grow <= kBoxMaxGrow) {
-            // (the 1e-3 m covers the rounding of the grown bounds; derive_pre's slack has a metre for the rest)
-            c = cull_box(s_pre, P.R, shortcuts,
-                         __builtin_bit_cast(float, bw[0]) - g0 - 1e-3f, __builtin_bit_cast(float, bw[1]) - g1 - 1e-3f,
-                         __builtin_bit_cast(float, bw[2]) - g2 - 1e-3f, __builtin_bit_cast(float, bw[3]) + g0 + 1e-3f,
-                         __builtin_bit_cast(float, bw[4]) + g1 + 1e-3f, __builtin_bit_cast(float, bw[5]) + g2 + 1e-3f);
+            if (wv == 0) {
+                // (the 1e-3 m covers the rounding of the grown bounds; derive_pre's slack has a metre for the rest)
+                const Cull c0 = cull_box(s_pre, P.R, shortcuts,
+                                         __builtin_bit_cast(float, bw[0]) - g0 - 1e-3f, __builtin_bit_cast(float, bw[1]) - g1 - 1e-3f,
+                                         __builtin_bit_cast(float, bw[2]) - g2 - 1e-3f, __builtin_bit_cast(float, bw[3]) + g0 + 1e-3f,
+                                         __builtin_bit_cast(float, bw[4]) + g1 + 1e-3f, __builtin_bit_cast(float, bw[5]) + g2 + 1e-3f);
+                if (lane == 0) { s_cull.cand = c0.cand; s_cull.inside = c0.inside; s_cull.plane = c0.plane; }
+                if (lane < ZRK_MAX_RADARS) { s_cull.pz_lo[lane] = c0.pz_lo; s_cull.pz_hi[lane] = c0.pz_hi; }
+            }
+            __syncthreads();
+            c.cand = s_cull.cand; c.inside = s_cull.inside; c.plane = s_cull.plane;
+            c.pz_lo = s_cull.pz_lo[lane & (ZRK_MAX_RADARS - 1)]; c.pz_hi = s_cull.pz_hi[lane & (ZRK_MAX_RADARS - 1)];
             have = true;
         }
     }
@@ -631,8 +675,9 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
         else if (any_wild) { c.cand = all; c.inside = 0u; c.plane = 0u; }   // min / max drop NaNs: never cull such a wave
         else c = cull_box(s_pre, P.R, shortcuts, blx, bly, blz, bhx, bhy, bhz);
         if (cached) {
-            // leave a record behind: lanes 0..11 store one word each.  The speeds are taken over every row of the
-            // wave, live or not (rows past the end read row 0's: harmless, it only widens), once per record's life.
+            // leave a record behind: every wave puts its box to LDS, the first wave joins them and lanes 0..11 store
+            // one word each.  The speeds are taken over every row of the block, live or not (rows past the end read
+            // row 0's: harmless, it only widens), once per record's life.
             float m0 = __builtin_bit_cast(float, bw[6]), m1 = __builtin_bit_cast(float, bw[7]), m2 = __builtin_bit_cast(float, bv[0]);
             if (bstate == 0u) {
                 float n0 = fabsf((float)vx) * 1.000001f, n1 = fabsf((float)vy) * 1.000001f, n2 = fabsf((float)vz) * 1.000001f;
@@ -643,22 +688,32 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
                 const bool vfin = (n0 < kBig) & (n1 < kBig) & (n2 < kBig);      // NaN / inf speeds: the record never holds
                 m0 = vfin ? n0 : inf; m1 = vfin ? n1 : inf; m2 = vfin ? n2 : inf;
             }
-            const uint32_t st = !any_live ? kBoxEmpty : (any_wild ? kBoxWild : kBoxOk);
-            const uint64_t tb = __builtin_bit_cast(uint64_t, P.t);
-            const int lane = tid & 63;
-            uint32_t word = __builtin_bit_cast(uint32_t, blx);
-            word = lane == 1 ? __builtin_bit_cast(uint32_t, bly) : word;
-            word = lane == 2 ? __builtin_bit_cast(uint32_t, blz) : word;
-            word = lane == 3 ? __builtin_bit_cast(uint32_t, bhx) : word;
-            word = lane == 4 ? __builtin_bit_cast(uint32_t, bhy) : word;
-            word = lane == 5 ? __builtin_bit_cast(uint32_t, bhz) : word;
-            word = lane == 6 ? __builtin_bit_cast(uint32_t, m0) : word;
-            word = lane == 7 ? __builtin_bit_cast(uint32_t, m1) : word;
-            word = lane == 8 ? __builtin_bit_cast(uint32_t, m2) : word;
-            word = lane == 9 ? st : word;
-            word = lane == 10 ? (uint32_t)tb : word;
-            word = lane == 11 ? (uint32_t)(tb >> 32) : word;
-            if (lane < 12) ((uint32_t *)(P.boxes + wave))[lane] = word;
+            if (lane == 0) {
+                float *wb = s_wbox[wv];
+                wb[0] = blx; wb[1] = bly; wb[2] = blz; wb[3] = bhx; wb[4] = bhy; wb[5] = bhz;
+                wb[6] = m0; wb[7] = m1; wb[8] = m2;
+                wb[9] = any_wild ? 1.f : 0.f; wb[10] = any_live ? 1.f : 0.f;
+            }
+            __syncthreads();
+            if (wv == 0 && lane < 12) {
+                const bool is_lo = lane < 3;
+                float v = s_wbox[0][lane < 11 ? lane : 0];
+#pragma unroll
+                for (int k = 1; k < ZRK_BLOCK / 64; ++k) {
+                    const float u = s_wbox[k][lane < 11 ? lane : 0];
+                    v = is_lo ? fminf(v, u) : fmaxf(v, u);
+                }
+                float wild_any = 0.f, live_any = 0.f;
+#pragma unroll
+                for (int k = 0; k < ZRK_BLOCK / 64; ++k) { wild_any = fmaxf(wild_any, s_wbox[k][9]); live_any = fmaxf(live_any, s_wbox[k][10]); }
+                const uint32_t st = live_any == 0.f ? kBoxEmpty : (wild_any != 0.f ? kBoxWild : kBoxOk);
+                const uint64_t tb = __builtin_bit_cast(uint64_t, P.t);
+                uint32_t word = __builtin_bit_cast(uint32_t, v);
+                word = lane == 9 ? st : word;
+                word = lane == 10 ? (uint32_t)tb : word;
+                word = lane == 11 ? (uint32_t)(tb >> 32) : word;
+                ((uint32_t *)(P.boxes + blk))[lane] = word;
+            }
         }
     }
     const int walked = __builtin_popcount(c.cand);     // wave-uniform: what this wave costs, for next tick's order
@@ -1441,6 +1496,8 @@ void derive_radar(const zrk_radar &hr, bool exact_only, RadarHot &h, RadarCold &
     h.d2f_in = plain_range ? (float)(c.d2_max * (1.0 - 1e-5)) : -1.f;
     h.d2f_out = plain_range ? (float)(c.d2_max * (1.0 + 1e-5)) : INFINITY;
     h.s_lo_up = h.s_lo_dn = 2.f; h.s_hi_up = h.s_hi_dn = -2.f;
+    c.s_lo_up = c.s_lo_dn = 2.0; c.s_hi_up = c.s_hi_dn = -2.0;
+    c.elx = c.ely = c.ehx = c.ehy = 0.0; c.az_sgn = 0.0;
     h.az_guard = plain_range ? (float)(kGuard * std::sqrt(c.d2_max) * 1.001) : INFINITY;
     h.az_sgn = 1.f;
     const bool finite = std::isfinite(c.az_lo) && std::isfinite(c.az_hi) && std::isfinite(c.el_lo) && std::isfinite(c.el_hi);
@@ -1454,16 +1511,23 @@ void derive_radar(const zrk_radar &hr, bool exact_only, RadarHot &h, RadarCold &
     h.az_sgn = (hi - lo <= 180.0) ? 1.f : -1.f;
     h.elx = h.az_sgn * (float)std::cos(lo * deg); h.ely = h.az_sgn * (float)std::sin(lo * deg);
     h.ehx = h.az_sgn * (float)std::cos(hi * deg); h.ehy = h.az_sgn * (float)std::sin(hi * deg);
+    c.az_sgn = exact_only ? 0.0 : (double)h.az_sgn;        // ZRK_F_EXACT_ONLY: the reference's formula and nothing else
+    c.elx = (double)h.az_sgn * std::cos(lo * deg); c.ely = (double)h.az_sgn * std::sin(lo * deg);
+    c.ehx = (double)h.az_sgn * std::cos(hi * deg); c.ehy = (double)h.az_sgn * std::sin(hi * deg);
     // elevation: dz >= 0 -> el = theta in [0,90];  dz < 0 -> el = 180 + theta in [90,180]
     const double lo_u = std::fmax(c.el_lo, 0.0), hi_u = std::fmin(c.el_hi, 90.0);
     if (lo_u <= hi_u) {
         h.s_lo_up = (c.el_lo <= 0.0) ? -2.f : (float)std::sin(lo_u * deg);
         h.s_hi_up = (c.el_hi >= 90.0) ? 2.f : (float)std::sin(hi_u * deg);
+        c.s_lo_up = (c.el_lo <= 0.0) ? -2.0 : std::sin(lo_u * deg);
+        c.s_hi_up = (c.el_hi >= 90.0) ? 2.0 : std::sin(hi_u * deg);
     }
     const double lo_d = std::fmax(c.el_lo - 180.0, -90.0), hi_d = std::fmin(c.el_hi - 180.0, 0.0);
     if (lo_d <= hi_d) {
         h.s_lo_dn = (c.el_lo - 180.0 <= -90.0) ? -2.f : (float)std::sin(lo_d * deg);
         h.s_hi_dn = (c.el_hi >= 180.0) ? 2.f : (float)std::sin(hi_d * deg);
+        c.s_lo_dn = (c.el_lo - 180.0 <= -90.0) ? -2.0 : std::sin(lo_d * deg);
+        c.s_hi_dn = (c.el_hi >= 180.0) ? 2.0 : std::sin(hi_d * deg);
     }
 }
 
@@ -1560,7 +1624,7 @@ constexpr int64_t kFusedBytes = kFusedCtlInts * (int64_t)sizeof(int32_t) +
                                 (int64_t)kFusedMaxBlocks * kAggStride * (int64_t)sizeof(unsigned long long);
 
 inline int64_t order_ints(int64_t n) { return ((n + ZRK_BLOCK - 1) / ZRK_BLOCK + 64) & ~(int64_t)63; }
-inline int64_t box_ints(int64_t n) { return ((((n + 63) / 64 + 4) * (int64_t)(sizeof(WaveBox) / 4)) + 63) & ~(int64_t)63; }
+inline int64_t box_ints(int64_t n) { return ((((n + ZRK_BLOCK - 1) / ZRK_BLOCK + 4) * (int64_t)(sizeof(WaveBox) / 4)) + 63) & ~(int64_t)63; }
 
 // Layout: [single-launch control words and records][totals][three-launch counts, offsets: sized for n_max]
 // [cost][order][box records].  The first three parts start at fixed offsets and are all a stand-alone compaction
@@ -1996,7 +2060,7 @@ ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missile
             ctx->box_ws = workspace; ctx->box_key = e->start_pos; ctx->box_n = 0;
         }
         if (st->n != ctx->box_n) {
-            const int64_t w0 = ctx->box_n / 64, w1 = (st->n + 63) / 64;
+            const int64_t w0 = ctx->box_n / ZRK_BLOCK, w1 = (st->n + ZRK_BLOCK - 1) / ZRK_BLOCK;
             if (hipMemsetAsync(w.boxes + w0, 0, sizeof(WaveBox) * (size_t)(w1 - w0), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset boxes"); break; }
             ctx->box_n = st->n;
         }
