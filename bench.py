@@ -1,85 +1,81 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: entity-timesteps/sec of the L1 tick loop on N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3|C2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3|C2|C4|C5|tiny|tiny4|tiny5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step is one simulation tick over one batch of synthetic input: apply last
-tick's detonations, step every in-flight missile, advance every live air object, sweep every radar
-over them with measurement noise (Philox mode), compact the detection lists, advance the scan.
-Inputs are resident in HBM when the timed region starts.  Default workload: BASELINE.json configs[2]
-(1e6 targets, 16 radars, 1e4 missiles per GPU), the configuration north_star quotes the HBM-roofline
-target on; `--workload C2` runs configs[1].  With N > 1 every rank owns a contiguous shard of the
-population (weak scaling: the per-GPU shard is the single-GPU workload) and each tick ends with an
-RCCL all-gather of the packed detection list.
+A step is one simulation tick over one batch of synthetic input: apply last tick's
+detonations, step every in-flight missile, advance every live air object, sweep every radar over them with
+measurement noise (Philox mode), compact the detection lists, advance the scan.  Inputs are resident in HBM
+when the timed region starts.
 
-Prints ONE JSON line (rank 0).  `roofline` is the fused advance+sweep kernel: algorithmic bytes
-per launch (85 B per live entity, 1 B per tombstone) over its average duration, measured with HIP
-events on the launch stream inside the timed region.  `cpu_baseline` is the oracle (C restatement of
-the reference, oracle/) timed on this host on a bounded number of ticks of the same scene.
+Workloads (BASELINE.json `configs`):
+  C3 (default)  configs[2]: 1e6 AirObjects, 16 radars, 1e4 missiles in flight per GPU -- the configuration
+                north_star quotes the HBM-roofline target on.  With N > 1 every rank holds such a shard (weak scaling).
+  C2            configs[1]: 1e5 / 4 / 1e3 (launch-bound; weak scaling).
+  C4            configs[3]: ONE seeded population of 1e7, rank g owns [g*1e7/N, (g+1)*1e7/N) (strong scaling).
+  C5            configs[4]: Monte-Carlo ensemble, 128 independent scenarios x 1e4 targets per GPU in one batched table
+                (no exchange; weak scaling).
+  tiny, tiny4, tiny5: the same mechanics at test size.
+With N > 1 (C2 / C3 / C4) each tick ends with an RCCL all-gather of the rank's compacted detection list (bitmap wire
+format) and its detonation events, issued from the C side (zrk_run_ticks_x) on RCCL's own stream so that it
+overlaps the next tick's sweep.  ZRK_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs
+than ranks (the exchange then goes through torch.distributed from Python, tick by tick).
+
+`--gpus N` without a torch.distributed environment starts the N ranks itself (children of this process, spawned
+before anything here touches the GPU) and relays rank 0's line; under torch.distributed.run it must equal WORLD_SIZE.
+
+Prints ONE JSON line (rank 0).  `roofline` is the fused advance+sweep kernel: algorithmic bytes per launch (85 B per
+live entity, 1 B per tombstone) over its average duration, measured with HIP events on the launch stream inside the
+timed region (the pair also brackets the dispatch gap in front of the kernel, ~3 us more than rocprofv3 reports for
+the kernel alone; the rocprofv3 figure of the same command is kept under profiles/ and echoed as
+`profiled_kernel_us_recorded`).  `traffic_recorded` is the PMC figure of the committed counter passes -- counters
+cannot be read from inside this process.  `cpu_baseline` is the oracle (C restatement of the reference, oracle/) timed
+on this host on a bounded number of ticks of the same scene.  Before the warm-up steps the device runs ~100 ms of an
+unrelated self-test kernel so that a 20-step run is not measured while the clocks are still ramping
+(`setup.clock_spinup_ms`; none of it counts as a step).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
-
-import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PROF_STRIDE = 8                # sweep kernel timed with HIP events every 8th tick (one call covers all ticks) ...
-PROF_STRIDE_RANKS = 64         # ... every 64th when ticks are driven one call at a time: reading the events drains the stream
+SPINUP_MS = 100.0
+PROFILE_TAG = "r02"            # profiles/<tag>_* hold the recorded figures echoed in the line
 
 
-def build_engine(workload, rank, world, device, seed_off=0):
-    from zrk_modulation_amd.engine import HotPathEngine
-    from zrk_modulation_amd import scenario as S
-    n, R, m = S.WORKLOADS[workload]
-    ids, sp, vel, t0 = S.synthetic_targets(n, S.SEEDS[workload] + 1000 * rank + seed_off, first_id=1000 + rank * n)
-    radars = S.synthetic_radars(R)
-    stride = n + m                                   # global index space: shard g starts at g * stride
-    eng = HotPathEngine(device=device, dt_ms=10, seed=S.SEEDS[workload], noise="philox", gid0=rank * stride)
-    eng.load(ids, sp, vel, t0, radars, missile_capacity=m, union_capacity=(n + m) if world > 1 else None,
-             union_format="bits")
-    # (the exchange buffers are re-sized to the observed detection count after warm-up, see main)
-    if world == 1:
-        eng.enable_lists()
-    launched = eng.launch_missiles(S.missile_targets(n, m))
-    return eng, dict(n=n, R=R, m=m, launched=launched, scene=(ids, sp, vel, t0, radars))
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5", "tiny", "tiny4", "tiny5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--selfcheck-launch", action="store_true",
+                    help="rank start-up and rendezvous only (gloo, no GPU): what tests/ use to cover --gpus N on a CPU box")
+    return ap.parse_args()
 
 
-def pmc_traffic(workload, world):
-    """HBM bytes per sweep launch from the committed PMC passes (profiles/r01_pmc_traffic.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate rocprofv3 --pmc runs of this workload, corrected as
-    MI355X_MICROARCH.md prescribes and calibrated on a pure-streaming launch).  Counters cannot be read
-    from inside this process, so the figure is the recorded one for the same workload, else null."""
-    try:
-        rec = json.load(open(ROOT / "profiles" / "r01_pmc_traffic.json"))
-        if rec["workload"] == workload and world == 1:
-            return rec["traffic_bytes"]
-    except Exception:
-        pass
-    return None
-
-
-def profiled_kernel_us(workload, world):
-    """Average duration of the sweep kernel in the committed rocprofv3 --kernel-trace --stats summary of this
-    command (profiles/r01_g_final_kernel_stats.csv), for cross-reference with the live HIP-event figure: the
-    event pair also brackets the dispatch latency on both sides of the kernel (about 3 us).  Recorded, not live."""
-    try:
-        if workload != "C3" or world != 1:
-            return None
-        import csv
-        for row in csv.DictReader(open(ROOT / "profiles" / "r01_g_final_kernel_stats.csv")):
-            if "k_tick_sweep" in row["Name"]:
-                return float(row["AverageNs"]) / 1e3
-    except Exception:
-        pass
-    return None
+def launch_ranks(args):
+    """Parent of an N > 1 run started as plain `python bench.py --gpus N`: N ranks through torch.distributed.run,
+    as children.  Nothing in this process has touched HIP (torch is not even imported here)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def usable_cores():
@@ -98,15 +94,86 @@ def usable_cores():
     return cores
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def recorded(name):
+    """A figure recorded under profiles/ for cross-reference (never measured by this run)."""
+    try:
+        return json.load(open(ROOT / "profiles" / f"{PROFILE_TAG}_recorded.json")).get(name)
+    except Exception:
+        return None
+
+
+def fill_missiles(eng, n_targets, m, S):
+    """Launch until m missiles are in flight (some of the synthetic lead-collision solves fail: the next
+    candidates are the failed targets' neighbours)."""
+    if m <= 0:
+        return 0
+    launched, shift = 0, 0
+    base = S.missile_targets(n_targets, m).astype("int64")
+    want = base
+    while launched < m and shift < 16 and len(want):
+        k = eng.launch_missiles(want % n_targets)
+        failed = want[eng.launch_results["rc"] != 0]
+        launched += k
+        shift += 1
+        want = (failed + shift)[: m - launched]
+    return launched
+
+
+def build_engine(workload, rank, world, device):
+    import numpy as np
+    from zrk_modulation_amd.engine import HotPathEngine
+    from zrk_modulation_amd import scenario as S
+    n_total, R, m_total = S.WORKLOADS[workload]
+    radars = S.synthetic_radars(R)
+    if workload in S.STRONG:
+        lo, hi = S.shard_bounds(n_total, world, rank)
+        ids, sp, vel, t0 = S.population_slice(S.SEEDS[workload], lo, hi)
+        n = hi - lo
+        m = (m_total * (rank + 1)) // world - (m_total * rank) // world
+        stride = (n_total + world - 1) // world + (m_total + world - 1) // world
+    else:
+        n, m = n_total, m_total
+        ids, sp, vel, t0 = S.synthetic_targets(n, S.SEEDS[workload] + 1000 * rank, first_id=1000 + rank * n)
+        stride = n + m
+    # global index space: shard g starts at g * stride (targets, then the missiles the rank launches)
+    eng = HotPathEngine(device=device, dt_ms=10, seed=S.SEEDS[workload], noise="philox", gid0=rank * stride)
+    eng.load(ids, sp, vel, t0, radars, missile_capacity=m)
+    if world == 1:
+        eng.enable_lists()
+    launched = fill_missiles(eng, n, m, S)
+    return eng, dict(n=n, R=R, m=m, launched=launched, stride=stride, scene=(ids, sp, vel, t0, radars),
+                     n_total=n_total if workload in S.STRONG else n * world)
+
+
+def build_ensemble(workload, rank, world, device):
+    from zrk_modulation_amd.ensemble import EnsembleEngine
+    from zrk_modulation_amd import scenario as S
+    scen, n, R, m = S.ENSEMBLES[workload]
+    eng = EnsembleEngine(device=device, dt_ms=10, noise="philox")
+    first = rank * scen
+    eng.load_synthetic(scen, n, R, m, seed=S.SEEDS[workload], first_scenario=first)
+    return eng, dict(n=scen * n, R=R, m=scen * m, launched=eng.launched, scenarios=scen, per_scenario=n,
+                     n_total=scen * n * world)
+
+
 def cpu_baseline(info, eng, budget_s=15.0):
     """Time the oracle's L1 tick on the same scene (test infrastructure used as the reported CPU
     baseline only).  Single-threaded advance/missile loop + OpenMP radar phase on all host cores."""
-    import ctypes as C
+    import numpy as np
     from oracle import oracle as O
     L = O.lib()
     ids, sp, vel, t0, radars = info["scene"]
     st = eng.store
-    n_t = info["n"]
     # rebuild the initial table (targets + the launched missiles) on the host
     n = st.n_uploaded
     cap = n
@@ -152,7 +219,8 @@ def cpu_baseline(info, eng, budget_s=15.0):
     t_all = time.perf_counter() - t_a
     live = int(alive.sum())
     t_b = time.perf_counter(); tick(1 + ticks, 1); t_1core = time.perf_counter() - t_b
-    return {"value": live * ticks / t_all, "unit": "entity-timesteps/s", "cores": cores, "kind": "port",
+    return {"value": live * ticks / t_all, "unit": "entity-timesteps/s", "cores": cores, "cpu_model": cpu_model(),
+            "kind": "port",
             "sample": f"same scene, {ticks} ticks, oracle/zrk_oracle.c: 1-thread AirEnv+missile loop, "
                       f"OpenMP radar phase on {cores} threads",
             "value_1core": live / t_1core,
@@ -161,18 +229,34 @@ def cpu_baseline(info, eng, budget_s=15.0):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "tiny"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
-    args = ap.parse_args()
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or under "
+                 f"torch.distributed.run with --nproc-per-node equal to --gpus")
+    if args.selfcheck_launch:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.tensor([int(os.environ.get("RANK", "0"))], dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(t)
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"selfcheck": True, "n_gpus": world, "rank_sum": int(t.item())}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")       # kernel arguments in device memory (PyTorch's default too)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+    import numpy as np
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # ZRK_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks
@@ -181,7 +265,6 @@ def main():
         local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -190,42 +273,70 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
-    eng, info = build_engine(args.workload, rank, world, device)
-    # N > 1: two packed buffers / exchanges in flight, so the all-gather of tick t (RCCL's own stream)
-    # overlaps the sweep of tick t+1; a buffer is reused only after its collective has been waited for
-    xchg = {"ex": [], "buf": [], "work": [None, None], "tick": 0}
+    from zrk_modulation_amd import scenario as S
+    ensemble = args.workload in S.ENSEMBLES
+    strong = args.workload in S.STRONG
+    if ensemble:
+        eng, info = build_ensemble(args.workload, rank, world, device)
+    else:
+        eng, info = build_engine(args.workload, rank, world, device)
+    exchanging = world > 1 and not ensemble
+    c_side = exchanging and backend == "nccl"
+    xchg = {"x": None, "ex": [], "buf": [], "work": [None, None], "tick": 0, "entries": 0, "words": 0}
+    ev_cap = max(64, info["m"]) if exchanging else 0
+
+    def coll_device(t):
+        return t.to(device) if backend == "nccl" else t.cpu()
 
     def size_exchange(entries):
-        """Buffers for up to `entries` seen objects per rank, in the wire format of zrk_compact_bits (count, n, one
+        """Lists for up to `entries` seen objects per rank, in the wire format of zrk_compact_bits (count, n, one
         bit per slot, 16-bit masks): a quarter of the bytes of (index, mask) pairs."""
-        from zrk_modulation_amd.exchange import DetectionExchange, union_bits_words
-        n_slots = torch.tensor([int(eng.loop.n)], dtype=torch.int64, device=device)
-        dist.all_reduce(n_slots, op=dist.ReduceOp.MAX)                 # launch counts differ a little between ranks
+        from zrk_modulation_amd.exchange import DetectionExchange, RcclExchange, union_bits_words
+        n_slots = coll_device(torch.tensor([int(eng.store.cap)], dtype=torch.int64))
+        dist.all_reduce(n_slots, op=dist.ReduceOp.MAX)
         words = union_bits_words(int(n_slots.item()), info["R"], entries)
-        stride = info["n"] + info["m"]
-        xchg["ex"] = [DetectionExchange(words, device, fmt="bits", offsets=[g * stride for g in range(world)], R=info["R"])
-                      for _ in range(2)]
-        xchg["buf"] = [torch.zeros(words, dtype=torch.int64, device=device) for _ in range(2)]
-        xchg["work"] = [None, None]
+        offsets = [g * info["stride"] for g in range(world)]
+        if c_side:
+            if xchg["x"] is not None:
+                xchg["x"].close()
+            xchg["x"] = RcclExchange(words, device, info["R"], offsets=offsets, ev_capacity=ev_cap)
+        else:
+            xchg["ex"] = [DetectionExchange(words, device, fmt="bits", offsets=offsets, R=info["R"]) for _ in range(2)]
+            xchg["buf"] = [torch.zeros(words, dtype=torch.int64, device=device) for _ in range(2)]
+            xchg["work"] = [None, None]
         xchg["entries"], xchg["words"] = int(entries), int(words)
 
     def drain_exchange():
+        if c_side and xchg["x"] is not None:
+            xchg["x"].sync()
         for k, w in enumerate(xchg["work"]):
             if w is not None:
                 w.wait()
                 xchg["work"][k] = None
 
-    stride = PROF_STRIDE if world == 1 else PROF_STRIDE_RANKS
+    def max_count():
+        if c_side:
+            return max(max(xchg["x"].counts(0)), max(xchg["x"].counts(1)))
+        return max(max(e.counts()) for e in xchg["ex"])
+
+    # every tick's sweep is timed when the run is short, every 8th otherwise (one C call covers all ticks)
+    stride = 1 if args.steps <= 64 else 8
+    if exchanging and not c_side:
+        stride = 64                      # ticks driven one call at a time: reading the events drains the stream
 
     def run_ticks(k, sweep_ms=None):
-        if world == 1:
-            eng.run(k, sweep_ms=sweep_ms, prof_stride=PROF_STRIDE)
+        if not exchanging:
+            eng.run(k, sweep_ms=sweep_ms, prof_stride=stride)
             return
-        for j in range(k):
+        if c_side:
+            eng.run(k, sweep_ms=sweep_ms, prof_stride=stride, exchange=xchg["x"])
+            return
+        for j in range(k):               # rehearsal path: the exchange goes through torch.distributed, tick by tick
             b = xchg["tick"] & 1
             if xchg["work"][b] is not None:
                 xchg["work"][b].wait()
             eng.packed = xchg["buf"][b]
+            eng.loop.flags |= 8          # ZRK_F_UNION_BITS
             one = np.zeros(1, np.float32) if (sweep_ms is not None and j % stride == 0) else None
             eng.run(1, sweep_ms=one, prof_stride=1)
             xchg["work"][b] = xchg["ex"][b].all_gather(eng.packed, async_op=True)
@@ -233,22 +344,31 @@ def main():
             if one is not None:
                 sweep_ms[j // stride] = one[0]
 
-    if world > 1:
-        size_exchange(info["n"] + info["m"])
-
     def barrier():
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    if exchanging:
+        size_exchange(eng.store.cap)
+    # clocks: ~100 ms of an unrelated kernel (the noise self-test) before the warm-up steps, see the docstring
+    spin = torch.zeros(3 << 20, dtype=torch.float64, device=device)
+    t_spin = time.perf_counter()
+    st0 = eng.store
+    while (time.perf_counter() - t_spin) * 1e3 < SPINUP_MS:
+        for _ in range(8):
+            st0.ctx.check(st0.lib.zrk_selftest_noise(st0.ctx.handle, 1, 1, 3, 0, spin.data_ptr(), 1 << 20, None), "spin-up")
+        torch.cuda.synchronize(device)
+    del spin
+
     run_ticks(args.warmup)
     overflow = False
-    if world > 1:
-        # size the fixed exchange buffers from what the warm-up saw (1.25x the largest per-rank count: the count
-        # follows the sectors round their scan period, which the warm-up covers; an overflow is reported)
+    if exchanging and args.warmup > 0:
+        # size the fixed lists from what the warm-up saw (1.25x the largest per-rank count: the count follows the
+        # sectors round their scan period, which a full warm-up covers; an overflow is reported)
         drain_exchange()
-        seen = torch.tensor([max(max(e.counts()) for e in xchg["ex"])], dtype=torch.int64, device=device)
+        seen = coll_device(torch.tensor([max_count()], dtype=torch.int64))
         dist.all_reduce(seen, op=dist.ReduceOp.MAX)
         size_exchange(int(seen.item() * 1.25) + 1024)
     barrier()
@@ -257,16 +377,17 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run_ticks(args.steps, sweep_ms)
-    if world > 1:
+    if exchanging:
         drain_exchange()
     barrier()
     elapsed = time.perf_counter() - t0
     live1 = eng.alive_count()
-    if world > 1:
-        overflow = any(e.overflowed() for e in xchg["ex"])
+    eng.store.compact_status()           # outside the timing: a compaction that did not run to completion raises here
+    if exchanging:
+        overflow = xchg["x"].overflowed() if c_side else any(e.overflowed() for e in xchg["ex"])
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    units = torch.tensor([float(min(live0, live1)) * args.steps], dtype=torch.float64, device=device)
+    el = coll_device(torch.tensor([elapsed], dtype=torch.float64))
+    units = coll_device(torch.tensor([float(min(live0, live1)) * args.steps], dtype=torch.float64))
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(units, op=dist.ReduceOp.SUM)
@@ -279,34 +400,54 @@ def main():
         good = sweep_ms[sweep_ms > 0]
         sweep_avg_ms = float(good.mean()) if len(good) else float("nan")
         achieved = alg_bytes / (sweep_avg_ms * 1e-3) / 1e9
+        if ensemble:
+            what = (f"{args.workload}: {info['scenarios']} independent scenarios x {info['per_scenario']} AirObjects, "
+                    f"{info['R']} SectorRadars and {info['m'] // info['scenarios']} missiles each, per GPU, one batched table")
+        else:
+            what = (f"{args.workload}: {info['n']} AirObjects, {info['R']} SectorRadars, "
+                    f"{info['launched']}/{info['m']} missiles in flight per GPU")
+            if strong:
+                what += f" (rank 0's shard of ONE population of {info['n_total']})"
+        what += ", dt=10 ms, Philox measurement noise, "
+        if exchanging:
+            what += ("union compaction in the bitmap wire format + per-tick RCCL all-gather of the detection list and the "
+                     "detonation events, " + ("issued from the C side, overlapped with the next sweep" if c_side
+                                              else "through torch.distributed (rehearsal backend)"))
+        else:
+            what += "per-radar compaction"
         out = {
             "metric": "entity-timesteps/sec (targets+missiles)", "value": total_units / elapsed,
             "unit": "entity-timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {info['n']} AirObjects, {info['R']} SectorRadars, "
-                                   f"{info['launched']}/{info['m']} missiles in flight per GPU, dt=10 ms, "
-                                   f"Philox measurement noise, "
-                                   + ("union compaction in the bitmap wire format + per-tick RCCL all-gather of the detection list, "
-                                      "overlapped with the next sweep" if world > 1 else "per-radar compaction"),
-                       "entities_per_gpu": n_slots, "live_per_gpu": int(live1), "parallelism": f"shard{world}"},
+            "config": {"workload": what, "entities_per_gpu": n_slots, "live_per_gpu": int(live1),
+                       "parallelism": f"shard{world}" if not ensemble else f"replicas{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, world),
-                         "kernel": "k_tick_sweep",
-                         "avg_kernel_us": sweep_avg_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
-                         "profiled_kernel_us": profiled_kernel_us(args.workload, world)},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "traffic_recorded": recorded(f"traffic_bytes_{args.workload}") if world == 1 else None,
+                         "kernel": "k_tick_sweep", "avg_kernel_us": sweep_avg_ms * 1e3, "samples": int(len(good)),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "profiled_kernel_us_recorded": recorded(f"sweep_us_{args.workload}") if world == 1 else None,
+                         "recorded_from": f"profiles/{PROFILE_TAG}_recorded.json (rocprofv3 passes of this command, committed)"},
+            "setup": {"clock_spinup_ms": SPINUP_MS},
         }
-        if world > 1:
+        if exchanging:
+            out["config"]["exchange"] = "rccl, C side" if c_side else f"torch.distributed {backend}"
             out["config"]["exchange_entries_per_rank"] = xchg["entries"]
-            out["config"]["exchange_bytes_per_rank"] = 8 * xchg["words"]
+            out["config"]["exchange_bytes_per_rank"] = 8 * (xchg["words"] + (1 + ev_cap if c_side else 0))
             out["config"]["exchange_overflow"] = bool(overflow)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not ensemble:
             out["cpu_baseline"] = cpu_baseline(info, eng, args.cpu_budget)
+        elif world == 1 and not args.no_cpu_baseline and ensemble:
+            out["cpu_baseline"] = eng.cpu_baseline(args.cpu_budget, usable_cores(), cpu_model())
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if xchg["x"] is not None:
+            xchg["x"].close()
         dist.destroy_process_group()
 
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ZRK_ABI_VERSION 3
+#define ZRK_ABI_VERSION 4
 #define ZRK_MAX_RADARS 32           /* one bit per radar in the visibility mask */
 #define ZRK_BLOCK 256               /* table rows per sweep workgroup */
 
@@ -114,7 +114,8 @@ int zrk_ctx_create(int device, zrk_ctx **out);
 void zrk_ctx_destroy(zrk_ctx *ctx);
 const char *zrk_last_error(zrk_ctx *ctx);
 
-/* Bytes of DEVICE scratch the sweep + compaction need for up to n_max entities. */
+/* Bytes of DEVICE scratch the sweep + compaction need for a table of capacity n_max (zrk_run_ticks finds its
+ * own arrays in the workspace from ents->capacity: size the workspace for exactly that). */
 int64_t zrk_workspace_bytes(int64_t n_max);
 
 /*
@@ -253,6 +254,55 @@ int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *ents, const zrk_missiles *mi
                   int32_t *det_idx, int64_t det_stride, int32_t *det_cnt, int64_t *packed,
                   int64_t packed_capacity, int K, float *sweep_ms /* HOST, may be NULL */, int prof_stride,
                   void *stream);
+
+/*
+ * Per-tick exchange of the compacted detection list between the GPUs of one node (no counterpart in the
+ * reference, which is one process: modules/Manager.py:123-131).  One process per GPU; every
+ * rank holds a contiguous shard of AirEnv's list, and what FoundObjectsMessage (modules/Radar.py:168-174) would
+ * carry for the whole population is the rank-ordered concatenation of the shards' lists.  The exchange object
+ * owns an RCCL communicator (librccl is bound at run time from `rccl_path`, or found by name when NULL) and a
+ * stream of its own; zrk_run_ticks_x issues one ncclAllGather per tick on it, behind that tick's compaction and
+ * beside the next tick's sweep.  Rank 0 makes the id and hands it to the others by any means (128 bytes).
+ */
+typedef struct { char internal[128]; } zrk_rccl_id;          /* ncclUniqueId */
+typedef struct zrk_exchange zrk_exchange;
+
+int zrk_exchange_unique_id(const char *rccl_path, zrk_rccl_id *id /* HOST out */);
+/* Collective over all ranks (ncclCommInitRank).  *out is set also on failure, for zrk_exchange_last_error. */
+int zrk_exchange_create(const char *rccl_path, const zrk_rccl_id *id, int world, int rank, int device,
+                        zrk_exchange **out);
+void zrk_exchange_destroy(zrk_exchange *x);
+const char *zrk_exchange_last_error(zrk_exchange *x);
+/* One all-gather of `words` 64-bit words per rank: recv = [world][words].  Enqueued on the exchange's stream
+ * behind everything `stream` holds so far; two slots (0 / 1) may be in flight. */
+int zrk_exchange_all_gather(zrk_exchange *x, int slot, const int64_t *send /* DEVICE */, int64_t *recv /* DEVICE */,
+                            int64_t words, void *stream);
+/* Make `stream` wait for the last all-gather posted on `slot` (nothing if none was). */
+int zrk_exchange_wait(zrk_exchange *x, int slot, void *stream);
+/* Block the host until the exchange's stream is idle. */
+int zrk_exchange_sync(zrk_exchange *x);
+
+/* What zrk_run_ticks_x sends each tick: this rank's list in the wire format of zrk_compact_bits, followed -- when
+ * ev_capacity > 0 -- by the tick's detonations, so that MissileDetonateMessage (modules/Missile.py:138-146) reaches
+ * every rank with the list: word `words - 1 - ev_capacity` = number of events, then one word per event,
+ * (global list index of the missile << 32) | global list index of the target, 0xFFFFFFFF for a self-detonation.
+ * Tick t uses slot t & 1 of send / recv. */
+typedef struct {
+    zrk_exchange *x;
+    int64_t *send[2];               /* DEVICE [words] */
+    int64_t *recv[2];               /* DEVICE [world][words] */
+    int64_t words;                  /* zrk_union_bits_words(capacity, R, entries) + (ev_capacity ? 1 + ev_capacity : 0) */
+    int32_t ev_capacity;
+    int32_t _pad;
+} zrk_exchange_io;
+
+/* zrk_run_ticks with the per-tick exchange: `packed` must be NULL when xio is given (the list goes to xio->send),
+ * zrk_loop.flags must have ZRK_F_UNION_BITS.  xio == NULL: exactly zrk_run_ticks. */
+int zrk_run_ticks_x(zrk_ctx *ctx, const zrk_entities *ents, const zrk_missiles *mis, int64_t m, zrk_loop *st,
+                    zrk_radar *radars /* HOST, in/out */, const zrk_scan *scan /* HOST */, int R, void *workspace,
+                    int32_t *det_idx, int64_t det_stride, int32_t *det_cnt, int64_t *packed,
+                    int64_t packed_capacity, const zrk_exchange_io *xio /* HOST, may be NULL */, int K,
+                    float *sweep_ms /* HOST, may be NULL */, int prof_stride, void *stream);
 
 /* Numerics self-test hooks used by tests/: y[i] = op(a[i], b[i]) in device binary64.
  * op: 0 sqrt(a), 1 a/b, 2 atan2(a,b), 3 asin(a), 4 fma-chain norm of (a,b,0). */

@@ -1,0 +1,39 @@
+"""bench.py end to end on the one GPU of the test box: the single-rank line, and the N = 2 control flow with both
+ranks sharing the device (gloo rehearsal backend: RCCL refuses two ranks on one GPU)."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+
+def _bench(args, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, env=e, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_single_rank_line_has_the_contract_fields():
+    rec = _bench(["--workload", "tiny", "--steps", "12", "--warmup", "3", "--cpu-budget", "1"])
+    assert rec["n_gpus"] == 1 and rec["steps"] == 12 and rec["scaling"] == "weak" and rec["dtype"] == "f64"
+    assert rec["roofline"]["bound"] == "hbm" and rec["roofline"]["samples"] == 12 and rec["roofline"]["achieved"] > 0
+    assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cpu_model"]
+    assert rec["value"] > 0 and "tiny" in rec["config"]["workload"]
+
+
+@pytest.mark.parametrize("workload,scaling", [("tiny", "weak"), ("tiny4", "strong")])
+def test_two_ranks_started_by_the_gpus_flag(workload, scaling):
+    rec = _bench(["--gpus", "2", "--workload", workload, "--steps", "10", "--warmup", "4", "--no-cpu-baseline"],
+                 env={"ZRK_BENCH_BACKEND": "gloo"})
+    assert rec["n_gpus"] == 2 and rec["scaling"] == scaling
+    assert rec["config"]["exchange_overflow"] is False
+    assert rec["value"] > 0

@@ -1,0 +1,62 @@
+"""The exchange issued from the C side (zrk_run_ticks_x + zrk_exchange_*): on the one GPU of the test box the
+communicator has one rank, which exercises everything but the wire -- RCCL bound at run time, its stream and the
+events both ways, the list and the detonation events in wire format -- against the plain loop."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _engines(n, R, m, seed):
+    from tests.test_gpu_engine import _engine
+    return _engine(n, R, m, seed=seed, noise="philox")
+
+
+def test_c_side_exchange_carries_the_same_list_and_events_as_the_plain_loop():
+    from zrk_modulation_amd.exchange import RcclExchange, union_bits_words
+    n, R, m = 30_000, 6, 400
+    eng_a, _, launched = _engines(n, R, m, 11)
+    eng_b, _, _ = _engines(n, R, m, 11)
+    assert launched > 100
+    eng_b.gid0 = eng_b.loop.gid0 = 0
+    x = RcclExchange(union_bits_words(eng_b.store.cap, R, eng_b.store.cap), eng_b.store.device, R, offsets=[0], ev_capacity=512)
+    total_events = 0
+    for k in range(40):
+        eng_a.run(1)
+        eng_b.run(1, exchange=x)
+        slot = k & 1
+        idx, msk = x.merged(slot)
+        st = eng_a.store
+        vis = st.vis()[:st.n_uploaded].cpu().numpy().view(np.uint32)
+        want = np.nonzero(vis)[0]
+        assert np.array_equal(idx.cpu().numpy(), want), f"tick {k}: union list differs"
+        assert np.array_equal(msk.cpu().numpy().astype(np.uint32), vis[want]), f"tick {k}: masks differ"
+        ev = x.events(slot)
+        ne = int(st.dm_evn.item())
+        rows_m, rows_t = st.dm_evm[:ne].cpu().numpy(), st.dm_evt[:ne].cpu().numpy()
+        lidx = st.d_lidx.cpu().numpy() if st.d_lidx is not None else None
+        to_list = lambda r: int(lidx[r]) if lidx is not None else int(r)      # noqa: E731
+        assert ev == [(to_list(a), -1 if b < 0 else to_list(b)) for a, b in zip(rows_m, rows_t)], f"tick {k}: events differ"
+        total_events += len(ev)
+        # and the two loops stay identical (same masks every tick)
+        vis_b = eng_b.store.vis()[:st.n_uploaded].cpu().numpy().view(np.uint32)
+        assert np.array_equal(vis, vis_b)
+    assert total_events > 5
+    assert not x.overflowed()
+    x.close()
+
+
+def test_k_ticks_per_call_with_the_exchange():
+    from zrk_modulation_amd.exchange import RcclExchange, union_bits_words
+    n, R, m = 20_000, 4, 100
+    eng_a, _, _ = _engines(n, R, m, 5)
+    eng_b, _, _ = _engines(n, R, m, 5)
+    x = RcclExchange(union_bits_words(eng_b.store.cap, R, eng_b.store.cap), eng_b.store.device, R, offsets=[0], ev_capacity=128)
+    eng_a.run(9)
+    eng_b.run(9, exchange=x)           # tick 8 went through slot 0
+    idx, msk = x.merged(0)
+    st = eng_a.store
+    vis = st.vis()[:st.n_uploaded].cpu().numpy().view(np.uint32)
+    assert np.array_equal(idx.cpu().numpy(), np.nonzero(vis)[0])
+    x.close()

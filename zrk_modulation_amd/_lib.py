@@ -14,7 +14,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = CSRC / "libzrk_hot.so"
 
-ZRK_ABI_VERSION = 3
+ZRK_ABI_VERSION = 4
 ZRK_MAX_RADARS = 32
 ZRK_BLOCK = 256
 F_ADVANCE, F_PHILOX, F_EXACT_ONLY, F_UNION_BITS = 1, 2, 4, 8
@@ -109,6 +109,21 @@ class ZrkLoop(C.Structure):
     ]
 
 
+class ZrkRcclId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+class ZrkExchangeIo(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p),
+        ("send", C.c_void_p * 2),
+        ("recv", C.c_void_p * 2),
+        ("words", C.c_int64),
+        ("ev_capacity", C.c_int32),
+        ("_pad", C.c_int32),
+    ]
+
+
 # name -> (restype, argtypes); the exported surface of include/zrk_hot.h
 _PROTOTYPES = {
     "zrk_abi_version": (C.c_int, []),
@@ -130,6 +145,17 @@ _PROTOTYPES = {
                                 C.POINTER(ZrkLoop), C.POINTER(ZrkRadar), C.POINTER(ZrkScan), C.c_int, C.c_void_p,
                                 C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                 C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+    "zrk_run_ticks_x": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.POINTER(ZrkMissiles), C.c_int64,
+                                  C.POINTER(ZrkLoop), C.POINTER(ZrkRadar), C.POINTER(ZrkScan), C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(ZrkExchangeIo),
+                                  C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+    "zrk_exchange_unique_id": (C.c_int, [C.c_char_p, C.POINTER(ZrkRcclId)]),
+    "zrk_exchange_create": (C.c_int, [C.c_char_p, C.POINTER(ZrkRcclId), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "zrk_exchange_destroy": (None, [C.c_void_p]),
+    "zrk_exchange_last_error": (C.c_char_p, [C.c_void_p]),
+    "zrk_exchange_all_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "zrk_exchange_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "zrk_exchange_sync": (C.c_int, [C.c_void_p]),
     "zrk_noise_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p,
                                   C.c_int64, C.c_void_p]),
     "zrk_missile_step": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.c_int, C.POINTER(ZrkMissiles),

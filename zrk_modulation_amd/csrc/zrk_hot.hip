@@ -20,6 +20,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
+
+#include <dlfcn.h>
 
 #include "zrk_hot.h"
 
@@ -138,7 +141,9 @@ struct MissileArgs {
     int32_t *ev_missile, *ev_target, *ev_count;
     int64_t m;
     double t, dts;
-    int32_t apply, _pad;
+    int32_t apply, ev_wire_cap;
+    int64_t *ev_wire;           // tail of the exchange list: [count, (missile index << 32 | target index or 0xFFFFFFFF) ...]
+    int64_t gid0;               // global list index of list element 0 (indices on the wire are global)
 };
 
 // Dispatch order of the next sweep.  The sweep's duration is set by the expensive waves (rows inside some
@@ -1269,7 +1274,9 @@ __device__ __forceinline__ void missile_finish_block(int *s_wave, const uint8_t 
                                                      const int32_t *__restrict__ m_tgt, int64_t m,
                                                      int32_t *__restrict__ ev_missile, int32_t *__restrict__ ev_target,
                                                      int32_t *__restrict__ ev_count, int apply, uint8_t *alive,
-                                                     const double *pos_cur, double *pos_prev, int64_t cap)
+                                                     const double *pos_cur, double *pos_prev, int64_t cap,
+                                                     int64_t *ev_wire = nullptr, int ev_wire_cap = 0, int64_t gid0 = 0,
+                                                     const int32_t *__restrict__ lidx = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (int)((m + 1023) / 1024);                 // consecutive rows per thread (<= kMissileItems)
@@ -1292,14 +1299,21 @@ __device__ __forceinline__ void missile_finish_block(int *s_wave, const uint8_t 
     __syncthreads();
     int base = incl - cnt, total = 0;
     for (int w = 0; w < 16; ++w) { if (w < wave) base += s_wave[w]; total += s_wave[w]; }
-    if (tid == 0) *ev_count = total;
+    if (tid == 0) {
+        *ev_count = total;
+        if (ev_wire) ev_wire[0] = total;
+    }
     if (cnt == 0) return;
 #pragma unroll
     for (int k = 0; k < kMissileItems; ++k) {
         if (codes[k]) {
             const int64_t row = row0 + k;
             const int32_t ms = m_slot[row], ts = (codes[k] == 1) ? m_tgt[row] : -1;
-            ev_missile[base] = ms; ev_target[base] = ts; ++base;
+            ev_missile[base] = ms; ev_target[base] = ts;
+            if (ev_wire && base < ev_wire_cap)                // MissileDetonateMessage (modules/Missile.py:138-146) for the other ranks
+                ev_wire[1 + base] = (int64_t)(((uint64_t)(gid0 + (lidx ? lidx[ms] : ms)) << 32) |
+                                              (ts >= 0 ? (uint64_t)(uint32_t)(gid0 + (lidx ? lidx[ts] : ts)) : 0xFFFFFFFFull));
+            ++base;
             if (apply) {                                      // AirEnv.py:33-40, effective from the next tick
                 kill_one(alive, pos_cur, pos_prev, cap, ms);
                 if (ts >= 0) kill_one(alive, pos_cur, pos_prev, cap, ts);
@@ -1324,7 +1338,7 @@ __global__ __launch_bounds__(1024) void k_missile_finish(const uint8_t *__restri
 __device__ void missile_finish_entry(int *s_wave, const MissileArgs &M)
 {
     missile_finish_block(s_wave, M.ev_code, M.m_slot, M.m_tgt, M.m, M.ev_missile, M.ev_target, M.ev_count, M.apply, M.alive,
-                         M.pos_cur, M.pos_prev, M.cap);
+                         M.pos_cur, M.pos_prev, M.cap, M.ev_wire, M.ev_wire_cap, M.gid0, M.lidx);
 }
 
 // Ordered event list from ev_code: one workgroup walks the (short) missile table in row order.
@@ -1358,6 +1372,21 @@ __global__ __launch_bounds__(1024) void k_missile_events(const uint8_t *__restri
         __syncthreads();
     }
     if (tid == 0) *ev_count = s_carry;
+}
+
+// The event rows of this tick in wire form (see MissileArgs::ev_wire), for the ticks whose event list was built by
+// the stand-alone launches.
+__global__ void k_events_wire(const int32_t *__restrict__ ev_missile, const int32_t *__restrict__ ev_target,
+                              const int32_t *__restrict__ ev_count, const int32_t *__restrict__ lidx, int64_t gid0,
+                              int64_t *__restrict__ ev_wire, int ev_wire_cap)
+{
+    const int n = *ev_count;
+    if (threadIdx.x == 0) ev_wire[0] = n;
+    for (int j = threadIdx.x; j < n && j < ev_wire_cap; j += blockDim.x) {
+        const int32_t ms = ev_missile[j], ts = ev_target[j];
+        ev_wire[1 + j] = (int64_t)(((uint64_t)(gid0 + (lidx ? lidx[ms] : ms)) << 32) |
+                                   (ts >= 0 ? (uint64_t)(uint32_t)(gid0 + (lidx ? lidx[ts] : ts)) : 0xFFFFFFFFull));
+    }
 }
 
 __global__ void k_kill_slots(uint8_t *alive, const double *src, double *dst, int64_t cap,
@@ -1591,6 +1620,7 @@ struct zrk_ctx {
     const void *box_key = nullptr;     // ... this table (its start_pos column) ...
     int64_t box_n = 0;                 // ... up to this many rows
     std::string err;
+    std::vector<hipEvent_t> tev;       // timing events of zrk_run_ticks, reused
     const void *ring_key = nullptr;    // mask buffers zrk_run_ticks has been alternating between ...
     int64_t ring_age = 0;              // ... for this many consecutive ticks (>= 1: the next one starts cleared)
 };
@@ -1679,7 +1709,12 @@ ZRK_API int zrk_ctx_create(int device, zrk_ctx **out)
     return 0;
 }
 
-ZRK_API void zrk_ctx_destroy(zrk_ctx *ctx) { delete ctx; }
+ZRK_API void zrk_ctx_destroy(zrk_ctx *ctx)
+{
+    if (!ctx) return;
+    for (hipEvent_t e : ctx->tev) (void)hipEventDestroy(e);
+    delete ctx;
+}
 
 ZRK_API const char *zrk_last_error(zrk_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -1710,7 +1745,7 @@ MissileArgs missile_args(const zrk_entities *e, int cur, const zrk_missiles *mis
     M.ev_missile = mis->ev_missile; M.ev_target = mis->ev_target; M.ev_count = mis->ev_count;
     M.m = m;
     M.t = (double)time_ms / 1000.0; M.dts = (double)dt_ms / 1000.0;
-    M.apply = apply; M._pad = 0;
+    M.apply = apply; M.ev_wire_cap = 0; M.ev_wire = nullptr; M.gid0 = 0;
     return M;
 }
 
@@ -1823,7 +1858,9 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         while (lanes < R + 1) lanes <<= 1;
         // Workgroups that all fit on the device at once may wait for each other in blockIdx order; beyond that
         // only tickets guarantee that whoever is waited for is already running.
-        int by_ticket = nbf > 2 * (int64_t)ctx->cus;
+        // (in practice workgroups are dispatched in index order, which is what makes waiting in index order safe on an
+        // idle device; a union list means other ranks' collectives share the device, so there nothing is assumed)
+        int by_ticket = nbf > 2 * (int64_t)ctx->cus || packed != nullptr;
         if (const char *v = std::getenv("ZRK_COMPACT_ORDER")) by_ticket = std::strcmp(v, "block") != 0;
         CompactArgs C;
         C.vis = vis_mask; C.zero_next = zero_next; C.n = n; C.R = R; C.nb = (int)nbf; C.items = items; C.lanes = lanes;
@@ -2010,39 +2047,189 @@ ZRK_API int zrk_scan_advance(zrk_radar *radars, const zrk_scan *scan, int R)
     return 0;
 }
 
-ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int64_t m, zrk_loop *st,
-                          zrk_radar *radars, const zrk_scan *scan, int R, void *workspace, int32_t *det_idx,
-                          int64_t det_stride, int32_t *det_cnt, int64_t *packed, int64_t packed_capacity, int K,
-                          float *sweep_ms, int prof_stride, void *stream)
+// ---------------------------------------------------------------------------------------------
+// Per-tick exchange of the detection list between the GPUs of a node: RCCL all-gather issued from here, on a
+// stream of its own, with events both ways -- no interpreter between a tick's compaction and its collective.
+// The library is bound at run time (dlopen: the process usually holds PyTorch's copy of librccl already, and
+// two copies in one process is asking for trouble), the communicator is this module's own.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, zrk_rccl_id, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+constexpr int kNcclInt64 = 4;          // ncclDataType_t: ncclInt64
+
+bool load_rccl(const char *path, RcclApi &api, std::string &err)
+{
+    const char *names[3] = {path, "librccl.so.1", "librccl.so"};
+    for (const char *nm : names) {
+        if (!nm || !*nm) continue;
+        api.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (api.lib) break;
+    }
+    if (!api.lib) { err = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "?"); return false; }
+    api.GetUniqueId = (int (*)(void *))dlsym(api.lib, "ncclGetUniqueId");
+    api.CommInitRank = (int (*)(void **, int, zrk_rccl_id, int))dlsym(api.lib, "ncclCommInitRank");
+    api.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(api.lib, "ncclAllGather");
+    api.CommDestroy = (int (*)(void *))dlsym(api.lib, "ncclCommDestroy");
+    api.GetErrorString = (const char *(*)(int))dlsym(api.lib, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) { err = "RCCL symbols missing"; return false; }
+    return true;
+}
+
+}  // namespace
+
+struct zrk_exchange {
+    RcclApi api;
+    void *comm = nullptr;
+    int world = 1, rank = 0, device = 0;
+    hipStream_t cstream = nullptr;
+    hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+    bool posted[2] = {false, false};
+    std::string err;
+};
+
+ZRK_API int zrk_exchange_unique_id(const char *rccl_path, zrk_rccl_id *id)
+{
+    if (!id) return ZRK_E_INVALID;
+    RcclApi api;
+    std::string err;
+    if (!load_rccl(rccl_path, api, err)) return ZRK_E_HIP;
+    return api.GetUniqueId(id) == 0 ? 0 : ZRK_E_HIP;
+}
+
+ZRK_API int zrk_exchange_create(const char *rccl_path, const zrk_rccl_id *id, int world, int rank, int device,
+                                zrk_exchange **out)
+{
+    if (!out) return ZRK_E_INVALID;
+    *out = nullptr;
+    if (!id || world < 1 || rank < 0 || rank >= world) return ZRK_E_INVALID;
+    zrk_exchange *x = new zrk_exchange;
+    x->world = world; x->rank = rank; x->device = device;
+    *out = x;                                            // handed back also on failure, for zrk_exchange_last_error
+    if (hipSetDevice(device) != hipSuccess) { x->err = "hipSetDevice failed"; return ZRK_E_HIP; }
+    if (!load_rccl(rccl_path, x->api, x->err)) return ZRK_E_HIP;
+    const int rc = x->api.CommInitRank(&x->comm, world, *id, rank);
+    if (rc != 0) {
+        x->err = std::string("ncclCommInitRank: ") + (x->api.GetErrorString ? x->api.GetErrorString(rc) : "error");
+        x->comm = nullptr;
+        return ZRK_E_HIP;
+    }
+    bool ok = hipStreamCreateWithFlags(&x->cstream, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 2 && ok; ++k)
+        ok = hipEventCreateWithFlags(&x->ready[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&x->done[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { x->err = "stream / event creation failed"; return ZRK_E_HIP; }
+    return 0;
+}
+
+ZRK_API void zrk_exchange_destroy(zrk_exchange *x)
+{
+    if (!x) return;
+    if (x->cstream) (void)hipStreamSynchronize(x->cstream);
+    if (x->comm) (void)x->api.CommDestroy(x->comm);
+    for (int k = 0; k < 2; ++k) {
+        if (x->ready[k]) (void)hipEventDestroy(x->ready[k]);
+        if (x->done[k]) (void)hipEventDestroy(x->done[k]);
+    }
+    if (x->cstream) (void)hipStreamDestroy(x->cstream);
+    delete x;
+}
+
+ZRK_API const char *zrk_exchange_last_error(zrk_exchange *x) { return x ? x->err.c_str() : "null exchange"; }
+
+ZRK_API int zrk_exchange_all_gather(zrk_exchange *x, int slot, const int64_t *send, int64_t *recv, int64_t words, void *stream)
+{
+    if (!x || !x->comm || !send || !recv || words <= 0 || (slot != 0 && slot != 1)) return ZRK_E_INVALID;
+    if (hipEventRecord(x->ready[slot], (hipStream_t)stream) != hipSuccess ||
+        hipStreamWaitEvent(x->cstream, x->ready[slot], 0) != hipSuccess) { x->err = "event hand-over to the exchange stream failed"; return ZRK_E_HIP; }
+    const int rc = x->api.AllGather(send, recv, (size_t)words, kNcclInt64, x->comm, x->cstream);
+    if (rc != 0) { x->err = std::string("ncclAllGather: ") + (x->api.GetErrorString ? x->api.GetErrorString(rc) : "error"); return ZRK_E_HIP; }
+    if (hipEventRecord(x->done[slot], x->cstream) != hipSuccess) { x->err = "hipEventRecord failed"; return ZRK_E_HIP; }
+    x->posted[slot] = true;
+    return 0;
+}
+
+ZRK_API int zrk_exchange_wait(zrk_exchange *x, int slot, void *stream)
+{
+    if (!x || (slot != 0 && slot != 1)) return ZRK_E_INVALID;
+    if (!x->posted[slot]) return 0;
+    if (hipStreamWaitEvent((hipStream_t)stream, x->done[slot], 0) != hipSuccess) { x->err = "hipStreamWaitEvent failed"; return ZRK_E_HIP; }
+    return 0;
+}
+
+ZRK_API int zrk_exchange_sync(zrk_exchange *x)
+{
+    if (!x) return ZRK_E_INVALID;
+    if (hipStreamSynchronize(x->cstream) != hipSuccess) { x->err = "hipStreamSynchronize failed"; return ZRK_E_HIP; }
+    return 0;
+}
+
+
+namespace {
+
+// Timing events of zrk_run_ticks: created once per context and reused (the multi-rank loop calls with K = 1).
+bool ensure_events(zrk_ctx *ctx, int pairs)
+{
+    while ((int)ctx->tev.size() < 2 * pairs) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return false;
+        ctx->tev.push_back(e);
+    }
+    return true;
+}
+
+}  // namespace
+
+ZRK_API int zrk_run_ticks_x(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int64_t m, zrk_loop *st,
+                            zrk_radar *radars, const zrk_scan *scan, int R, void *workspace, int32_t *det_idx,
+                            int64_t det_stride, int32_t *det_cnt, int64_t *packed, int64_t packed_capacity,
+                            const zrk_exchange_io *xio, int K, float *sweep_ms, int prof_stride, void *stream)
 {
     if (!ctx || !e || !st || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: null argument");
     if (m > 0 && !mis) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: missiles without a table");
     if (K < 0 || (st->cur != 0 && st->cur != 1)) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: K/cur out of range");
+    if (xio) {
+        if (packed) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: `packed` and an exchange are alternatives");
+        if (!xio->x || !xio->send[0] || !xio->send[1] || !xio->recv[0] || !xio->recv[1] || xio->ev_capacity < 0 ||
+            xio->words < 3 + xio->ev_capacity + (xio->ev_capacity > 0 ? 1 : 0))
+            return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: incomplete exchange description");
+        if (!(st->flags & ZRK_F_UNION_BITS)) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: the exchange carries the wire format (ZRK_F_UNION_BITS)");
+    }
     hipStream_t s = (hipStream_t)stream;
     const int stride = prof_stride > 0 ? prof_stride : 1;
     const int n_prof = sweep_ms ? (K + stride - 1) / stride : 0;
-    hipEvent_t *ev = nullptr;
-    if (n_prof) {
-        ev = new hipEvent_t[2 * n_prof];
-        for (int k = 0; k < 2 * n_prof; ++k)
-            if (hipEventCreate(&ev[k]) != hipSuccess) { delete[] ev; return fail(ctx, ZRK_E_HIP, "hipEventCreate"); }
-    }
+    if (n_prof && !ensure_events(ctx, n_prof)) return fail(ctx, ZRK_E_HIP, "hipEventCreate");
+    hipEvent_t *ev = n_prof ? ctx->tev.data() : nullptr;
+    // the tail of an exchanged list carries this tick's detonations: [count, rows ...]
+    const int64_t ev_words = (xio && xio->ev_capacity > 0) ? 1 + (int64_t)xio->ev_capacity : 0;
     int rc = 0;
     for (int k = 0; k < K && rc == 0; ++k) {
         st->cur ^= 1;
         const bool prof = sweep_ms && (k % stride == 0);
-        if (prof) (void)hipEventRecord(ev[2 * (k / stride)], s);
+        if (prof && hipEventRecord(ev[2 * (k / stride)], s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "hipEventRecord"); break; }
+        const int slot = (int)(st->tick & 1u);
+        int64_t *list = xio ? xio->send[slot] : packed;
+        const int64_t list_words = xio ? xio->words - ev_words : packed_capacity;
         // Missiles read last tick's positions (pos[cur^1]) and trajectories only, so their per-row step rides in
         // the sweep's grid; the ordered event list and the tombstones (effective from the next tick,
         // AirEnv.py:33-40) ride in the compaction's grid, behind the sweep.  Tables too long for one
         // finishing workgroup, or ticks without compaction, take the stand-alone launches instead.
-        const bool fused = m > 0 && m <= 1024 * (int64_t)kMissileItems && (det_idx || packed) && st->n > 0 && R > 0;
-        const MissileArgs M = fused ? missile_args(e, st->cur, mis, m, st->time_ms, st->dt_ms, 1) : no_missiles();
+        const bool fused = m > 0 && m <= 1024 * (int64_t)kMissileItems && (det_idx || list) && st->n > 0 && R > 0;
+        MissileArgs M = fused ? missile_args(e, st->cur, mis, m, st->time_ms, st->dt_ms, 1) : no_missiles();
+        if (fused && ev_words) { M.ev_wire = list + list_words; M.ev_wire_cap = xio->ev_capacity; M.gid0 = st->gid0; }
         // two mask buffers: tick t writes only its detections into one (cleared by the previous tick's
         // scatter) while its own scatter clears the other for tick t+1.  The first tick on a pair of buffers
         // writes densely; from then on the pair belongs to this loop, also between calls (a caller that
         // writes them itself must pass other buffers or call with vis_mask_alt = NULL).
-        const bool two_vis = e->vis_mask_alt && (det_idx || packed) && st->n > 0 && R > 0;
+        const bool two_vis = e->vis_mask_alt && (det_idx || list) && st->n > 0 && R > 0;
         if (ctx->ring_key != (const void *)e->vis_mask || !two_vis) { ctx->ring_key = e->vis_mask; ctx->ring_age = 0; }
         if (two_vis) st->vis_cur ^= 1; else st->vis_cur = 0;
         uint32_t *vis_now = st->vis_cur ? e->vis_mask_alt : e->vis_mask;
@@ -2052,7 +2239,7 @@ ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missile
         // next tick's dispatch order: built by this tick's compaction from the costs this tick's sweep records
         const int nbs = nblocks(st->n, ZRK_BLOCK);
         // (a grid that is resident all at once has no "last": eight workgroups of four waves fit a compute unit)
-        const bool ordering = ctx->order_enabled && (det_idx || packed) && R > 0 && nbs > 8 * ctx->cus &&
+        const bool ordering = ctx->order_enabled && (det_idx || list) && R > 0 && nbs > 8 * ctx->cus &&
                               compacts_in_one_launch(ctx, st->n);
         Workspace w = carve(workspace, 0, e->capacity);
         // box records: none for rows the loop has not swept yet on this table (new table, new workspace, rows appended)
@@ -2072,14 +2259,26 @@ ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missile
         rc = launch_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse, st->seed,
                           st->tick, st->gid0, workspace, stream, M, vis_now, ordering ? w.cost : nullptr,
                           (ordering && ctx->order_ready) ? w.order : nullptr, w.boxes);
-        if (prof) (void)hipEventRecord(ev[2 * (k / stride) + 1], s);
-        if (rc == 0 && (det_idx || packed))
-            rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, packed,
-                                packed_capacity, st->gid0, stream, M, vis_next,
+        if (prof && rc == 0 && hipEventRecord(ev[2 * (k / stride) + 1], s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipEventRecord");
+        // this slot's list was last sent two ticks ago: that collective must have read it before it is rewritten
+        if (rc == 0 && xio && zrk_exchange_wait(xio->x, slot, stream) != 0) rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
+        if (rc == 0 && (det_idx || list))
+            rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, list,
+                                list_words, st->gid0, stream, M, vis_next,
                                 ordering ? OrderArgs{w.cost, w.order, nbs, 0} : OrderArgs{nullptr, nullptr, 0, 0},
                                 (st->flags & ZRK_F_UNION_BITS) != 0);
         if (rc == 0 && ordering) ctx->order_ready = true;
         if (rc == 0 && m > 0 && !fused) rc = zrk_missile_step(ctx, e, st->cur, mis, m, st->time_ms, st->dt_ms, 1, stream);
+        if (rc == 0 && ev_words && !fused) {
+            if (m > 0) {
+                hipLaunchKernelGGL(k_events_wire, dim3(1), dim3(256), 0, s, mis->ev_missile, mis->ev_target, mis->ev_count,
+                                   e->list_index, st->gid0, list + list_words, xio->ev_capacity);
+                rc = check_launch(ctx, "k_events_wire");
+            } else if (hipMemsetAsync(list + list_words, 0, sizeof(int64_t), s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "memset events");
+        }
+        // the collective of this tick, behind the compaction on RCCL's own stream: it overlaps the next tick's sweep
+        if (rc == 0 && xio && zrk_exchange_all_gather(xio->x, slot, list, xio->recv[slot], xio->words, stream) != 0)
+            rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
         zrk_scan_advance(radars, scan, R);                                   // Radar.py:205
         st->time_ms += st->dt_ms;                                            // Manager.py:140
         st->tick += 1;
@@ -2088,11 +2287,21 @@ ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missile
         if (hipStreamSynchronize(s) != hipSuccess && rc == 0) rc = fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
         for (int k = 0; k < n_prof; ++k) {
             float ms = 0.f;
-            if (rc == 0 && hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]) != hipSuccess) ms = -1.f;
+            if (rc != 0 || hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]) != hipSuccess) {
+                ms = -1.f;
+                if (rc == 0) rc = fail(ctx, ZRK_E_HIP, "hipEventElapsedTime");
+            }
             sweep_ms[k] = ms;
         }
-        for (int k = 0; k < 2 * n_prof; ++k) (void)hipEventDestroy(ev[k]);
-        delete[] ev;
     }
     return rc;
+}
+
+ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int64_t m, zrk_loop *st,
+                          zrk_radar *radars, const zrk_scan *scan, int R, void *workspace, int32_t *det_idx,
+                          int64_t det_stride, int32_t *det_cnt, int64_t *packed, int64_t packed_capacity, int K,
+                          float *sweep_ms, int prof_stride, void *stream)
+{
+    return zrk_run_ticks_x(ctx, e, mis, m, st, radars, scan, R, workspace, det_idx, det_stride, det_cnt, packed, packed_capacity,
+                           nullptr, K, sweep_ms, prof_stride, stream);
 }

@@ -268,6 +268,7 @@ class HotPathEngine:
                                              d_res.data_ptr(), k, st._stream()), "zrk_launch_solve")
         res = d_res.cpu().numpy().view(np.dtype([("rc", "<i4"), ("_pad", "<i4"), ("velocity", "<f8", 3),
                                                  ("t_hit", "<f8")]))
+        self.launch_results = res
         ok = np.nonzero(res["rc"] == 0)[0]
         if len(ok) == 0:
             return 0
@@ -286,21 +287,29 @@ class HotPathEngine:
         self.launch_results = res
         return len(ok)
 
-    def run(self, K, sweep_ms=None, prof_stride=1):
+    def run(self, K, sweep_ms=None, prof_stride=1, exchange=None):
         """Enqueue K ticks.  With `sweep_ms` (a float32 numpy array of ceil(K/prof_stride)) the call
-        also times the sweep kernel with HIP events and synchronises the stream."""
+        also times the sweep kernel with HIP events and synchronises the stream.  `exchange` (an
+        exchange.RcclExchange): every tick's union list goes through its all-gather, issued from the C side."""
         C = self._C
         st = self.store
         self.loop.cur = st.cur
         ms_ptr = sweep_ms.ctypes.data_as(C.POINTER(C.c_float)) if sweep_ms is not None else None
-        st.ctx.check(st.lib.zrk_run_ticks(
-            st.ctx.handle, C.byref(st.ents), C.byref(st.mis), st.m, C.byref(self.loop), self.c_radars, self.c_scan,
-            self.R, st.workspace().data_ptr(),
-            self.det_idx.data_ptr() if self.det_idx is not None else None,
-            self.det_stride if self.det_idx is not None else 0, self.det_cnt.data_ptr(),
-            self.packed.data_ptr() if self.packed is not None else None,
-            self.packed.numel() if self.packed is not None else 0, int(K), ms_ptr, int(prof_stride), st._stream()),
-            "zrk_run_ticks")
+        det = (self.det_idx.data_ptr() if self.det_idx is not None else None,
+               self.det_stride if self.det_idx is not None else 0, self.det_cnt.data_ptr())
+        if exchange is not None:
+            self.loop.flags |= self._lib.F_UNION_BITS
+            st.ctx.check(st.lib.zrk_run_ticks_x(
+                st.ctx.handle, C.byref(st.ents), C.byref(st.mis), st.m, C.byref(self.loop), self.c_radars, self.c_scan,
+                self.R, st.workspace().data_ptr(), det[0], det[1], det[2], None, 0, C.byref(exchange.io), int(K), ms_ptr,
+                int(prof_stride), st._stream()), "zrk_run_ticks_x")
+        else:
+            st.ctx.check(st.lib.zrk_run_ticks(
+                st.ctx.handle, C.byref(st.ents), C.byref(st.mis), st.m, C.byref(self.loop), self.c_radars, self.c_scan,
+                self.R, st.workspace().data_ptr(), det[0], det[1], det[2],
+                self.packed.data_ptr() if self.packed is not None else None,
+                self.packed.numel() if self.packed is not None else 0, int(K), ms_ptr, int(prof_stride), st._stream()),
+                "zrk_run_ticks")
         st.cur = int(self.loop.cur)
         st.vis_cur = int(self.loop.vis_cur)
         st.time_ms = int(self.loop.time_ms) - self.dt_ms
@@ -312,6 +321,7 @@ class HotPathEngine:
         return int(self.store.d_alive[:self.store.n_uploaded].sum().item())
 
     def detections(self):
+        self.store.compact_status()                # a compaction that did not run to completion left wrong lists: raise
         cnt = self.det_cnt[:self.R].cpu().numpy()
         idx = self.det_idx.cpu().numpy() if cnt.max(initial=0) * 4 > self.det_stride else None
         out = []

@@ -40,6 +40,134 @@ def encode_union_bits(vis, R, words):
     return out
 
 
+def decode_union_bits(gathered, R, offsets, ev_capacity=0):
+    """Global union list from gathered wire-format buffers int64[world, words]: (indices int64, masks int64) in index
+    order.  Synchronises."""
+    world, words = gathered.shape
+    tail = 1 + int(ev_capacity) if ev_capacity else 0
+    idx, msk = [], []
+    shifts = torch.arange(64, dtype=torch.int64, device=gathered.device)
+    for g in range(world):
+        c, n = int(gathered[g, 0].item()), int(gathered[g, 1].item())
+        nw = (n + 63) // 64
+        bits = ((gathered[g, 2:2 + nw].unsqueeze(1) >> shifts) & 1).reshape(-1)[:n]
+        slots = torch.nonzero(bits).reshape(-1)
+        body = gathered[g, 2 + nw:words - tail]
+        room = body.numel() * (4 if R <= 16 else 2)
+        k = min(c, room)
+        masks = (body.view(torch.int16)[:k].to(torch.int64) & 0xFFFF) if R <= 16 else (body.view(torch.int32)[:k].to(torch.int64) & 0xFFFFFFFF)
+        idx.append(slots[:k] + offsets[g])
+        msk.append(masks)
+    return (torch.cat(idx) if idx else gathered.new_zeros(0)), (torch.cat(msk) if msk else gathered.new_zeros(0))
+
+
+def decode_events(gathered, ev_capacity):
+    """Detonations carried at the tail of gathered wire buffers, rank after rank, each rank's in list order:
+    [(global missile index, global target index | -1)].  Synchronises."""
+    out = []
+    if not ev_capacity:
+        return out
+    tail = gathered[:, gathered.shape[1] - 1 - int(ev_capacity):].cpu().numpy()
+    for g in range(tail.shape[0]):
+        k = min(int(tail[g, 0]), int(ev_capacity))
+        for w in tail[g, 1:1 + k]:
+            w = int(w) & 0xFFFFFFFFFFFFFFFF
+            t = w & 0xFFFFFFFF
+            out.append((w >> 32, -1 if t == 0xFFFFFFFF else t))
+    return out
+
+
+def rccl_library_path():
+    """The librccl this process already holds: PyTorch's own copy ("nccl" in torch.distributed is RCCL on ROCm)."""
+    import os
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p if os.path.exists(p) else None
+
+
+class RcclExchange:
+    """The exchange issued from the C side (zrk_exchange_*, include/zrk_hot.h): the library's own RCCL communicator and
+    stream; zrk_run_ticks_x posts one all-gather per tick behind that tick's compaction, so no Python runs between a
+    tick and its collective.  torch.distributed is used once, to hand rank 0's communicator id to the others."""
+
+    def __init__(self, words, device, R, offsets=None, ev_capacity=0, group=None):
+        import ctypes as C
+        from . import _lib
+        self._C, self.lib = C, _lib.load()
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = torch.device(device)
+        self.R, self.ev_capacity = int(R), int(ev_capacity)
+        self.words = int(words) + (1 + self.ev_capacity if self.ev_capacity else 0)
+        self.offsets = list(offsets) if offsets is not None else [0] * self.world
+        path = rccl_library_path()
+        cpath = path.encode() if path else None
+        uid = _lib.ZrkRcclId()
+        if self.rank == 0:
+            rc = self.lib.zrk_exchange_unique_id(cpath, C.byref(uid))
+            if rc != 0:
+                raise _lib.ZrkError(f"zrk_exchange_unique_id failed ({rc}): RCCL could not be loaded from {path}")
+        if self.world > 1:
+            backend = dist.get_backend(group)
+            t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone()
+            t = t.to(self.device) if backend == "nccl" else t
+            dist.broadcast(t, src=0, group=group)
+            C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+        h = C.c_void_p()
+        rc = self.lib.zrk_exchange_create(cpath, C.byref(uid), self.world, self.rank, self.device.index or 0, C.byref(h))
+        self.handle = h
+        if rc != 0:
+            msg = self.lib.zrk_exchange_last_error(h) if h.value else b""
+            raise _lib.ZrkError(f"zrk_exchange_create failed ({rc}): {msg.decode() if msg else ''}")
+        self.send = [torch.zeros(self.words, dtype=torch.int64, device=self.device) for _ in range(2)]
+        self.recv = [torch.zeros(self.world, self.words, dtype=torch.int64, device=self.device) for _ in range(2)]
+        io = _lib.ZrkExchangeIo()
+        io.x = h
+        io.send[0], io.send[1] = self.send[0].data_ptr(), self.send[1].data_ptr()
+        io.recv[0], io.recv[1] = self.recv[0].data_ptr(), self.recv[1].data_ptr()
+        io.words, io.ev_capacity = self.words, self.ev_capacity
+        self.io = io
+
+    def sync(self):
+        rc = self.lib.zrk_exchange_sync(self.handle)
+        if rc != 0:
+            raise RuntimeError(self.lib.zrk_exchange_last_error(self.handle).decode())
+
+    def counts(self, slot):
+        self.sync()
+        return self.recv[slot][:, 0].cpu().tolist()
+
+    def room(self):
+        """Masks a rank's list has room for, given the largest shard seen so far."""
+        n = int(max(self.recv[0][:, 1].max().item(), self.recv[1][:, 1].max().item()))
+        body = self.words - (1 + self.ev_capacity if self.ev_capacity else 0) - 2 - (n + 63) // 64
+        return body * (4 if self.R <= 16 else 2)
+
+    def overflowed(self):
+        self.sync()
+        room = self.room()
+        ev_over = self.ev_capacity and any(int(r[:, self.words - 1 - self.ev_capacity].max().item()) > self.ev_capacity for r in self.recv)
+        return any(c > room for s in (0, 1) for c in self.recv[s][:, 0].cpu().tolist()) or bool(ev_over)
+
+    def merged(self, slot):
+        self.sync()
+        return decode_union_bits(self.recv[slot], self.R, self.offsets, self.ev_capacity)
+
+    def events(self, slot):
+        self.sync()
+        return decode_events(self.recv[slot], self.ev_capacity)
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.zrk_exchange_destroy(self.handle)
+            self.handle = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DetectionExchange:
     def __init__(self, capacity, device, group=None, fmt="pairs", offsets=None, R=None):
         """fmt "pairs": buffers of capacity + 1 words, [count, (global index << 32 | mask) ...].

@@ -6,12 +6,21 @@ from __future__ import annotations
 import numpy as np
 
 WORKLOADS = {
-    # name: (targets, radars, missiles)       BASELINE.json configs[1], configs[2]
+    # name: (targets, radars, missiles)       BASELINE.json configs[1], configs[2], configs[3]
     "C2": (100_000, 4, 1_000),
     "C3": (1_000_000, 16, 10_000),
+    "C4": (10_000_000, 16, 10_000),           # ONE population of 1e7, cut into contiguous shards (strong scaling)
     "tiny": (4_096, 4, 64),
+    "tiny4": (16_384, 4, 64),                 # C4's mechanics at test size
 }
-SEEDS = {"C2": 1236, "C3": 1237, "tiny": 1234}
+# Monte-Carlo ensemble, BASELINE.json configs[4]: (scenarios per GPU, targets, radars, missiles) per scenario
+ENSEMBLES = {
+    "C5": (128, 10_000, 4, 100),
+    "tiny5": (6, 1_000, 3, 10),
+}
+SEEDS = {"C2": 1236, "C3": 1237, "C4": 1238, "C5": 1239, "tiny": 1234, "tiny4": 1235, "tiny5": 1233}
+STRONG = ("C4", "tiny4")
+CHUNK = 62_500                                # rows per independently seeded chunk of a sharded population
 
 
 def synthetic_targets(n, seed, first_id=1000):
@@ -23,6 +32,31 @@ def synthetic_targets(n, seed, first_id=1000):
     vel = g.normal(0.0, 150.0, (n, 3))
     ids = first_id + np.arange(n, dtype=np.int64)
     return ids, sp, vel, np.zeros(n)
+
+
+def population_slice(seed, lo, hi, first_id=1000, chunk=CHUNK):
+    """Rows [lo, hi) of the one population `seed` defines, whoever asks and however it is cut: the population is
+    generated in chunks of `chunk` rows, chunk c from PCG64([seed, c]), so a rank builds its shard without generating
+    anybody else's."""
+    parts = []
+    for c in range(lo // chunk, (hi + chunk - 1) // chunk):
+        g = np.random.Generator(np.random.PCG64([seed, c]))
+        sp = np.empty((chunk, 3))
+        sp[:, 0] = g.uniform(-60e3, 60e3, chunk)
+        sp[:, 1] = g.uniform(-60e3, 60e3, chunk)
+        sp[:, 2] = g.uniform(100.0, 12e3, chunk)
+        vel = g.normal(0.0, 150.0, (chunk, 3))
+        a, b = max(lo, c * chunk) - c * chunk, min(hi, (c + 1) * chunk) - c * chunk
+        parts.append((sp[a:b], vel[a:b]))
+    sp = np.concatenate([p[0] for p in parts]) if parts else np.zeros((0, 3))
+    vel = np.concatenate([p[1] for p in parts]) if parts else np.zeros((0, 3))
+    ids = first_id + np.arange(lo, hi, dtype=np.int64)
+    return ids, sp, vel, np.zeros(hi - lo)
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous index range of rank `rank`: [g*n/G, (g+1)*n/G)."""
+    return (rank * n) // world, ((rank + 1) * n) // world
 
 
 def synthetic_radars(R):
