@@ -228,6 +228,53 @@ def cpu_baseline(info, eng, budget_s=15.0):
                                      "1.6 us/entity + 4.3 us/(radar x entity), 1 thread (BASELINE.md section 2)"}
 
 
+def cpu_baseline_ensemble(self, budget_s, cores, cpu_model):
+    """The oracle (oracle/, test infrastructure) timed on scenario 0 of the batch: the reported CPU baseline."""
+    import time
+    from oracle import oracle as O
+    from zrk_modulation_amd.engine import scan_mode_code, scan_next
+    import numpy as np
+    L = O.lib()
+    v = self.scenario_view(0).store
+    n = v.n_uploaded
+    hsp = np.ascontiguousarray(v.h_sp.T).reshape(-1); hvel = np.ascontiguousarray(v.h_vel.T).reshape(-1)
+    ht0 = v.h_t0.copy(); pos = np.ascontiguousarray(v.h_pos0.T).reshape(-1).copy()
+    prev = pos.copy(); pv = np.zeros(n, np.uint8); alive = np.ones(n, np.uint8)
+    kind = v.h_kind.copy(); mrow = np.full(n, -1, np.int32)
+    m = v.m
+    mrow[v.hm_slot] = np.arange(m, dtype=np.int32)
+    m_tgt = v.hm_tgt.astype(np.int32).copy(); m_radius = np.full(max(m, 1), 150.0); m_period = np.full(max(m, 1), 60.0)
+    m_status = np.ones(max(m, 1), np.uint8)
+    evm = np.zeros(max(m, 1), np.int32); evt = np.zeros(max(m, 1), np.int32); evs = np.zeros(max(m, 1), np.uint8)
+    vis = np.zeros(n, np.uint32)
+    rs = [dict(r, caz=r["azimuth_start"], cel=r["elevation_start"]) for r in self.radars[0]]
+    out = np.zeros(n, np.int32)
+
+    def tick(k):
+        L.zo_airenv_step(n, n, self.dt_ms * k, self.dt_ms, O.dptr(hsp), O.dptr(hvel), O.dptr(ht0), O.u8ptr(alive),
+                         O.u8ptr(kind), O.i32ptr(mrow), O.dptr(pos), O.dptr(prev), O.u8ptr(pv), O.i32ptr(m_tgt),
+                         O.dptr(m_radius), O.dptr(m_period), O.u8ptr(m_status), O.i32ptr(evm), O.i32ptr(evt), O.u8ptr(evs))
+        arr = O.radar_array([(r["position"][0], r["position"][1], r["position"][2], r["max_distance"], r["caz"],
+                              r["azimuth_range"], r["cel"], r["elevation_range"]) for r in rs])
+        L.zo_radar_phase_fused(n, n, O.dptr(pos), O.u8ptr(alive), len(rs), arr, 1, None, int(self.seeds[0]), k, 0,
+                               O.u32ptr(vis), cores)
+        for r in range(len(rs)):
+            L.zo_compact_bit(n, O.u32ptr(vis), r, 0, O.i32ptr(out))
+        for r in rs:
+            r["caz"], r["cel"] = scan_next(scan_mode_code(r.get("scan_mode", "horizontal")), r["azimuth_range"],
+                                           r["azimuth_speed"], r["elevation_speed"], r["elevation_start"], r["caz"], r["cel"])
+
+    t_a = time.perf_counter(); tick(0); t_one = time.perf_counter() - t_a
+    ticks = int(max(2, min(2000, budget_s / max(t_one, 1e-6))))
+    t_a = time.perf_counter()
+    for k in range(1, 1 + ticks):
+        tick(k)
+    t_all = time.perf_counter() - t_a
+    return {"value": n * ticks / t_all, "unit": "entity-timesteps/s", "cores": cores, "cpu_model": cpu_model,
+            "kind": "port", "sample": f"scenario 0 of the batch ({n} entities, {len(rs)} radars), {ticks} ticks, "
+                                      f"oracle/zrk_oracle.c with the radar phase on {cores} OpenMP threads"}
+
+
 def main():
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
@@ -440,7 +487,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not ensemble:
             out["cpu_baseline"] = cpu_baseline(info, eng, args.cpu_budget)
         elif world == 1 and not args.no_cpu_baseline and ensemble:
-            out["cpu_baseline"] = eng.cpu_baseline(args.cpu_budget, usable_cores(), cpu_model())
+            out["cpu_baseline"] = cpu_baseline_ensemble(eng, args.cpu_budget, usable_cores(), cpu_model())
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

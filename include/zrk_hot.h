@@ -112,6 +112,13 @@ typedef struct {
 int zrk_abi_version(void);
 int zrk_ctx_create(int device, zrk_ctx **out);
 void zrk_ctx_destroy(zrk_ctx *ctx);
+/* Diagnostics: the tuning variables (ZRK_SWEEP_ORDER, ZRK_DIAG, ZRK_COMPACT_*) are read when a context is created;
+ * this reads them again. */
+void zrk_ctx_reload_env(zrk_ctx *ctx);
+/* zrk_run_ticks keeps, in the workspace, a bounding box per block of table rows between ticks (rows move along
+ * straight lines, so an old box grown by the block's top speed still holds them).  It notices rows appended to the
+ * table by itself; a caller that rewrites the trajectory or the alive flag of EXISTING rows says so here. */
+void zrk_ctx_invalidate_boxes(zrk_ctx *ctx);
 const char *zrk_last_error(zrk_ctx *ctx);
 
 /* Bytes of DEVICE scratch the sweep + compaction need for a table of capacity n_max (zrk_run_ticks finds its
@@ -303,6 +310,36 @@ int zrk_run_ticks_x(zrk_ctx *ctx, const zrk_entities *ents, const zrk_missiles *
                     int32_t *det_idx, int64_t det_stride, int32_t *det_cnt, int64_t *packed,
                     int64_t packed_capacity, const zrk_exchange_io *xio /* HOST, may be NULL */, int K,
                     float *sweep_ms /* HOST, may be NULL */, int prof_stride, void *stream);
+
+/*
+ * Batched Monte-Carlo ensemble (BASELINE configs[4]; no counterpart in the reference, which runs one scenario per
+ * process: main.py:151-174): S independent scenarios in ONE table, scenario s in rows [s * rows_per_scenario,
+ * (s + 1) * rows_per_scenario), each with its own `radars` SectorRadars, scan state, noise key, missiles and
+ * detection lists -- one sweep launch and one compaction launch per tick for all of them.  The radars live on the
+ * device: workgroups riding in the compaction move every scan on (modules/Radar.py:96-117, :205) and derive the
+ * next tick's records, so the host has no per-scenario work in the loop.  list_index is required and counts
+ * within the scenario; rows past a scenario's population are padding (alive = 0).  Missile rows name table rows.
+ */
+typedef struct {
+    int32_t scenarios;              /* S */
+    int32_t radars;                 /* R per scenario, <= ZRK_MAX_RADARS */
+    int64_t rows_per_scenario;      /* a multiple of 1024 */
+    zrk_radar *radar_state;         /* DEVICE [S][R], in/out: advanced by every tick */
+    const zrk_scan *scan;           /* DEVICE [S][R] */
+    const double *d2_max;           /* DEVICE [S][R]: zrk_d2_threshold(max_distance) of each radar */
+    const uint64_t *seeds;          /* DEVICE [S]: noise key of each scenario (zrk_loop.seed is not used) */
+    void *tables;                   /* DEVICE scratch, zrk_ensemble_table_bytes(S) */
+} zrk_ensemble;
+
+int64_t zrk_ensemble_table_bytes(int scenarios);
+/* The largest d2 whose correctly rounded square root is <= max_distance: `distance > max_distance`
+ * (modules/Radar.py:57) as a comparison of squares. */
+double zrk_d2_threshold(double max_distance);
+/* zrk_run_ticks for an ensemble.  det_idx: [S][R][det_stride] (scenario-local list indices), det_cnt: [S][R + 1];
+ * zrk_loop.n must be S * rows_per_scenario, gid0 0. */
+int zrk_run_ticks_ensemble(zrk_ctx *ctx, const zrk_entities *ents, const zrk_missiles *mis, int64_t m, zrk_loop *st,
+                           const zrk_ensemble *ens /* HOST */, void *workspace, int32_t *det_idx, int64_t det_stride,
+                           int32_t *det_cnt, int K, float *sweep_ms /* HOST, may be NULL */, int prof_stride, void *stream);
 
 /* Numerics self-test hooks used by tests/: y[i] = op(a[i], b[i]) in device binary64.
  * op: 0 sqrt(a), 1 a/b, 2 atan2(a,b), 3 asin(a), 4 fma-chain norm of (a,b,0). */

@@ -62,18 +62,21 @@ def factory(monkeypatch):
     def make(max_blocks=None, items=None):
         from zrk_modulation_amd.store import EntityStore
         if items is not None:
-            monkeypatch.setenv("ZRK_COMPACT_ITEMS", str(items))            # read at every launch
+            monkeypatch.setenv("ZRK_COMPACT_ITEMS", str(items))
         else:
             monkeypatch.delenv("ZRK_COMPACT_ITEMS", raising=False)
 
         def get():
-            if max_blocks not in _STORES:                                   # read when the context is created
-                if max_blocks is not None:
-                    monkeypatch.setenv("ZRK_COMPACT_FUSED_MAX_BLOCKS", str(max_blocks))
-                else:
-                    monkeypatch.delenv("ZRK_COMPACT_FUSED_MAX_BLOCKS", raising=False)
+            # the tuning variables are read when a context is created and by zrk_ctx_reload_env
+            if max_blocks is not None:
+                monkeypatch.setenv("ZRK_COMPACT_FUSED_MAX_BLOCKS", str(max_blocks))
+            else:
+                monkeypatch.delenv("ZRK_COMPACT_FUSED_MAX_BLOCKS", raising=False)
+            if max_blocks not in _STORES:
                 _STORES[max_blocks] = EntityStore("cuda:0", capacity=1 << 21)
-            return _STORES[max_blocks]
+            st = _STORES[max_blocks]
+            st.lib.zrk_ctx_reload_env(st.ctx.handle)
+            return st
         return get
     return make
 
@@ -160,11 +163,13 @@ def test_status_reports_a_foreign_workspace(factory):
     ws[:4] = torch.tensor([0x40, 0x42, 0x0F, 0x7F], dtype=torch.uint8, device=ws.device)    # a huge "ticket"
     import os
     os.environ["ZRK_COMPACT_ORDER"] = "ticket"
+    st.lib.zrk_ctx_reload_env(st.ctx.handle)
     try:
         with pytest.raises(ZrkError):
             _run(lambda: st, vis, 4)
     finally:
         os.environ.pop("ZRK_COMPACT_ORDER", None)
+        st.lib.zrk_ctx_reload_env(st.ctx.handle)
     det, cnt, packed = _run(lambda: st, vis, 4)               # cleared again on the next use
     _check(det, cnt, packed, vis, 4)
 

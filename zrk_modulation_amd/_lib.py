@@ -124,11 +124,26 @@ class ZrkExchangeIo(C.Structure):
     ]
 
 
+class ZrkEnsemble(C.Structure):
+    _fields_ = [
+        ("scenarios", C.c_int32),
+        ("radars", C.c_int32),
+        ("rows_per_scenario", C.c_int64),
+        ("radar_state", C.c_void_p),
+        ("scan", C.c_void_p),
+        ("d2_max", C.c_void_p),
+        ("seeds", C.c_void_p),
+        ("tables", C.c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); the exported surface of include/zrk_hot.h
 _PROTOTYPES = {
     "zrk_abi_version": (C.c_int, []),
     "zrk_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "zrk_ctx_destroy": (None, [C.c_void_p]),
+    "zrk_ctx_reload_env": (None, [C.c_void_p]),
+    "zrk_ctx_invalidate_boxes": (None, [C.c_void_p]),
     "zrk_last_error": (C.c_char_p, [C.c_void_p]),
     "zrk_workspace_bytes": (C.c_int64, [C.c_int64]),
     "zrk_tick_sweep": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.c_int64, C.c_int, C.c_int64,
@@ -149,6 +164,11 @@ _PROTOTYPES = {
                                   C.POINTER(ZrkLoop), C.POINTER(ZrkRadar), C.POINTER(ZrkScan), C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(ZrkExchangeIo),
                                   C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+    "zrk_run_ticks_ensemble": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.POINTER(ZrkMissiles), C.c_int64,
+                                         C.POINTER(ZrkLoop), C.POINTER(ZrkEnsemble), C.c_void_p, C.c_void_p, C.c_int64,
+                                         C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+    "zrk_ensemble_table_bytes": (C.c_int64, [C.c_int]),
+    "zrk_d2_threshold": (C.c_double, [C.c_double]),
     "zrk_exchange_unique_id": (C.c_int, [C.c_char_p, C.POINTER(ZrkRcclId)]),
     "zrk_exchange_create": (C.c_int, [C.c_char_p, C.POINTER(ZrkRcclId), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "zrk_exchange_destroy": (None, [C.c_void_p]),

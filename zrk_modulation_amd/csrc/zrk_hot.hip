@@ -118,11 +118,17 @@ struct SweepParams {
     int64_t gid0;
     int32_t R, nb;              // nb: sweep workgroups, behind the mb leading workgroups that step the missiles
     int32_t mb, _pad0;
-    WaveBox *boxes;             // per-wave box records (NULL: none kept), see WaveBox
+    WaveBox *boxes;             // per-block box records (NULL: none kept), see WaveBox
+    // batched ensemble of independent scenarios (zrk_run_ticks_ensemble): scenario s owns rows_ps consecutive rows
+    // (bps row blocks), its radar records are block s of rb_table, its noise key is seeds[s]; lists restart per scenario
+    const char *rb_table;       // DEVICE RadarBlock per scenario (NULL: one scenario, records in `rb` below)
+    const uint64_t *seeds;
+    int64_t rows_ps;
+    int32_t bps;
+    uint32_t bps_magic;         // ceil(2^32 / bps): block / bps == umulhi(block, magic) for block < 2^16
     uint32_t flags;
     RadarBlock rb;
 };
-constexpr size_t kColdOffset = offsetof(SweepParams, rb.cold);   // where the cold records sit in the kernel-argument segment
 
 // The missile phase rides along in other kernels' grids (its own launches would cost more in kernel
 // boundaries than in work): the per-row step as extra workgroups of the sweep, the ordered event list
@@ -211,6 +217,132 @@ __device__ __noinline__ bool visible_exact(uint64_t cold_record, double dx, doub
     const double az = floormod_small(atan2(dy, dx) * kRad2Deg, 360.0);
     const double el = floormod_small(asin(dz / dist) * kRad2Deg, 180.0);
     return (c.az_lo <= az) && (az <= c.az_hi) && (c.el_lo <= el) && (el <= c.el_hi);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-radar derivations, host and device: the host runs them for the radars of one scenario every tick (they
+// travel in the kernel-argument segment); for a batched ensemble of scenarios a workgroup riding in the compaction
+// runs them on the device for the next tick (k_compact_fused, EnsembleArgs).
+// ---------------------------------------------------------------------------------------------
+// CPython / numpy float floor-mod (modules/Radar.py:103, :109, :114, :117).
+__host__ __device__ inline double floormod_py(double a, double b)
+{
+    double m = fmod(a, b);
+    if (m != 0.0) {
+        if ((b < 0.0) != (m < 0.0)) m += b;
+    } else {
+        m = copysign(0.0, b);
+    }
+    return m;
+}
+
+// SectorRadar.move_to_next_sector_circular (modules/Radar.py:96-117) for one radar.
+__host__ __device__ inline void scan_advance_one(zrk_radar &rd, const zrk_scan &sc)
+{
+    if (sc.mode == 0) {            // "horizontal"
+        if (rd.cur_azimuth + rd.azimuth_range < 360.0) rd.cur_azimuth = floormod_py(rd.cur_azimuth + sc.azimuth_speed, 360.0);
+        else rd.cur_azimuth = sc.elevation_start;           // sic, modules/Radar.py:105
+        if (rd.cur_azimuth < sc.azimuth_speed) {
+            if (rd.cur_elevation + sc.elevation_speed < 90.0) rd.cur_elevation = floormod_py(rd.cur_elevation + sc.elevation_speed, 90.0);
+            else rd.cur_elevation = sc.elevation_start;
+        }
+    } else if (sc.mode == 1) {     // "vertical"
+        rd.cur_elevation = floormod_py(rd.cur_elevation + sc.elevation_speed, 90.0);
+        if (rd.cur_elevation < sc.elevation_speed) rd.cur_azimuth = floormod_py(rd.cur_azimuth + sc.azimuth_speed, 360.0);
+    }                               // any other mode string: the reference does nothing
+}
+
+__host__ __device__ inline void derive_radar(const zrk_radar &hr, double d2_max, bool exact_only, RadarHot &h, RadarCold &c)
+{
+    const double deg = 3.14159265358979323846 / 180.0;
+    h = RadarHot{};
+    h.px = hr.pos[0]; h.py = hr.pos[1]; h.pz = hr.pos[2];
+    c.d2_max = d2_max;                                  // d2_threshold(max_distance), from the host
+    c.az_lo = hr.cur_azimuth; c.az_hi = hr.cur_azimuth + hr.azimuth_range;
+    c.el_lo = hr.cur_elevation; c.el_hi = hr.cur_elevation + hr.elevation_range;
+    // float32 pre-gate: d2 computed in binary32 from rounded differences is within ~1e-6 relative.
+    // "always binary64" is encoded as d2f_in = -1 (every in-range pair counts as shell),
+    // "never visible" as d2f_out = -1 (nothing is in range).
+    const bool plain_range = __builtin_isfinite(c.d2_max) && c.d2_max > 0.0 && c.d2_max < 1e30;
+    h.d2f_in = plain_range ? (float)(c.d2_max * (1.0 - 1e-5)) : -1.f;
+    h.d2f_out = plain_range ? (float)(c.d2_max * (1.0 + 1e-5)) : INFINITY;
+    h.s_lo_up = h.s_lo_dn = 2.f; h.s_hi_up = h.s_hi_dn = -2.f;
+    c.s_lo_up = c.s_lo_dn = 2.0; c.s_hi_up = c.s_hi_dn = -2.0;
+    c.elx = c.ely = c.ehx = c.ehy = 0.0; c.az_sgn = 0.0;
+    h.az_guard = plain_range ? (float)(kGuard * sqrt(c.d2_max) * 1.001) : INFINITY;
+    h.az_sgn = 1.f;
+    const bool finite = __builtin_isfinite(c.az_lo) && __builtin_isfinite(c.az_hi) && __builtin_isfinite(c.el_lo) && __builtin_isfinite(c.el_hi);
+    if (!finite || exact_only) h.d2f_in = -1.f;   // decide every in-range pair in binary64
+    if (!finite) return;
+    // azimuth lives in [0, 360]; the comparison has no wrap-around (modules/Radar.py:67-68)
+    const double lo = fmax(c.az_lo, 0.0), hi = fmin(c.az_hi, 360.0);
+    if (!(lo <= hi) || c.d2_max < 0.0) { h.d2f_out = -1.f; return; }
+    // width <= 180: inside <=> cross(e_lo,p) > 0 and cross(p,e_hi) > 0; wider: either one, which is
+    // min(-c1,-c2) < 0, so the edges are stored negated and az_sgn = -1 flips the minimum back
+    h.az_sgn = (hi - lo <= 180.0) ? 1.f : -1.f;
+    h.elx = h.az_sgn * (float)cos(lo * deg); h.ely = h.az_sgn * (float)sin(lo * deg);
+    h.ehx = h.az_sgn * (float)cos(hi * deg); h.ehy = h.az_sgn * (float)sin(hi * deg);
+    c.az_sgn = exact_only ? 0.0 : (double)h.az_sgn;        // ZRK_F_EXACT_ONLY: the reference's formula and nothing else
+    c.elx = (double)h.az_sgn * cos(lo * deg); c.ely = (double)h.az_sgn * sin(lo * deg);
+    c.ehx = (double)h.az_sgn * cos(hi * deg); c.ehy = (double)h.az_sgn * sin(hi * deg);
+    // elevation: dz >= 0 -> el = theta in [0,90];  dz < 0 -> el = 180 + theta in [90,180]
+    const double lo_u = fmax(c.el_lo, 0.0), hi_u = fmin(c.el_hi, 90.0);
+    if (lo_u <= hi_u) {
+        h.s_lo_up = (c.el_lo <= 0.0) ? -2.f : (float)sin(lo_u * deg);
+        h.s_hi_up = (c.el_hi >= 90.0) ? 2.f : (float)sin(hi_u * deg);
+        c.s_lo_up = (c.el_lo <= 0.0) ? -2.0 : sin(lo_u * deg);
+        c.s_hi_up = (c.el_hi >= 90.0) ? 2.0 : sin(hi_u * deg);
+    }
+    const double lo_d = fmax(c.el_lo - 180.0, -90.0), hi_d = fmin(c.el_hi - 180.0, 0.0);
+    if (lo_d <= hi_d) {
+        h.s_lo_dn = (c.el_lo - 180.0 <= -90.0) ? -2.f : (float)sin(lo_d * deg);
+        h.s_hi_dn = (c.el_hi >= 180.0) ? 2.f : (float)sin(hi_d * deg);
+        c.s_lo_dn = (c.el_lo - 180.0 <= -90.0) ? -2.0 : sin(lo_d * deg);
+        c.s_hi_dn = (c.el_hi >= 180.0) ? 2.0 : sin(hi_d * deg);
+    }
+}
+
+// Bounds of the pre-pass.  Outside: a row that, seen from its position BEFORE this tick's noise, is farther than
+// d2_out from the radar or more than az_out outside the azimuth wedge cannot be in the sector whatever
+// happens earlier in the tick.  Inside: a box that keeps t_in metres from every face of the sector and whose
+// farthest corner is closer than sqrt(d2_in) holds only rows the radar certainly sees.  Slack: every detection
+// moves a row by at most kNoiseReach (Box-Muller on 16-bit uniforms: radius <= 5 * sqrt(-2 ln(2^-17)) = 24.3 m in
+// the x-y plane and along z, 34.4 m in space), and radar number `index` looks after at most `index` of them;
+// the distance to a wedge face and to the range sphere are 1-Lipschitz in the position, the elevation margins
+// dz -+ s * dist 2-Lipschitz.  Binary32 coordinates are off by 2^-24 relative per axis: covered by
+// 4e-6 * (|radar| + reach) + 1 m and the factor on the square.  Degenerate radars keep the encoding of their
+// hot record (d2f_out < 0: never visible; infinite: every row is a candidate) and are never "certainly inside".
+__host__ __device__ inline void derive_pre(const zrk_radar &hr, const RadarHot &h, bool philox, int index, RadarPre &p)
+{
+    constexpr double kNoiseReach = 34.4;
+    p = RadarPre{};
+    p.px = (float)hr.pos[0]; p.py = (float)hr.pos[1]; p.pz = (float)hr.pos[2];
+    p.elx = h.elx; p.ely = h.ely; p.ehx = h.ehx; p.ehy = h.ehy; p.az_sgn = h.az_sgn;
+    p.s_lo_up = h.s_lo_up; p.s_hi_up = h.s_hi_up; p.s_lo_dn = h.s_lo_dn; p.s_hi_dn = h.s_hi_dn;
+    p.az_out = INFINITY;
+    p.d2_in = -1.f; p.t_in = INFINITY; p.z_in = INFINITY; p.pz64 = hr.pos[2];
+    if (h.d2f_out < 0.f) { p.d2_out = -1.f; return; }
+    p.d2_out = INFINITY;
+    if (__builtin_isinf(h.d2f_out) || __builtin_isnan(h.d2f_out)) return;
+    const double reach = sqrt((double)h.d2f_out);
+    const double centre = fabs(hr.pos[0]) + fabs(hr.pos[1]) + fabs(hr.pos[2]);
+    if (!__builtin_isfinite(centre)) return;
+    const double slack = (philox ? kNoiseReach * (index > 0 ? index : 0) : 0.0) + 4e-6 * (centre + reach) + 1.0;
+    const double b = (reach + slack) * (reach + slack) * (1.0 + 1e-5);
+    if (b < 3e38) p.d2_out = (float)b;
+    const double a = ((double)h.az_guard + slack) * (1.0 + 1e-5);
+    if (__builtin_isfinite(a) && a < 3e38) p.az_out = (float)a;
+    // inside: only for radars whose every in-range pair may be settled in binary32 (d2f_in > 0)
+    if (h.d2f_in > 0.f) {
+        const double inner = sqrt((double)h.d2f_in) - slack;
+        const double t = ((double)h.az_guard + 2.0 * slack) * (1.0 + 1e-5);
+        if (inner > 0.0 && __builtin_isfinite(t) && t < 3e38) {
+            p.d2_in = (float)(inner * inner * (1.0 - 1e-5));
+            p.t_in = (float)t;
+            // along z a draw moves a row by at most 24.3 m
+            p.z_in = (float)(((philox ? 24.3 * (index > 0 ? index : 0) : 0.0) + 4e-6 * (centre + reach) + 1.0) * (1.0 + 1e-5));
+        }
+    }
 }
 
 // Philox4x32-10, counter (entity lo, entity hi, tick, radar), key = seed.
@@ -351,9 +483,9 @@ struct PreTable {
 // Issued as the wave's first vector load and waited for by count (stage_pre_table: all but the `younger` loads
 // issued since), so that the row loads behind it stay in flight; the compiler does not see the load and would
 // otherwise sink it below them and wait for everything.
-__device__ __forceinline__ uint4 pre_table_fetch()
+__device__ __forceinline__ uint4 pre_table_fetch(const char *rbp)
 {
-    const char *tab = (const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SweepParams, rb.prew);
+    const char *tab = rbp + offsetof(RadarBlock, prew);
     const uint32_t off = (threadIdx.x < kPreVec ? threadIdx.x : 0u) * 16u;
     uint4 piece;
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(piece) : "v"(off), "s"(tab) : "memory");
@@ -465,9 +597,10 @@ __device__ __forceinline__ Cull cull_box(const PreTable &T, int R, bool shortcut
 // Radars in `c.cand`, in order, over the wave's rows at (x, y, z); leaves the visibility mask in `mask` and the
 // (perturbed) position in place.  Called with the whole wave converged (the early-outs are wave-level votes).
 template <bool PHILOX>
-__device__ __forceinline__ void sweep_rows(const SweepParams &P, const Cull &c, int64_t li, bool live, double &x, double &y,
-                                           double &z, uint32_t &mask, int64_t probe_wave)
+__device__ __forceinline__ void sweep_rows(const SweepParams &P, const char *rbp, uint64_t seed, const Cull &c, int64_t li,
+                                           bool live, double &x, double &y, double &z, uint32_t &mask, int64_t probe_wave)
 {
+    typedef const uint32_t __attribute__((address_space(4))) *ConstWords;
     // keyed by list index: layout-independent.  Seeded when the first lane of the wave is detected -- in
     // spatial order most waves never are, and the ten Philox rounds are a fifth of a quiet wave's work.
     NoiseState ns = NoiseState{0u, 0u, 0u, 0u};
@@ -484,7 +617,7 @@ __device__ __forceinline__ void sweep_rows(const SweepParams &P, const Cull &c, 
                                                                (uint32_t)__builtin_amdgcn_readlane((int)c.pz_lo, r));
             const bool vis = live & (!by_plane | (z - rpz >= 0.0));
             if (PHILOX && !seeded && __ballot(vis)) {
-                ns = noise_init(P.seed, P.tick, (uint64_t)(P.gid0 + li));
+                ns = noise_init(seed, P.tick, (uint64_t)(P.gid0 + li));
                 seeded = true;
             }
             if (vis) {
@@ -499,8 +632,9 @@ __device__ __forceinline__ void sweep_rows(const SweepParams &P, const Cull &c, 
         }
         // one scalar-load burst for the whole hot record, resident in SGPRs before any use
         uint32_t w[18];
+        const ConstWords hw = (ConstWords)(uint64_t)(rbp + offsetof(RadarBlock, hotw) + (size_t)r * sizeof(RadarHot));
 #pragma unroll
-        for (int k = 0; k < 18; ++k) w[k] = P.rb.hotw[r][k];
+        for (int k = 0; k < 18; ++k) w[k] = hw[k];
         asm volatile("" ::"s"(w[0]), "s"(w[1]), "s"(w[2]), "s"(w[3]), "s"(w[4]), "s"(w[5]), "s"(w[6]), "s"(w[7]),
                      "s"(w[8]), "s"(w[9]), "s"(w[10]), "s"(w[11]), "s"(w[12]), "s"(w[13]), "s"(w[14]), "s"(w[15]),
                      "s"(w[16]), "s"(w[17]));
@@ -544,9 +678,9 @@ __device__ __forceinline__ void sweep_rows(const SweepParams &P, const Cull &c, 
         const float gd = kGuard * dist;
         bool vis = in_range & (t > gd);
         const bool amb = in_range & ((fabsf(t) <= gd) | !(d2f < d2f_in));
-        if (amb) vis = visible_exact((uint64_t)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + kColdOffset + (size_t)r * sizeof(RadarCold)), dx, dy, dz);
+        if (amb) vis = visible_exact((uint64_t)(rbp + offsetof(RadarBlock, cold) + (size_t)r * sizeof(RadarCold)), dx, dy, dz);
         if (PHILOX && !seeded && __ballot(vis)) {
-            ns = noise_init(P.seed, P.tick, (uint64_t)(P.gid0 + li));
+            ns = noise_init(seed, P.tick, (uint64_t)(P.gid0 + li));
             seeded = true;
         }
         if (vis) {
@@ -588,8 +722,18 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     }
     const int64_t wave = (int64_t)blk * (ZRK_BLOCK / 64) + (tid >> 6);
     const int64_t cap = P.cap;
+    // one scenario: the radar records travel in this launch's kernel-argument segment; a batched ensemble: block `scen`
+    // of a table in device memory (written by the previous tick's compaction launch), its own noise key, its own lists
+    const int scen = P.bps ? (int)__umulhi((uint32_t)blk, P.bps_magic) : 0;
+    const char *rbp = P.rb_table ? P.rb_table + (size_t)scen * sizeof(RadarBlock)
+                                 : (const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SweepParams, rb);
+    uint64_t seed = P.seed;
+    if (P.seeds) {
+        const uint64_t *ps = P.seeds + scen;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seed) : "s"(ps) : "memory");
+    }
     __shared__ PreTable s_pre;
-    uint4 pre_piece = pre_table_fetch();
+    uint4 pre_piece = pre_table_fetch(rbp);
     ZRK_WAVE_PROBE(wave, 0, wall_clock64());
     // where the wave runs: HW_REG_HW_ID (wave / simd / cu / sh / se) and HW_REG_XCC_ID
     ZRK_WAVE_PROBE(wave, 6, (long long)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
@@ -609,7 +753,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
         sx0 = P.pos[ic]; sy0 = P.pos[cap + ic]; sz0 = P.pos[2 * cap + ic];
     }
     const bool live = (i < P.n) & (al != 0);
-    const int64_t li = (LIDX && i < P.n) ? (int64_t)lix : i;     // where this row sits in AirEnv's list
+    const int64_t li = (LIDX && i < P.n) ? (int64_t)lix : i;     // where this row sits in (its scenario's) AirEnv list
     // the wave's box record, if the caller keeps any (zrk_run_ticks does): twelve scalar words
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 b0 = {0u, 0u, 0u, 0u}, b1 = {0u, 0u, 0u, 0u}, bv = {0u, 0u, 0u, 0u};     // lo[3] hi[0] | hi[1..2] vmax[0..1] | vmax[2] state t_ref
@@ -724,7 +868,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     const int walked = __builtin_popcount(c.cand);     // wave-uniform: what this wave costs, for next tick's order
     ZRK_WAVE_PROBE(wave, 7, (long long)(walked | (__builtin_popcount(c.inside) << 8) | (__builtin_popcount(c.plane) << 16) | ((int)have << 24)));
     uint32_t mask = 0u;
-    if (walked) sweep_rows<PHILOX>(P, c, li, live, x, y, z, mask, wave);
+    if (walked) sweep_rows<PHILOX>(P, rbp, seed, c, li, live, x, y, z, mask, wave);
     if (P.cost && walked && (tid & 63) == 0) atomicAdd(&P.cost[blk], walked);
     ZRK_WAVE_PROBE(wave, 2, wall_clock64());
     ZRK_WAVE_PROBE(wave, 4, (long long)__popcll(__ballot(mask != 0)));
@@ -733,7 +877,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     }
     // sparse mode: the buffer is known to be all zero (the previous tick's compaction cleared it), so only
     // detections are written -- list-indexed stores are scattered when the table is spatially sorted
-    if (i < P.n && (mask || !(P.flags & kSparseVis))) P.vis[li] = mask;
+    if (i < P.n && (mask || !(P.flags & kSparseVis))) P.vis[(int64_t)scen * P.rows_ps + li] = mask;
     ZRK_WAVE_PROBE(wave, 3, wall_clock64());
 }
 
@@ -997,6 +1141,10 @@ struct CompactArgs {
     int64_t *packed;
     int64_t packed_capacity, gid0;
     UnionBits bits;
+    // batched ensemble: the lists restart every seg_blocks workgroups (= seg_slots list slots, one scenario); radar r
+    // of scenario s writes to det_idx[(s * R + r) * det_stride ...], counts to det_cnt[s * (R + 1) + r]; 0: one list
+    int32_t seg_blocks, _pad1;
+    int64_t seg_slots;
 };
 
 template <int THREADS>
@@ -1024,6 +1172,9 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
         return;
     }
     const int64_t blk0 = (int64_t)b * C.items * THREADS;
+    const int seg = C.seg_blocks ? b / C.seg_blocks : 0;          // scenario of this workgroup
+    const int first = seg * C.seg_blocks;                         // its first workgroup: nobody before it counts
+    const bool last_of_seg = C.seg_blocks ? (b == first + C.seg_blocks - 1) : (b == C.nb - 1);
     ZRK_PROBE(0);
     uint32_t mk[kFusedMaxItems];
 #pragma unroll
@@ -1105,7 +1256,7 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
         int acc = 0;
         bool timed_out = false;
         if (c <= C.R) {
-            for (int p0 = p_first; p0 < b; p0 += p_step * kBatch) {
+            for (int p0 = first + p_first; p0 < b; p0 += p_step * kBatch) {
                 unsigned long long v[kBatch];
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u) {
@@ -1141,7 +1292,8 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
     if (C.det_idx) {
         for (int r = wave; r < C.R; r += (THREADS / 64)) {
             int run = S.pre[r];
-            int32_t *out = C.det_idx + (int64_t)r * C.det_stride;
+            int32_t *out = C.det_idx + ((int64_t)seg * C.R + r) * C.det_stride;
+            const int32_t slot0 = C.base_index + (int32_t)(blk0 - (int64_t)seg * C.seg_slots);
             for (int c = 0; c < found; c += 256) {     // four steps of 64 entries, their LDS reads in flight together
                 uint32_t q[4];
                 unsigned short ix[4];
@@ -1157,16 +1309,16 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
                     const unsigned long long bb = __ballot(bit);
                     if (bit) {
                         const int64_t dst = (int64_t)run + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u));
-                        if (dst < C.det_stride) out[dst] = C.base_index + (int32_t)(blk0 + ix[u]);
+                        if (dst < C.det_stride) out[dst] = slot0 + (int32_t)ix[u];
                     }
                     run += (int)__popcll(bb);
                 }
             }
         }
     }
-    if (b == C.nb - 1 && tid <= C.R) {                 // the end of the list: totals
+    if (last_of_seg && tid <= C.R) {                   // the end of the (scenario's) list: totals
         const int tot = S.pre[tid] + S.cnt[tid];
-        if (C.det_cnt) C.det_cnt[tid] = tot;
+        if (C.det_cnt) C.det_cnt[(int64_t)seg * (C.R + 1) + tid] = tot;
         if (C.packed && tid == C.R) {
             C.packed[0] = tot;
             if (C.bits.words) C.packed[1] = C.n;
@@ -1181,14 +1333,58 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
     }
 }
 
+// Batched ensemble: the radars of every scenario live on the device.  One thread per (scenario, radar slot) moves
+// the scan on (SectorRadar.move_to_next_sector_circular, modules/Radar.py:96-117, :205) and derives the records the
+// NEXT tick's sweep reads -- as extra workgroups of this tick's compaction, so that the host has no per-scenario
+// work in the loop at all.
+struct EnsembleArgs {
+    zrk_radar *state;            // [S][R] current angles, in/out
+    const zrk_scan *scan;        // [S][R]
+    const double *d2max;         // [S][R] d2_threshold(max_distance)
+    RadarBlock *table_out;       // [S]
+    int32_t S, R;
+    uint32_t flags;              // ZRK_F_PHILOX / ZRK_F_EXACT_ONLY
+    int32_t advance;             // 0: records for the angles as they are
+};
+
+__device__ void ensemble_derive(const EnsembleArgs &E, int part)
+{
+    const int64_t g = (int64_t)part * blockDim.x + threadIdx.x;
+    if (g >= (int64_t)E.S * ZRK_MAX_RADARS) return;
+    const int sc = (int)(g / ZRK_MAX_RADARS), r = (int)(g % ZRK_MAX_RADARS);
+    RadarBlock *rb = E.table_out + sc;
+    RadarPre pre = RadarPre{};
+    pre.d2_out = -1.f;                                  // beyond R: nobody is a candidate
+    if (r < E.R) {
+        zrk_radar rd = E.state[(int64_t)sc * E.R + r];
+        if (E.advance) {
+            scan_advance_one(rd, E.scan[(int64_t)sc * E.R + r]);
+            E.state[(int64_t)sc * E.R + r] = rd;
+        }
+        RadarHot hot;
+        RadarCold cold;
+        derive_radar(rd, E.d2max[(int64_t)sc * E.R + r], (E.flags & ZRK_F_EXACT_ONLY) != 0, hot, cold);
+        derive_pre(rd, hot, (E.flags & ZRK_F_PHILOX) != 0, r, pre);
+        rb->cold[r] = cold;
+        const uint32_t *hwords = (const uint32_t *)&hot;
+        for (int k = 0; k < 20; ++k) rb->hotw[r][k] = hwords[k];
+    }
+    const uint32_t *pwords = (const uint32_t *)&pre;
+    for (int k = 0; k < 20; ++k) rb->prew[r][k] = pwords[k];
+}
+
+__global__ __launch_bounds__(kCompBlock) void k_ensemble_derive(const EnsembleArgs E) { ensemble_derive(E, (int)blockIdx.x); }
+
 __global__ __launch_bounds__(kCompBlock) void k_compact_fused(const CompactArgs C, int by_ticket, const MissileArgs M,
-                                                              const OrderArgs O)
+                                                              const OrderArgs O, const EnsembleArgs E)
 {
     __shared__ int s_wave[kCompBlock / 64];
     __shared__ CompactShared<kCompBlock> S;
-    if ((int)blockIdx.x >= C.nb) {                 // extra workgroups: missile events + tombstones, sweep order
-        if ((int)blockIdx.x == C.nb && M.m > 0) missile_finish_entry(s_wave, M);
-        else build_order(s_wave, O);
+    if ((int)blockIdx.x >= C.nb) {                 // extra workgroups: missile events + tombstones, sweep order, radars
+        int extra = (int)blockIdx.x - C.nb;
+        if (M.m > 0 && extra-- == 0) { missile_finish_entry(s_wave, M); return; }
+        if (O.nb > 0 && extra-- == 0) { build_order(s_wave, O); return; }
+        if (E.S > 0) ensemble_derive(E, extra);
         return;
     }
     compact_block<kCompBlock>(S, C, by_ticket);
@@ -1510,98 +1706,6 @@ double d2_threshold(double m)
     return c;
 }
 
-void derive_radar(const zrk_radar &hr, bool exact_only, RadarHot &h, RadarCold &c)
-{
-    const double deg = 3.14159265358979323846 / 180.0;
-    std::memset(&h, 0, sizeof(h));
-    h.px = hr.pos[0]; h.py = hr.pos[1]; h.pz = hr.pos[2];
-    c.d2_max = d2_threshold(hr.max_distance);
-    c.az_lo = hr.cur_azimuth; c.az_hi = hr.cur_azimuth + hr.azimuth_range;
-    c.el_lo = hr.cur_elevation; c.el_hi = hr.cur_elevation + hr.elevation_range;
-    // float32 pre-gate: d2 computed in binary32 from rounded differences is within ~1e-6 relative.
-    // "always binary64" is encoded as d2f_in = -1 (every in-range pair counts as shell),
-    // "never visible" as d2f_out = -1 (nothing is in range).
-    const bool plain_range = std::isfinite(c.d2_max) && c.d2_max > 0.0 && c.d2_max < 1e30;
-    h.d2f_in = plain_range ? (float)(c.d2_max * (1.0 - 1e-5)) : -1.f;
-    h.d2f_out = plain_range ? (float)(c.d2_max * (1.0 + 1e-5)) : INFINITY;
-    h.s_lo_up = h.s_lo_dn = 2.f; h.s_hi_up = h.s_hi_dn = -2.f;
-    c.s_lo_up = c.s_lo_dn = 2.0; c.s_hi_up = c.s_hi_dn = -2.0;
-    c.elx = c.ely = c.ehx = c.ehy = 0.0; c.az_sgn = 0.0;
-    h.az_guard = plain_range ? (float)(kGuard * std::sqrt(c.d2_max) * 1.001) : INFINITY;
-    h.az_sgn = 1.f;
-    const bool finite = std::isfinite(c.az_lo) && std::isfinite(c.az_hi) && std::isfinite(c.el_lo) && std::isfinite(c.el_hi);
-    if (!finite || exact_only) h.d2f_in = -1.f;   // decide every in-range pair in binary64
-    if (!finite) return;
-    // azimuth lives in [0, 360]; the comparison has no wrap-around (modules/Radar.py:67-68)
-    const double lo = std::fmax(c.az_lo, 0.0), hi = std::fmin(c.az_hi, 360.0);
-    if (!(lo <= hi) || c.d2_max < 0.0) { h.d2f_out = -1.f; return; }
-    // width <= 180: inside <=> cross(e_lo,p) > 0 and cross(p,e_hi) > 0; wider: either one, which is
-    // min(-c1,-c2) < 0, so the edges are stored negated and az_sgn = -1 flips the minimum back
-    h.az_sgn = (hi - lo <= 180.0) ? 1.f : -1.f;
-    h.elx = h.az_sgn * (float)std::cos(lo * deg); h.ely = h.az_sgn * (float)std::sin(lo * deg);
-    h.ehx = h.az_sgn * (float)std::cos(hi * deg); h.ehy = h.az_sgn * (float)std::sin(hi * deg);
-    c.az_sgn = exact_only ? 0.0 : (double)h.az_sgn;        // ZRK_F_EXACT_ONLY: the reference's formula and nothing else
-    c.elx = (double)h.az_sgn * std::cos(lo * deg); c.ely = (double)h.az_sgn * std::sin(lo * deg);
-    c.ehx = (double)h.az_sgn * std::cos(hi * deg); c.ehy = (double)h.az_sgn * std::sin(hi * deg);
-    // elevation: dz >= 0 -> el = theta in [0,90];  dz < 0 -> el = 180 + theta in [90,180]
-    const double lo_u = std::fmax(c.el_lo, 0.0), hi_u = std::fmin(c.el_hi, 90.0);
-    if (lo_u <= hi_u) {
-        h.s_lo_up = (c.el_lo <= 0.0) ? -2.f : (float)std::sin(lo_u * deg);
-        h.s_hi_up = (c.el_hi >= 90.0) ? 2.f : (float)std::sin(hi_u * deg);
-        c.s_lo_up = (c.el_lo <= 0.0) ? -2.0 : std::sin(lo_u * deg);
-        c.s_hi_up = (c.el_hi >= 90.0) ? 2.0 : std::sin(hi_u * deg);
-    }
-    const double lo_d = std::fmax(c.el_lo - 180.0, -90.0), hi_d = std::fmin(c.el_hi - 180.0, 0.0);
-    if (lo_d <= hi_d) {
-        h.s_lo_dn = (c.el_lo - 180.0 <= -90.0) ? -2.f : (float)std::sin(lo_d * deg);
-        h.s_hi_dn = (c.el_hi >= 180.0) ? 2.f : (float)std::sin(hi_d * deg);
-        c.s_lo_dn = (c.el_lo - 180.0 <= -90.0) ? -2.0 : std::sin(lo_d * deg);
-        c.s_hi_dn = (c.el_hi >= 180.0) ? 2.0 : std::sin(hi_d * deg);
-    }
-}
-
-// Bounds of the pre-pass.  Outside: a row that, seen from its position BEFORE this tick's noise, is farther than
-// d2_out from the radar or more than az_out outside the azimuth wedge cannot be in the sector whatever
-// happens earlier in the tick.  Inside: a box that keeps t_in metres from every face of the sector and whose
-// farthest corner is closer than sqrt(d2_in) holds only rows the radar certainly sees.  Slack: every detection
-// moves a row by at most kNoiseReach (Box-Muller on 16-bit uniforms: radius <= 5 * sqrt(-2 ln(2^-17)) = 24.3 m in
-// the x-y plane and along z, 34.4 m in space), and radar number `index` looks after at most `index` of them;
-// the distance to a wedge face and to the range sphere are 1-Lipschitz in the position, the elevation margins
-// dz -+ s * dist 2-Lipschitz.  Binary32 coordinates are off by 2^-24 relative per axis: covered by
-// 4e-6 * (|radar| + reach) + 1 m and the factor on the square.  Degenerate radars keep the encoding of their
-// hot record (d2f_out < 0: never visible; infinite: every row is a candidate) and are never "certainly inside".
-void derive_pre(const zrk_radar &hr, const RadarHot &h, bool philox, int index, RadarPre &p)
-{
-    constexpr double kNoiseReach = 34.4;
-    std::memset(&p, 0, sizeof(p));
-    p.px = (float)hr.pos[0]; p.py = (float)hr.pos[1]; p.pz = (float)hr.pos[2];
-    p.elx = h.elx; p.ely = h.ely; p.ehx = h.ehx; p.ehy = h.ehy; p.az_sgn = h.az_sgn;
-    p.s_lo_up = h.s_lo_up; p.s_hi_up = h.s_hi_up; p.s_lo_dn = h.s_lo_dn; p.s_hi_dn = h.s_hi_dn;
-    p.az_out = INFINITY;
-    p.d2_in = -1.f; p.t_in = INFINITY; p.z_in = INFINITY; p.pz64 = hr.pos[2];
-    if (h.d2f_out < 0.f) { p.d2_out = -1.f; return; }
-    p.d2_out = INFINITY;
-    if (std::isinf(h.d2f_out) || std::isnan(h.d2f_out)) return;
-    const double reach = std::sqrt((double)h.d2f_out);
-    const double centre = std::fabs(hr.pos[0]) + std::fabs(hr.pos[1]) + std::fabs(hr.pos[2]);
-    if (!std::isfinite(centre)) return;
-    const double slack = (philox ? kNoiseReach * std::max(index, 0) : 0.0) + 4e-6 * (centre + reach) + 1.0;
-    const double b = (reach + slack) * (reach + slack) * (1.0 + 1e-5);
-    if (b < 3e38) p.d2_out = (float)b;
-    const double a = ((double)h.az_guard + slack) * (1.0 + 1e-5);
-    if (std::isfinite(a) && a < 3e38) p.az_out = (float)a;
-    // inside: only for radars whose every in-range pair may be settled in binary32 (d2f_in > 0)
-    if (h.d2f_in > 0.f) {
-        const double inner = std::sqrt((double)h.d2f_in) - slack;
-        const double t = ((double)h.az_guard + 2.0 * slack) * (1.0 + 1e-5);
-        if (inner > 0.0 && std::isfinite(t) && t < 3e38) {
-            p.d2_in = (float)(inner * inner * (1.0 - 1e-5));
-            p.t_in = (float)t;
-            // along z a draw moves a row by at most 24.3 m
-            p.z_in = (float)(((philox ? 24.3 * std::max(index, 0) : 0.0) + 4e-6 * (centre + reach) + 1.0) * (1.0 + 1e-5));
-        }
-    }
-}
 
 }  // namespace
 
@@ -1615,11 +1719,24 @@ struct zrk_ctx {
     int order_nb = 0;                  // ... for this many row blocks
     bool order_ready = false;
     bool order_enabled = true;
+    int env_items = 0;                 // ZRK_COMPACT_ITEMS (0: automatic), read once: getenv per launch costs microseconds
+    int env_order = -1;                // ZRK_COMPACT_ORDER: 0 "block", 1 anything else, -1 automatic
     uint32_t diag = 0;                 // ZRK_DIAG: bit 0 no "certainly visible" shortcut, bit 1 no box records
     const void *box_ws = nullptr;      // workspace whose box records belong to ...
     const void *box_key = nullptr;     // ... this table (its start_pos column) ...
     int64_t box_n = 0;                 // ... up to this many rows
     std::string err;
+    // d2_threshold(max_distance) per radar slot: static for a radar, not worth a search every tick
+    uint64_t d2_key[ZRK_MAX_RADARS] = {};
+    double d2_val[ZRK_MAX_RADARS] = {};
+    bool d2_set[ZRK_MAX_RADARS] = {};
+    double d2_of(double max_distance, int r)
+    {
+        uint64_t key;
+        std::memcpy(&key, &max_distance, sizeof(key));
+        if (!d2_set[r] || d2_key[r] != key) { d2_key[r] = key; d2_val[r] = d2_threshold(max_distance); d2_set[r] = true; }
+        return d2_val[r];
+    }
     std::vector<hipEvent_t> tev;       // timing events of zrk_run_ticks, reused
     const void *ring_key = nullptr;    // mask buffers zrk_run_ticks has been alternating between ...
     int64_t ring_age = 0;              // ... for this many consecutive ticks (>= 1: the next one starts cleared)
@@ -1687,6 +1804,26 @@ ZRK_API int zrk_debug_wave_probe(long long *buf)
 
 ZRK_API int zrk_abi_version(void) { return ZRK_ABI_VERSION; }
 
+ZRK_API void zrk_ctx_invalidate_boxes(zrk_ctx *ctx)
+{
+    if (ctx) { ctx->box_ws = nullptr; ctx->box_n = 0; }
+}
+
+ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
+{
+    if (!c) return;
+    c->order_enabled = true; c->diag = 0; c->env_items = 0; c->env_order = -1;
+    if (const char *v = std::getenv("ZRK_SWEEP_ORDER")) c->order_enabled = std::atoi(v) != 0;
+    if (const char *v = std::getenv("ZRK_DIAG")) c->diag = (uint32_t)std::strtoul(v, nullptr, 0);
+    if (const char *v = std::getenv("ZRK_COMPACT_ITEMS")) c->env_items = std::max(1, std::atoi(v));
+    if (const char *v = std::getenv("ZRK_COMPACT_ORDER")) c->env_order = std::strcmp(v, "block") != 0;
+    c->fused_max_blocks = kFusedMaxBlocks;
+    if (const char *v = std::getenv("ZRK_COMPACT_FUSED_MAX_BLOCKS")) {     // 0 = always the three-launch path
+        const long k = std::strtol(v, nullptr, 10);
+        c->fused_max_blocks = (int)std::min<long>(std::max<long>(k, 0), kFusedMaxBlocks);
+    }
+}
+
 ZRK_API int zrk_ctx_create(int device, zrk_ctx **out)
 {
     if (!out) return ZRK_E_INVALID;
@@ -1698,13 +1835,7 @@ ZRK_API int zrk_ctx_create(int device, zrk_ctx **out)
     c->device = device;
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = cus;
-    if (const char *v = std::getenv("ZRK_SWEEP_ORDER")) c->order_enabled = std::atoi(v) != 0;
-    if (const char *v = std::getenv("ZRK_DIAG")) c->diag = (uint32_t)std::strtoul(v, nullptr, 0);
-    c->fused_max_blocks = kFusedMaxBlocks;
-    if (const char *v = std::getenv("ZRK_COMPACT_FUSED_MAX_BLOCKS")) {     // 0 = always the three-launch path
-        const long k = std::strtol(v, nullptr, 10);
-        c->fused_max_blocks = (int)std::min<long>(std::max<long>(k, 0), kFusedMaxBlocks);
-    }
+    zrk_ctx_reload_env(c);
     *out = c;
     return 0;
 }
@@ -1749,12 +1880,21 @@ MissileArgs missile_args(const zrk_entities *e, int cur, const zrk_missiles *mis
     return M;
 }
 
+// What a batched ensemble adds to the two launches of a tick.
+struct EnsLaunch {
+    const char *rb_table;          // this tick's records, [S] RadarBlock
+    const uint64_t *seeds;
+    int64_t rows_ps;
+    int32_t bps, items;            // sweep row blocks / compaction workgroups... per scenario: rows_ps / (1024 * items)
+    EnsembleArgs next;             // what the compaction's extra workgroups derive for the next tick
+};
+
 int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_t time_ms, const zrk_radar *radars,
                  int R, uint32_t flags, uint64_t seed, uint64_t tick, int64_t gid0, void *workspace, void *stream,
                  const MissileArgs &M, uint32_t *vis = nullptr, int32_t *cost = nullptr, const int32_t *order = nullptr,
-                 WaveBox *boxes = nullptr)
+                 WaveBox *boxes = nullptr, const EnsLaunch *ens = nullptr)
 {
-    if (!ctx || !e || !workspace || (R > 0 && !radars)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
+    if (!ctx || !e || !workspace || (R > 0 && !radars && !ens)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
     if (R < 0 || R > ZRK_MAX_RADARS)
         return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: radar count out of range");
     if (n < 0 || n > e->capacity || (cur != 0 && cur != 1)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: n/cur out of range");
@@ -1769,16 +1909,19 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
     P.R = R; P.nb = nblocks(n, ZRK_BLOCK); P.flags = flags;
     P.mb = nblocks(M.m, ZRK_BLOCK); P._pad0 = 0;
     P.boxes = boxes;
+    P.rb_table = ens ? ens->rb_table : nullptr; P.seeds = ens ? ens->seeds : nullptr;
+    P.rows_ps = ens ? ens->rows_ps : 0; P.bps = ens ? ens->bps : 0;
+    P.bps_magic = ens ? (uint32_t)((0x100000000ull + (uint64_t)ens->bps - 1) / (uint64_t)ens->bps) : 0u;
     if (ctx->diag & 1u) P.flags |= kNoInside;
     if (ctx->diag & 2u) P.flags |= kNoBoxCache;
     std::memset(&P.rb, 0, sizeof(P.rb));
-    for (int r = 0; r < ZRK_MAX_RADARS; ++r) {
+    for (int r = 0; r < ZRK_MAX_RADARS && !ens; ++r) {
         RadarPre pre;
         std::memset(&pre, 0, sizeof(pre));
         pre.d2_out = -1.f;                                  // beyond R: nobody is a candidate
         if (r < R) {
             RadarHot hot;
-            derive_radar(radars[r], (flags & ZRK_F_EXACT_ONLY) != 0, hot, P.rb.cold[r]);
+            derive_radar(radars[r], ctx->d2_of(radars[r].max_distance, r), (flags & ZRK_F_EXACT_ONLY) != 0, hot, P.rb.cold[r]);
             std::memcpy(P.rb.hotw[r], &hot, sizeof(hot));
             derive_pre(radars[r], hot, (flags & ZRK_F_PHILOX) != 0, r, pre);
         }
@@ -1810,7 +1953,7 @@ namespace {
 int fused_items(const zrk_ctx *ctx, int64_t n)
 {
     int items = (int)std::min<int64_t>(kFusedMaxItems, std::max<int64_t>(1, (n + (int64_t)kCompBlock * ctx->cus - 1) / ((int64_t)kCompBlock * ctx->cus)));
-    if (const char *v = std::getenv("ZRK_COMPACT_ITEMS")) items = std::min(kFusedMaxItems, std::max(1, std::atoi(v)));
+    if (ctx->env_items > 0) items = std::min(kFusedMaxItems, ctx->env_items);
     return items;
 }
 
@@ -1823,7 +1966,7 @@ bool compacts_in_one_launch(const zrk_ctx *ctx, int64_t n)
 int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int32_t base_index, void *workspace,
                    int32_t *det_idx, int64_t det_stride, int32_t *det_cnt, int64_t *packed, int64_t packed_capacity,
                    int64_t gid0, void *stream, const MissileArgs &M, uint32_t *zero_next, const OrderArgs &O,
-                   bool union_bits = false)
+                   bool union_bits = false, const EnsLaunch *ens = nullptr)
 {
     if (!ctx || !vis_mask || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_compact: null argument");
     if ((det_idx && !det_cnt) || (!det_idx && !packed)) return fail(ctx, ZRK_E_INVALID, "zrk_compact: no output requested");
@@ -1845,9 +1988,11 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         return 0;
     }
     // single launch: about one workgroup per compute unit, each thread holding up to kFusedMaxItems slots
-    const int items = fused_items(ctx, n);
+    const int items = ens ? ens->items : fused_items(ctx, n);
     const int64_t nbf = (n + (int64_t)kCompBlock * items - 1) / ((int64_t)kCompBlock * items);
-    if (compacts_in_one_launch(ctx, n)) {
+    if (ens && (packed || nbf > kFusedMaxBlocks || nbf > ctx->fused_max_blocks))
+        return fail(ctx, ZRK_E_INVALID, "zrk_compact: an ensemble takes the single-launch path and has no union list");
+    if (ens || compacts_in_one_launch(ctx, n)) {
         Workspace w = carve(workspace, 0, n);
         if (ctx->fused_ws != workspace) {          // first use by this context: no ticket, no record, no error
             if (hipMemsetAsync(workspace, 0, kFusedBytes, s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "memset workspace");
@@ -1861,14 +2006,20 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         // (in practice workgroups are dispatched in index order, which is what makes waiting in index order safe on an
         // idle device; a union list means other ranks' collectives share the device, so there nothing is assumed)
         int by_ticket = nbf > 2 * (int64_t)ctx->cus || packed != nullptr;
-        if (const char *v = std::getenv("ZRK_COMPACT_ORDER")) by_ticket = std::strcmp(v, "block") != 0;
+        if (ctx->env_order >= 0) by_ticket = ctx->env_order;
         CompactArgs C;
         C.vis = vis_mask; C.zero_next = zero_next; C.n = n; C.R = R; C.nb = (int)nbf; C.items = items; C.lanes = lanes;
         C.epoch = ctx->epoch; C.base_index = base_index; C.ctl = w.ctl; C.agg = w.agg; C.det_idx = det_idx;
         C.det_stride = det_stride; C.det_cnt = det_cnt; C.packed = packed; C.packed_capacity = packed_capacity; C.gid0 = gid0;
         C.bits = U;
-        hipLaunchKernelGGL(k_compact_fused, dim3((int)nbf + (M.m > 0 ? 1 : 0) + (O.nb > 0 ? 1 : 0)), dim3(kCompBlock), 0, s, C,
-                           by_ticket, M, O);
+        C.seg_blocks = ens ? (int32_t)(ens->rows_ps / ((int64_t)kCompBlock * items)) : 0; C._pad1 = 0;
+        C.seg_slots = ens ? ens->rows_ps : 0;
+        EnsembleArgs E;
+        std::memset(&E, 0, sizeof(E));
+        if (ens) E = ens->next;
+        const int eparts = ens ? nblocks((int64_t)E.S * ZRK_MAX_RADARS, kCompBlock) : 0;
+        hipLaunchKernelGGL(k_compact_fused, dim3((int)nbf + (M.m > 0 ? 1 : 0) + (O.nb > 0 ? 1 : 0) + eparts), dim3(kCompBlock), 0, s,
+                           C, by_ticket, M, O, E);
         return check_launch(ctx, "k_compact_fused");
     }
     const int nb = nblocks(n, kCompBlock);
@@ -2010,40 +2161,10 @@ ZRK_API int zrk_selftest_noise(zrk_ctx *ctx, uint64_t seed, uint64_t tick, uint3
 // Host loop: K ticks of the L1 path without returning to the caller (the headless counterpart of
 // Manager.run_simulation's per-tick module calls, reference modules/Manager.py:111-140).
 // ---------------------------------------------------------------------------------------------
-namespace {
-
-// CPython / numpy float floor-mod (modules/Radar.py:103, :109, :114, :117).
-double floormod_host(double a, double b)
-{
-    double m = std::fmod(a, b);
-    if (m != 0.0) {
-        if ((b < 0.0) != (m < 0.0)) m += b;
-    } else {
-        m = std::copysign(0.0, b);
-    }
-    return m;
-}
-
-}  // namespace
-
 ZRK_API int zrk_scan_advance(zrk_radar *radars, const zrk_scan *scan, int R)
 {
     if (R < 0 || (R > 0 && (!radars || !scan))) return ZRK_E_INVALID;
-    for (int r = 0; r < R; ++r) {
-        zrk_radar &rd = radars[r];
-        const zrk_scan &sc = scan[r];
-        if (sc.mode == 0) {            // "horizontal"
-            if (rd.cur_azimuth + rd.azimuth_range < 360.0) rd.cur_azimuth = floormod_host(rd.cur_azimuth + sc.azimuth_speed, 360.0);
-            else rd.cur_azimuth = sc.elevation_start;           // sic, modules/Radar.py:105
-            if (rd.cur_azimuth < sc.azimuth_speed) {
-                if (rd.cur_elevation + sc.elevation_speed < 90.0) rd.cur_elevation = floormod_host(rd.cur_elevation + sc.elevation_speed, 90.0);
-                else rd.cur_elevation = sc.elevation_start;
-            }
-        } else if (sc.mode == 1) {     // "vertical"
-            rd.cur_elevation = floormod_host(rd.cur_elevation + sc.elevation_speed, 90.0);
-            if (rd.cur_elevation < sc.elevation_speed) rd.cur_azimuth = floormod_host(rd.cur_azimuth + sc.azimuth_speed, 360.0);
-        }                               // any other mode string: the reference does nothing
-    }
+    for (int r = 0; r < R; ++r) scan_advance_one(radars[r], scan[r]);
     return 0;
 }
 
@@ -2188,10 +2309,12 @@ bool ensure_events(zrk_ctx *ctx, int pairs)
 
 }  // namespace
 
-ZRK_API int zrk_run_ticks_x(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int64_t m, zrk_loop *st,
-                            zrk_radar *radars, const zrk_scan *scan, int R, void *workspace, int32_t *det_idx,
-                            int64_t det_stride, int32_t *det_cnt, int64_t *packed, int64_t packed_capacity,
-                            const zrk_exchange_io *xio, int K, float *sweep_ms, int prof_stride, void *stream)
+namespace {
+
+int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int64_t m, zrk_loop *st,
+              zrk_radar *radars, const zrk_scan *scan, int R, void *workspace, int32_t *det_idx,
+              int64_t det_stride, int32_t *det_cnt, int64_t *packed, int64_t packed_capacity,
+              const zrk_exchange_io *xio, const zrk_ensemble *ens, int K, float *sweep_ms, int prof_stride, void *stream)
 {
     if (!ctx || !e || !st || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: null argument");
     if (m > 0 && !mis) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: missiles without a table");
@@ -2204,6 +2327,41 @@ ZRK_API int zrk_run_ticks_x(zrk_ctx *ctx, const zrk_entities *e, const zrk_missi
         if (!(st->flags & ZRK_F_UNION_BITS)) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: the exchange carries the wire format (ZRK_F_UNION_BITS)");
     }
     hipStream_t s = (hipStream_t)stream;
+    // a batched ensemble: S scenarios of rows_per_scenario rows each, radars and scan state on the device
+    EnsLaunch EL;
+    std::memset(&EL, 0, sizeof(EL));
+    RadarBlock *ens_tables[2] = {nullptr, nullptr};
+    if (ens) {
+        if (packed || xio) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks_ensemble: no union list for an ensemble");
+        if (ens->scenarios < 1 || ens->radars < 0 || ens->radars > ZRK_MAX_RADARS || ens->rows_per_scenario < kCompBlock ||
+            ens->rows_per_scenario % kCompBlock != 0 || !ens->radar_state || !ens->scan || !ens->d2_max || !ens->tables)
+            return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks_ensemble: incomplete ensemble description");
+        if (st->n != (int64_t)ens->scenarios * ens->rows_per_scenario || st->n > e->capacity || !e->list_index)
+            return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks_ensemble: the table must hold scenarios x rows_per_scenario rows and a list_index column");
+        if (ens->rows_per_scenario / ZRK_BLOCK >= 65536 || st->n / ZRK_BLOCK >= 65536 * (int64_t)16)
+            return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks_ensemble: scenario too long");
+        R = ens->radars;
+        const int64_t granules = ens->rows_per_scenario / kCompBlock;
+        int want = fused_items(ctx, st->n), items = 1;
+        for (int k = 1; k <= std::min(want, kFusedMaxItems); ++k) if (granules % k == 0) items = k;
+        while (st->n / ((int64_t)kCompBlock * items) > std::min(ctx->fused_max_blocks, kFusedMaxBlocks)) {
+            int bigger = 0;
+            for (int k = items + 1; k <= kFusedMaxItems; ++k) if (granules % k == 0) { bigger = k; break; }
+            if (!bigger) return fail(ctx, ZRK_E_CAPACITY, "zrk_run_ticks_ensemble: too many rows for the single-launch compaction");
+            items = bigger;
+        }
+        ens_tables[0] = (RadarBlock *)ens->tables;
+        ens_tables[1] = ens_tables[0] + ens->scenarios;
+        EL.seeds = ens->seeds; EL.rows_ps = ens->rows_per_scenario; EL.bps = (int32_t)(ens->rows_per_scenario / ZRK_BLOCK);
+        EL.items = items;
+        EL.next.state = ens->radar_state; EL.next.scan = ens->scan; EL.next.d2max = ens->d2_max;
+        EL.next.S = ens->scenarios; EL.next.R = R; EL.next.flags = st->flags; EL.next.advance = 1;
+        // the records of the first tick of this call, from the angles as they stand
+        EnsembleArgs now = EL.next;
+        now.advance = 0; now.table_out = ens_tables[st->tick & 1u];
+        hipLaunchKernelGGL(k_ensemble_derive, dim3(nblocks((int64_t)now.S * ZRK_MAX_RADARS, kCompBlock)), dim3(kCompBlock), 0, s, now);
+        if (int rc0 = check_launch(ctx, "k_ensemble_derive")) return rc0;
+    }
     const int stride = prof_stride > 0 ? prof_stride : 1;
     const int n_prof = sweep_ms ? (K + stride - 1) / stride : 0;
     if (n_prof && !ensure_events(ctx, n_prof)) return fail(ctx, ZRK_E_HIP, "hipEventCreate");
@@ -2240,7 +2398,11 @@ ZRK_API int zrk_run_ticks_x(zrk_ctx *ctx, const zrk_entities *e, const zrk_missi
         const int nbs = nblocks(st->n, ZRK_BLOCK);
         // (a grid that is resident all at once has no "last": eight workgroups of four waves fit a compute unit)
         const bool ordering = ctx->order_enabled && (det_idx || list) && R > 0 && nbs > 8 * ctx->cus &&
-                              compacts_in_one_launch(ctx, st->n);
+                              (ens || compacts_in_one_launch(ctx, st->n));
+        if (ens) {
+            EL.rb_table = (const char *)ens_tables[st->tick & 1u];
+            EL.next.table_out = ens_tables[(st->tick + 1) & 1u];
+        }
         Workspace w = carve(workspace, 0, e->capacity);
         // box records: none for rows the loop has not swept yet on this table (new table, new workspace, rows appended)
         if (ctx->box_ws != workspace || ctx->box_key != (const void *)e->start_pos || st->n < ctx->box_n) {
@@ -2258,7 +2420,7 @@ ZRK_API int zrk_run_ticks_x(zrk_ctx *ctx, const zrk_entities *e, const zrk_missi
         if (!ordering) ctx->order_ready = false;
         rc = launch_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse, st->seed,
                           st->tick, st->gid0, workspace, stream, M, vis_now, ordering ? w.cost : nullptr,
-                          (ordering && ctx->order_ready) ? w.order : nullptr, w.boxes);
+                          (ordering && ctx->order_ready) ? w.order : nullptr, w.boxes, ens ? &EL : nullptr);
         if (prof && rc == 0 && hipEventRecord(ev[2 * (k / stride) + 1], s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipEventRecord");
         // this slot's list was last sent two ticks ago: that collective must have read it before it is rewritten
         if (rc == 0 && xio && zrk_exchange_wait(xio->x, slot, stream) != 0) rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
@@ -2266,7 +2428,7 @@ ZRK_API int zrk_run_ticks_x(zrk_ctx *ctx, const zrk_entities *e, const zrk_missi
             rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, list,
                                 list_words, st->gid0, stream, M, vis_next,
                                 ordering ? OrderArgs{w.cost, w.order, nbs, 0} : OrderArgs{nullptr, nullptr, 0, 0},
-                                (st->flags & ZRK_F_UNION_BITS) != 0);
+                                (st->flags & ZRK_F_UNION_BITS) != 0, ens ? &EL : nullptr);
         if (rc == 0 && ordering) ctx->order_ready = true;
         if (rc == 0 && m > 0 && !fused) rc = zrk_missile_step(ctx, e, st->cur, mis, m, st->time_ms, st->dt_ms, 1, stream);
         if (rc == 0 && ev_words && !fused) {
@@ -2279,7 +2441,7 @@ ZRK_API int zrk_run_ticks_x(zrk_ctx *ctx, const zrk_entities *e, const zrk_missi
         // the collective of this tick, behind the compaction on RCCL's own stream: it overlaps the next tick's sweep
         if (rc == 0 && xio && zrk_exchange_all_gather(xio->x, slot, list, xio->recv[slot], xio->words, stream) != 0)
             rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
-        zrk_scan_advance(radars, scan, R);                                   // Radar.py:205
+        if (!ens) zrk_scan_advance(radars, scan, R);                          // Radar.py:205 (an ensemble's: on the device)
         st->time_ms += st->dt_ms;                                            // Manager.py:140
         st->tick += 1;
     }
@@ -2296,6 +2458,33 @@ ZRK_API int zrk_run_ticks_x(zrk_ctx *ctx, const zrk_entities *e, const zrk_missi
     }
     return rc;
 }
+
+}  // namespace
+
+ZRK_API int zrk_run_ticks_x(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int64_t m, zrk_loop *st,
+                            zrk_radar *radars, const zrk_scan *scan, int R, void *workspace, int32_t *det_idx,
+                            int64_t det_stride, int32_t *det_cnt, int64_t *packed, int64_t packed_capacity,
+                            const zrk_exchange_io *xio, int K, float *sweep_ms, int prof_stride, void *stream)
+{
+    return run_ticks(ctx, e, mis, m, st, radars, scan, R, workspace, det_idx, det_stride, det_cnt, packed, packed_capacity, xio,
+                     nullptr, K, sweep_ms, prof_stride, stream);
+}
+
+ZRK_API int zrk_run_ticks_ensemble(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int64_t m, zrk_loop *st,
+                                   const zrk_ensemble *ens, void *workspace, int32_t *det_idx, int64_t det_stride,
+                                   int32_t *det_cnt, int K, float *sweep_ms, int prof_stride, void *stream)
+{
+    if (!ens) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks_ensemble: null ensemble");
+    return run_ticks(ctx, e, mis, m, st, nullptr, nullptr, ens->radars, workspace, det_idx, det_stride, det_cnt, nullptr, 0, nullptr,
+                     ens, K, sweep_ms, prof_stride, stream);
+}
+
+ZRK_API int64_t zrk_ensemble_table_bytes(int scenarios)
+{
+    return scenarios < 0 ? ZRK_E_INVALID : 2 * (int64_t)scenarios * (int64_t)sizeof(RadarBlock);
+}
+
+ZRK_API double zrk_d2_threshold(double max_distance) { return d2_threshold(max_distance); }
 
 ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int64_t m, zrk_loop *st,
                           zrk_radar *radars, const zrk_scan *scan, int R, void *workspace, int32_t *det_idx,

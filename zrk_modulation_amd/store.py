@@ -225,6 +225,29 @@ class EntityStore:
         self.n_uploaded = b
         self._bump()
 
+    def overwrite_rows(self, rows, start_pos, velocity, start_time, kind=0):
+        """Give existing (padding) rows a trajectory and bring them to life, in place: what a batched ensemble does
+        when a missile enters the air in a scenario's block of rows (the rows keep their list index).  The caller
+        tells the loop that rows changed under it (zrk_ctx_invalidate_boxes)."""
+        rows = np.asarray(rows, np.int64)
+        k = len(rows)
+        sp = np.asarray(start_pos, np.float64).reshape(k, 3); vel = np.asarray(velocity, np.float64).reshape(k, 3)
+        t0 = np.broadcast_to(np.asarray(start_time, np.float64), (k,))
+        self.flush()
+        self.h_sp[rows] = sp; self.h_vel[rows] = vel; self.h_t0[rows] = t0; self.h_pos0[rows] = sp
+        self.h_kind[rows] = kind; self.h_alive[rows] = 1
+        dev = self.device
+        r = torch.as_tensor(rows, device=dev)
+        dsp = torch.from_numpy(np.ascontiguousarray(sp.T)).to(dev)
+        self.d_sp[:, r] = dsp
+        self.d_vel[:, r] = torch.from_numpy(np.ascontiguousarray(vel.T)).to(dev)
+        self.d_t0[r] = torch.from_numpy(np.ascontiguousarray(t0)).to(dev)
+        self.d_kind[r] = int(kind)
+        self.d_pos[0][:, r] = dsp
+        self.d_pos[1][:, r] = dsp
+        self.d_alive[r] = 1
+        self._bump()
+
     def add_missile_row(self, slot, target_slot, radius, period):
         if self.m + 1 > self.mcap:
             self._alloc_missiles(2 * self.mcap)
