@@ -100,6 +100,7 @@ typedef struct {
     double missile_pos[3];
     double speed;                   /* velocity_module */
     double period;                  /* detonate_period */
+    double radius;                  /* detonate_radius (used by zrk_launch_salvo only) */
 } zrk_launch_req;
 
 typedef struct {
@@ -217,6 +218,21 @@ int zrk_apply_events(zrk_ctx *ctx, const zrk_entities *ents, int src, const zrk_
  * targets' current positions from pos[cur]. */
 int zrk_launch_solve(zrk_ctx *ctx, const zrk_entities *ents, int cur, const zrk_launch_req *req /* DEVICE */,
                      zrk_launch_res *res /* DEVICE */, int64_t k, void *stream);
+
+/*
+ * A salvo without the host: zrk_launch_solve for k requests, then the successful ones enter the air in request
+ * order -- table rows n .. n + count - 1 (trajectory (V, missile_pos, time_ms / 1000), alive, kind 1, both position
+ * buffers at missile_pos, list_index = list_base + p when the table has that column) and missile rows
+ * m .. m + count - 1 (slot, target, radius, period, status 1).
+ *   replaces: MissileLauncher.step -> launch_missile -> Missile.step 'ready' -> _launch   modules/MissileLauncher.py:82-138,
+ *             modules/Missile.py:104-133, and AirEnv taking the missile in, modules/AirEnv.py:42-43, for a whole salvo.
+ * The k - count failed requests take the rows behind them, dead and inactive, so the caller continues with n + k and
+ * m + k (upper bounds) without reading anything back; *count_out (DEVICE, may be NULL) receives count.  Writes the
+ * trajectory columns, kind and list_index of the new rows although zrk_entities / zrk_missiles declare them const.
+ */
+int zrk_launch_salvo(zrk_ctx *ctx, const zrk_entities *ents, int cur, const zrk_missiles *mis, int64_t n, int64_t m,
+                     const zrk_launch_req *req /* DEVICE */, zrk_launch_res *res /* DEVICE */, int64_t k,
+                     int64_t time_ms, int32_t list_base, int32_t *count_out /* DEVICE */, void *stream);
 
 /* Static scan parameters of one radar (modules/Radar.py:13-42): what
  * move_to_next_sector_circular reads besides the current angles. */

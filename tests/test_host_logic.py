@@ -27,8 +27,10 @@ def test_ctypes_structs_match_the_header_layout():
     assert C.sizeof(_lib.ZrkRadar) == 8 * 8
     assert C.sizeof(_lib.ZrkEntities) == 8 * 11
     assert C.sizeof(_lib.ZrkMissiles) == 8 * 10
-    assert C.sizeof(_lib.ZrkLaunchReq) == 48 and C.sizeof(_lib.ZrkLaunchRes) == 40
+    assert C.sizeof(_lib.ZrkLaunchReq) == 56 and C.sizeof(_lib.ZrkLaunchRes) == 40
     assert C.sizeof(_lib.ZrkScan) == 32 and C.sizeof(_lib.ZrkLoop) == 64
+    assert C.sizeof(_lib.ZrkRcclId) == 128 and C.sizeof(_lib.ZrkExchangeIo) == 56 and C.sizeof(_lib.ZrkEnsemble) == 56
+    _lib.launch_dtypes()                      # numpy views of the launch records agree with the structs
 
 
 def test_no_gpu_means_loud_failure_not_a_fallback():

@@ -72,6 +72,7 @@ class ZrkLaunchReq(C.Structure):
         ("missile_pos", C.c_double * 3),
         ("speed", C.c_double),
         ("period", C.c_double),
+        ("radius", C.c_double),
     ]
 
 
@@ -82,6 +83,16 @@ class ZrkLaunchRes(C.Structure):
         ("velocity", C.c_double * 3),
         ("t_hit", C.c_double),
     ]
+
+
+def launch_dtypes():
+    """numpy views of zrk_launch_req / zrk_launch_res arrays."""
+    import numpy as np
+    req = np.dtype([("target_slot", "<i4"), ("_pad", "<i4"), ("missile_pos", "<f8", 3), ("speed", "<f8"),
+                    ("period", "<f8"), ("radius", "<f8")])
+    res = np.dtype([("rc", "<i4"), ("_pad", "<i4"), ("velocity", "<f8", 3), ("t_hit", "<f8")])
+    assert req.itemsize == C.sizeof(ZrkLaunchReq) and res.itemsize == C.sizeof(ZrkLaunchRes)
+    return req, res
 
 
 class ZrkScan(C.Structure):
@@ -186,6 +197,9 @@ _PROTOTYPES = {
                                    C.c_void_p]),
     "zrk_launch_solve": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_int64, C.c_void_p]),
+    "zrk_launch_salvo": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.c_int, C.POINTER(ZrkMissiles), C.c_int64,
+                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
+                                   C.c_void_p]),
     "zrk_selftest_math": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                     C.c_void_p]),
     "zrk_selftest_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64, C.c_void_p,

@@ -1662,6 +1662,74 @@ __global__ void k_launch_solve(const double *__restrict__ vel, const uint8_t *__
     res[q] = out;
 }
 
+// The successful launches of a salvo enter the air (Missile._launch, modules/Missile.py:104-133; MissileLauncher
+// hands the missile to AirEnv, modules/MissileLauncher.py:103-124, modules/AirEnv.py:42-43), in request order, without
+// the host: an exclusive prefix sum of (rc == 0) gives success number p the next table row n + p -- trajectory
+// (V, launcher position, now), alive, kind 1, both position buffers at the launcher -- and the next missile row m + p.
+// The k - count requests that failed take the rows behind, dead and inactive, so that the host's upper bounds
+// n + k and m + k hold without reading anything back; list indices stay dense for the missiles in the air.
+__global__ __launch_bounds__(1024) void k_launch_append(const zrk_launch_req *__restrict__ req,
+                                                        const zrk_launch_res *__restrict__ res, int64_t k, double *sp,
+                                                        double *vel, double *t0, uint8_t *alive, uint8_t *kind, double *pos0,
+                                                        double *pos1, int32_t *lidx, int64_t cap, int64_t n, int32_t list_base,
+                                                        int32_t *m_slot, int32_t *m_tgt, double *m_radius, double *m_period,
+                                                        uint8_t *m_status, int64_t m, double t, int32_t *count_out)
+{
+    __shared__ int s_wave[16];
+    __shared__ int s_total;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // pass 1: how many succeeded (the failures' rows start behind all of them)
+    int mine = 0;
+    for (int64_t q = tid; q < k; q += 1024) mine += res[q].rc == 0;
+    for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d);
+    if (lane == 0) s_wave[wave] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) tot += s_wave[w];
+        s_total = tot;
+        if (count_out) *count_out = tot;
+    }
+    __syncthreads();
+    const int total = s_total;
+    int carry_ok = 0, carry_bad = 0;
+    for (int64_t base = 0; base < k; base += 1024) {
+        const int64_t q = base + tid;
+        const bool in = q < k;
+        const bool ok = in && res[q].rc == 0;
+        const unsigned long long b_ok = __ballot(ok), b_bad = __ballot(in && !ok);
+        __syncthreads();
+        if (lane == 0) s_wave[wave] = (int)__popcll(b_ok) | ((int)__popcll(b_bad) << 16);
+        __syncthreads();
+        int o_ok = carry_ok, o_bad = carry_bad, t_ok = 0, t_bad = 0;
+        for (int w = 0; w < 16; ++w) {
+            const int v = s_wave[w];
+            if (w < wave) { o_ok += v & 0xFFFF; o_bad += v >> 16; }
+            t_ok += v & 0xFFFF; t_bad += v >> 16;
+        }
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        if (in) {
+            const int p = ok ? o_ok + (int)__popcll(b_ok & below) : total + o_bad + (int)__popcll(b_bad & below);
+            const int64_t row = n + p, mrow = m + p;
+            const zrk_launch_req rq = req[q];
+            for (int c = 0; c < 3; ++c) {
+                sp[c * cap + row] = rq.missile_pos[c];
+                vel[c * cap + row] = ok ? res[q].velocity[c] : 0.0;
+                pos0[c * cap + row] = rq.missile_pos[c];
+                pos1[c * cap + row] = rq.missile_pos[c];
+            }
+            t0[row] = t;
+            alive[row] = ok ? 1 : 0;
+            kind[row] = 1;
+            if (lidx) lidx[row] = list_base + p;
+            m_slot[mrow] = (int32_t)row; m_tgt[mrow] = rq.target_slot;
+            m_radius[mrow] = rq.radius; m_period[mrow] = rq.period;
+            m_status[mrow] = ok ? 1 : 0;
+        }
+        carry_ok += t_ok; carry_bad += t_bad;
+    }
+}
+
 __global__ void k_selftest_math(int op, const double *a, const double *b, double *y, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2137,6 +2205,27 @@ ZRK_API int zrk_launch_solve(zrk_ctx *ctx, const zrk_entities *e, int cur, const
     hipLaunchKernelGGL(k_launch_solve, dim3(nblocks(k, 64)), dim3(64), 0, (hipStream_t)stream, e->velocity, e->kind,
                        e->pos[cur], e->capacity, req, res, k);
     return check_launch(ctx, "k_launch_solve");
+}
+
+ZRK_API int zrk_launch_salvo(zrk_ctx *ctx, const zrk_entities *e, int cur, const zrk_missiles *mis, int64_t n, int64_t m,
+                             const zrk_launch_req *req, zrk_launch_res *res, int64_t k, int64_t time_ms, int32_t list_base,
+                             int32_t *count_out, void *stream)
+{
+    if (!ctx || !e || !mis || (k > 0 && (!req || !res))) return fail(ctx, ZRK_E_INVALID, "zrk_launch_salvo: null argument");
+    if ((cur != 0 && cur != 1) || n < 0 || m < 0 || k < 0) return fail(ctx, ZRK_E_INVALID, "zrk_launch_salvo: size out of range");
+    if (n + k > e->capacity || m + k > mis->capacity)
+        return fail(ctx, ZRK_E_CAPACITY, "zrk_launch_salvo: the tables need room for every request (n + k rows, m + k missile rows)");
+    hipStream_t s = (hipStream_t)stream;
+    if (k == 0) {
+        if (count_out && hipMemsetAsync(count_out, 0, sizeof(int32_t), s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "memset count");
+        return 0;
+    }
+    if (int rc = zrk_launch_solve(ctx, e, cur, req, res, k, stream)) return rc;
+    hipLaunchKernelGGL(k_launch_append, dim3(1), dim3(1024), 0, s, req, res, k, (double *)e->start_pos, (double *)e->velocity,
+                       (double *)e->start_time, e->alive, (uint8_t *)e->kind, e->pos[0], e->pos[1], (int32_t *)e->list_index,
+                       e->capacity, n, list_base, (int32_t *)mis->slot, (int32_t *)mis->target, (double *)mis->radius, mis->period,
+                       mis->status, m, (double)time_ms / 1000.0, count_out);
+    return check_launch(ctx, "k_launch_append");
 }
 
 ZRK_API int zrk_selftest_math(zrk_ctx *ctx, int op, const double *a, const double *b, double *y, int64_t n, void *stream)

@@ -246,9 +246,13 @@ class HotPathEngine:
         return self
 
     def launch_missiles(self, target_slots, launcher_pos=(0.0, 0.0, 0.0), speed=1000.0, radius=150.0, period=60.0,
-                        id0=10_000_000):
-        """Batched Missile._launch at the current time against the given target slots; the ones whose
-        solve succeeds enter the table as active missiles (in request order).  Returns their count."""
+                        id0=10_000_000, mirror=True):
+        """Batched Missile._launch at the current time against the given targets (list indices); the ones whose
+        solve succeeds enter the table as active missiles, in request order.  Solve AND append run on the device
+        (zrk_launch_salvo): nothing is uploaded but the requests.  With mirror=True (default) the results are read
+        back once for the host-side mirrors (ids, trajectories, row map) and the table grows by the number of
+        successes, which is returned; with mirror=False nothing is read back, the table grows by len(target_slots)
+        (the failed requests' rows sit dead behind the successes) and None is returned."""
         C, _lib = self._C, self._lib
         st = self.store
         k = len(target_slots)
@@ -257,35 +261,50 @@ class HotPathEngine:
         target_slots = np.asarray(target_slots, np.int64)
         if self.row_of_list is not None:                 # callers speak list indices, the table speaks rows
             target_slots = self.row_of_list[target_slots]
-        req = np.zeros(k, dtype=np.dtype([("target_slot", "<i4"), ("_pad", "<i4"), ("missile_pos", "<f8", 3),
-                                          ("speed", "<f8"), ("period", "<f8")]))
+        req_t, res_t = _lib.launch_dtypes()
+        req = np.zeros(k, dtype=req_t)
         req["target_slot"] = np.asarray(target_slots, np.int32)
         req["missile_pos"] = np.asarray(launcher_pos, np.float64)
-        req["speed"], req["period"] = speed, period
+        req["speed"], req["period"], req["radius"] = speed, period, radius
+        st.flush()
+        if st.n + k > st.cap:
+            st._alloc_entities(max(st.n + k, 2 * st.cap))
+            self.loop.n = st.n_uploaded
+        if st.m + k > st.mcap:
+            st._alloc_missiles(max(2 * st.mcap, st.m + k))
         d_req = torch.from_numpy(req.view(np.uint8).reshape(-1)).to(st.device)
         d_res = torch.zeros(k * C.sizeof(_lib.ZrkLaunchRes), dtype=torch.uint8, device=st.device)
-        st.ctx.check(st.lib.zrk_launch_solve(st.ctx.handle, C.byref(st.ents), st.cur, d_req.data_ptr(),
-                                             d_res.data_ptr(), k, st._stream()), "zrk_launch_solve")
-        res = d_res.cpu().numpy().view(np.dtype([("rc", "<i4"), ("_pad", "<i4"), ("velocity", "<f8", 3),
-                                                 ("t_hit", "<f8")]))
+        n0, m0, list_base = st.n, st.m, self.n_list
+        st.ctx.check(st.lib.zrk_launch_salvo(st.ctx.handle, C.byref(st.ents), st.cur, C.byref(st.mis), n0, m0, d_req.data_ptr(),
+                                             d_res.data_ptr(), k, int(self.loop.time_ms), list_base, None, st._stream()),
+                     "zrk_launch_salvo")
+        st._bump()
+        if not mirror:
+            st.adopt_device_rows(k, kind=1)
+            st.m += k
+            self.n_list += k
+            if self.row_of_list is not None:
+                self.row_of_list = np.concatenate([self.row_of_list, n0 + np.arange(k)])
+            self.loop.n = st.n_uploaded
+            self.launch_results = None
+            return None
+        res = d_res.cpu().numpy().view(res_t)
         self.launch_results = res
         ok = np.nonzero(res["rc"] == 0)[0]
-        if len(ok) == 0:
+        c = len(ok)
+        if c == 0:
             return 0
         t0 = self.loop.time_ms / 1000
         li = None
         if self.row_of_list is not None:
-            li = np.arange(self.n_list, self.n_list + len(ok), dtype=np.int32)
-            self.row_of_list = np.concatenate([self.row_of_list, st.n + np.arange(len(ok))])
-        self.n_list += len(ok)
-        first = st.add_entities(id0 + ok, np.broadcast_to(np.asarray(launcher_pos, np.float64), (len(ok), 3)),
-                                res["velocity"][ok], t0, kind=1, list_index=li)
-        st.flush()
-        st.add_missile_rows(np.arange(first, first + len(ok), dtype=np.int32),
-                            np.asarray(target_slots, np.int32)[ok], radius, period)
+            li = np.arange(list_base, list_base + c, dtype=np.int32)
+            self.row_of_list = np.concatenate([self.row_of_list, n0 + np.arange(c)])
+        self.n_list += c
+        st.adopt_device_rows(c, kind=1, ids=id0 + ok, start_pos=np.broadcast_to(np.asarray(launcher_pos, np.float64), (c, 3)),
+                             velocity=res["velocity"][ok], start_time=t0, list_index=li)
+        st.adopt_device_missile_rows(np.arange(n0, n0 + c, dtype=np.int32), np.asarray(target_slots, np.int32)[ok])
         self.loop.n = st.n_uploaded
-        self.launch_results = res
-        return len(ok)
+        return c
 
     def run(self, K, sweep_ms=None, prof_stride=1, exchange=None):
         """Enqueue K ticks.  With `sweep_ms` (a float32 numpy array of ceil(K/prof_stride)) the call

@@ -139,8 +139,8 @@ class EnsembleEngine:
         k = len(rows)
         if k == 0:
             return 0
-        req = np.zeros(k, dtype=np.dtype([("target_slot", "<i4"), ("_pad", "<i4"), ("missile_pos", "<f8", 3),
-                                          ("speed", "<f8"), ("period", "<f8")]))
+        req_t, res_t = _lib.launch_dtypes()
+        req = np.zeros(k, dtype=req_t)
         req["target_slot"] = rows.astype(np.int32)
         req["missile_pos"] = np.asarray(launcher_pos, np.float64)
         req["speed"], req["period"] = speed, period
@@ -148,7 +148,7 @@ class EnsembleEngine:
         d_res = torch.zeros(k * C.sizeof(_lib.ZrkLaunchRes), dtype=torch.uint8, device=st.device)
         st.ctx.check(st.lib.zrk_launch_solve(st.ctx.handle, C.byref(st.ents), st.cur, d_req.data_ptr(), d_res.data_ptr(), k,
                                              st._stream()), "zrk_launch_solve")
-        res = d_res.cpu().numpy().view(np.dtype([("rc", "<i4"), ("_pad", "<i4"), ("velocity", "<f8", 3), ("t_hit", "<f8")]))
+        res = d_res.cpu().numpy().view(res_t)
         self.launch_results = res
         ok = np.nonzero(res["rc"] == 0)[0]
         if len(ok) == 0:

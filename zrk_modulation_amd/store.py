@@ -225,6 +225,32 @@ class EntityStore:
         self.n_uploaded = b
         self._bump()
 
+    def adopt_device_rows(self, k, kind=0, ids=None, start_pos=None, velocity=None, start_time=0.0, list_index=None):
+        """The next k table rows were written on the device (zrk_launch_salvo): count them in; the host mirrors
+        take what the caller knows of them (nothing is uploaded)."""
+        z3 = np.zeros((k, 3))
+        self.h_ids = np.concatenate([self.h_ids, np.asarray(ids, np.int64) if ids is not None else np.full(k, -1, np.int64)])
+        self.h_kind = np.concatenate([self.h_kind, np.full(k, kind, np.uint8)])
+        sp = np.asarray(start_pos, np.float64).reshape(k, 3) if start_pos is not None else z3
+        self.h_sp = np.concatenate([self.h_sp, sp])
+        self.h_vel = np.concatenate([self.h_vel, np.asarray(velocity, np.float64).reshape(k, 3) if velocity is not None else z3])
+        self.h_t0 = np.concatenate([self.h_t0, np.broadcast_to(np.asarray(start_time, np.float64), (k,))])
+        self.h_pos0 = np.concatenate([self.h_pos0, sp])
+        self.h_alive = np.concatenate([self.h_alive, np.ones(k, np.uint8)])
+        if self.h_lidx is not None:
+            li = np.asarray(list_index, np.int32) if list_index is not None else np.arange(self.n, self.n + k, dtype=np.int32)
+            self.h_lidx = np.concatenate([self.h_lidx, li])
+        self.slots_of_id = None
+        self.n += k
+        self.n_uploaded += k
+        self._bump()
+
+    def adopt_device_missile_rows(self, slots, target_slots):
+        """Missile-table rows written on the device (zrk_launch_salvo): host mirrors of their static columns."""
+        self.hm_slot = np.concatenate([self.hm_slot, np.asarray(slots, np.int32)])
+        self.hm_tgt = np.concatenate([self.hm_tgt, np.asarray(target_slots, np.int32)])
+        self.m += len(slots)
+
     def overwrite_rows(self, rows, start_pos, velocity, start_time, kind=0):
         """Give existing (padding) rows a trajectory and bring them to life, in place: what a batched ensemble does
         when a missile enters the air in a scenario's block of rows (the rows keep their list index).  The caller
@@ -368,9 +394,8 @@ class EntityStore:
 
     def launch_solve(self, target_slot, missile_pos, speed, period):
         """Missile._calculate_trajectory_params on the device.  Returns (rc, V[3], t_hit)."""
-        req = np.zeros(1, dtype=np.dtype([("target_slot", "<i4"), ("_pad", "<i4"), ("missile_pos", "<f8", 3),
-                                          ("speed", "<f8"), ("period", "<f8")]))
-        assert req.dtype.itemsize == C.sizeof(ZrkLaunchReq)
+        req_t, res_t = _lib.launch_dtypes()
+        req = np.zeros(1, dtype=req_t)
         req["target_slot"] = int(target_slot); req["missile_pos"] = np.asarray(missile_pos, np.float64)
         req["speed"] = float(speed); req["period"] = float(period)
         d_req = torch.from_numpy(req.view(np.uint8)).to(self.device)
@@ -378,6 +403,5 @@ class EntityStore:
         self.flush()
         self.ctx.check(self.lib.zrk_launch_solve(self.ctx.handle, C.byref(self.ents), self.cur, d_req.data_ptr(),
                                                  d_res.data_ptr(), 1, self._stream()), "zrk_launch_solve")
-        res = d_res.cpu().numpy().view(np.dtype([("rc", "<i4"), ("_pad", "<i4"), ("velocity", "<f8", 3),
-                                                 ("t_hit", "<f8")]))[0]
+        res = d_res.cpu().numpy().view(res_t)[0]
         return int(res["rc"]), np.array(res["velocity"], np.float64), float(res["t_hit"])
