@@ -209,3 +209,61 @@ def test_gui_schema_scene_runs_the_same_through_modules_and_headless():
         assert total > 50
     finally:
         np.random.normal = real_normal
+
+
+def test_bulk_scenario_load_is_linear_and_equals_one_by_one():
+    """A GUI-schema scenario of 1e5 targets loads through create_objects_from_config in seconds (one table append),
+    and a bulk-loaded AirEnv is the same table as one filled by add_target calls."""
+    import time
+    from zrk_modulation_amd import scenario as S
+    from zrk_modulation_amd.main import create_objects_from_config
+    cfg = S.synthetic_config(100_000, 2, seed=3, duration=30)
+    cfg.pop("combat_control_point")          # the command post is host code, quadratic like the reference's: not the loader
+    cfg["missile_launchers"] = []
+    t = time.perf_counter()
+    mgr, by_id = create_objects_from_config(cfg, device="cuda:0")
+    mgr.run_simulation(30)
+    took = time.perf_counter() - t
+    assert took < 60, f"loading and 3 ticks of 1e5 targets took {took:.1f} s"
+    st = by_id[1].store
+    assert st.n_uploaded == 100_000 and int(st.d_alive[:st.n_uploaded].sum().item()) == 100_000
+    small = S.synthetic_config(300, 2, seed=4, duration=50)
+    ma, a = create_objects_from_config(small, device="cuda:0")
+    mb, b = create_objects_from_config(dict(small, air_environment=dict(small["air_environment"], targets=[])), device="cuda:0")
+    from zrk_modulation_amd.modules.AirObject import Trajectory
+    from zrk_modulation_amd.modules.utils import Target, TargetType
+    for tc in small["air_environment"]["targets"]:
+        pos, vel = np.array(tc["position"]), np.array(tc["velocity"])
+        b[1].add_target(Target(mb, tc["id"], pos, Trajectory(velocity=vel, start_pos=pos, start_time=0.0), TargetType.AIR_PLANE))
+    np.random.seed(1); ma.run_simulation(50)
+    np.random.seed(1); mb.run_simulation(50)
+    sa, sb = a[1].store, b[1].store
+    assert np.array_equal(sa.host_pos("cur").view(np.uint64), sb.host_pos("cur").view(np.uint64))
+    assert np.array_equal(sa.h_ids[:300], sb.h_ids[:300])
+
+
+def test_smooth_objects_and_get_pos_work_on_device_backed_objects():
+    """SectorRadar.smooth_objects (reference modules/Radar.py:138-142) on a list of device-backed objects: the same
+    draws from numpy's global stream as the reference's loop, added in place; SectorRadar.start (reference :207-218)."""
+    from zrk_modulation_amd import scenario as S
+    from zrk_modulation_amd.main import create_objects_from_config
+    cfg = S.synthetic_config(64, 1, seed=8, duration=10)
+    mgr, by_id = create_objects_from_config(cfg, device="cuda:0")
+    mgr.run_simulation(10)
+    env, radar = by_id[1], by_id[10_000]
+    objs = [env._handles[k] for k in (5, 9, 2)]
+    before = [o.pos.copy() for o in objs]
+    np.random.seed(33)
+    want = [b + np.random.normal(0, 5, 3) for b in before]
+    np.random.seed(33)
+    radar.smooth_objects(objs)
+    for o, w in zip(objs, want):
+        assert np.array_equal(o.pos.view(np.uint64), w.view(np.uint64))
+    o = objs[0]
+    assert np.array_equal(o.trajectory.get_pos(0.0), o.trajectory.start_pos)
+    from zrk_modulation_amd.modules.constants import MessageType
+    active = mgr.give_messages_by_type(MessageType.ACTIVE_OBJECTS, step_time=0)[0].active_objects
+    radar.elevation_speed = 15.0
+    seen = radar.start(active)
+    assert len(seen) == int(radar.azimuth_range / radar.azimuth_speed * radar.elevation_range / radar.elevation_speed)
+    assert all(isinstance(lst, list) for lst in seen)

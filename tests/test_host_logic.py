@@ -211,3 +211,40 @@ def test_synthetic_config_is_in_the_gui_schema():
     ids, sp, vel, _ = S.synthetic_targets(50, 4)
     assert [t["id"] for t in cfg["air_environment"]["targets"]] == ids.tolist()
     assert np.array_equal(np.array([t["position"] for t in cfg["air_environment"]["targets"]]), sp)
+
+
+def test_trajectory_get_pos_and_unbound_airobject_step_follow_the_reference_arithmetic():
+    """reference modules/AirObject.py:23-25, :39-42: three roundings per axis; prev_pos aliases the old pos, None on
+    the tick where t equals start_time."""
+    from zrk_modulation_amd.modules.AirObject import AirObject, Trajectory
+    from zrk_modulation_amd.modules.Manager import Manager
+    from zrk_modulation_amd.modules.Timer import Timer
+    tr = Trajectory(velocity=(0.1, -0.2, 0.3), start_pos=(1e5, 2e5, 3e3), start_time=0.5)
+    t = 1234 / 1000
+    want = np.array([1e5, 2e5, 3e3]) + np.array([0.1, -0.2, 0.3]) * (t - 0.5)
+    assert np.array_equal(tr.get_pos(t).view(np.uint64), want.view(np.uint64))
+    m = Manager()
+    m.time = Timer(); m.time.set_dt(10); m.time.set_time(500)
+    obj = AirObject(m, 7, np.array([1e5, 2e5, 3e3]), tr)
+    obj.step()
+    assert obj.prev_pos is None and np.array_equal(obj.pos, tr.get_pos(0.5))
+    first = obj.pos
+    m.time.set_time(510)
+    obj.step()
+    assert np.array_equal(obj.prev_pos, first) and np.array_equal(obj.pos, tr.get_pos(0.51))
+
+
+def test_host_mirror_append_is_amortised():
+    """EntityStore's host mirrors grow by doubling: appending objects one at a time does not re-copy the table."""
+    from zrk_modulation_amd.store import EntityStore
+    st = EntityStore.__new__(EntityStore)
+    st.h_ids = np.zeros(0, np.int64)
+    copies = 0
+    last = None
+    for k in range(5000):
+        st._happend("h_ids", np.asarray([k], np.int64))
+        base = st._hbuf["h_ids"]
+        if base is not last:
+            copies += 1
+            last = base
+    assert copies <= 5 and np.array_equal(st.h_ids, np.arange(5000))

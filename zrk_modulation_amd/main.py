@@ -70,10 +70,12 @@ def create_objects_from_config(config: Dict[str, Any], device=None, replay=None)
         manager.add_module(ccp)
         by_id[ccp_cfg["id"]] = ccp
 
+    targets = []
     for tc in ae_cfg.get("targets", []) or []:
         pos, vel = np.array(tc["position"]), np.array(tc["velocity"])
-        air_env.add_target(Target(manager, tc["id"], pos, Trajectory(velocity=vel, start_pos=pos, start_time=0.0),
-                                  getattr(TargetType, tc["type"])))
+        targets.append(Target(manager, tc["id"], pos, Trajectory(velocity=vel, start_pos=pos, start_time=0.0),
+                              getattr(TargetType, tc["type"])))
+    air_env.add_targets(targets)             # one table append, list order as given (reference main.py:128-147)
     return manager, by_id
 
 

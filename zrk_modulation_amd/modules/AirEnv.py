@@ -67,6 +67,22 @@ class AirEnv(BaseModel):
     def add_target(self, target: Target) -> None:
         self._append(target, kind=0)
 
+    def add_targets(self, targets) -> None:
+        """Bulk form of add_target: one table append for the whole list (a scenario of 1e5 targets loads in time
+        linear in their number).  List order = the order given, exactly as repeated add_target calls."""
+        targets = list(targets)
+        if not targets:
+            return
+        first = self.store.add_entities(
+            [t.id for t in targets], np.asarray([t.trajectory.start_pos for t in targets], np.float64),
+            np.asarray([t.trajectory.velocity for t in targets], np.float64),
+            np.asarray([t.trajectory.start_time for t in targets], np.float64), kind=0,
+            pos0=np.asarray([np.asarray(t.pos, np.float64) for t in targets], np.float64))
+        for k, t in enumerate(targets):
+            t._bind(self.store, first + k)
+        self._handles.extend(targets)
+        self._live_dirty = True
+
     def _append(self, obj: AirObject, kind: int) -> int:
         tr = obj.trajectory
         pos0 = np.asarray(obj.pos, dtype=np.float64)      # int-typed YAML positions are coerced (SURVEY 5.9-11)

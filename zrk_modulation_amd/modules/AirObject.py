@@ -24,9 +24,9 @@ class Trajectory:
         self.start_time = start_time
 
     def get_pos(self, t: float) -> np.ndarray:
-        raise NotImplementedError(
-            "Trajectory.get_pos is evaluated on the device for every live object by AirEnv.step(); "
-            "read obj.pos after the step instead")
+        """Host evaluation with the reference's three roundings per axis (reference :23-25).  AirEnv.step() does
+        the same arithmetic for every live row on the device; this is for callers that ask about one object."""
+        return self.start_pos + self.velocity * (t - self.start_time)
 
 
 class AirObject(BaseModel):
@@ -85,5 +85,17 @@ class AirObject(BaseModel):
         self._initial_prev = value
 
     def step(self):
-        raise RuntimeError("AirObject.step() runs on the device inside AirEnv.step(); "
-                           "add the object to an AirEnv instead of stepping it directly")
+        """One object stepped on its own (reference :39-42).  Inside an AirEnv every live row is advanced by one kernel
+        launch and nobody calls this; an object that is not in any AirEnv (or a caller that insists) gets the
+        reference's two assignments, written through to the table when the object has a row."""
+        t = to_seconds(self._manager.time.get_time())
+        new_prev = self.pos if self.trajectory.start_time != t else None
+        new_pos = self.trajectory.get_pos(t)
+        if self._store is None or self._frozen is not None:
+            self._initial_prev = new_prev
+            self.pos = new_pos
+        else:
+            st = self._store
+            if new_prev is not None:
+                st.write_pos(self._slot, new_prev, which="prev")
+            st.write_pos(self._slot, new_pos)

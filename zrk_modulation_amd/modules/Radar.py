@@ -58,8 +58,32 @@ class SectorRadar(BaseModel):
         return [objects._handles[s] for s in slots]
 
     def smooth_objects(self, objects):
-        """Only meaningful right after find_visible_objects on the same list; step() fuses both."""
-        raise NotImplementedError("noise is applied on the device inside SectorRadar.step()")
+        """pos += N(0, 5^2) per axis for every object of the list, in list order, from numpy's global legacy stream
+        (reference :138-142): one (k, 3) draw is bit-identical to the reference's k separate draws.  Objects that live
+        in a device table are perturbed there in one launch; others on the host."""
+        objects = list(objects)
+        if not objects:
+            return
+        noise = np.random.normal(0, RADAR_NOISE_SIGMA, (len(objects), 3))
+        bound = [k for k, o in enumerate(objects) if getattr(o, "_store", None) is not None and o._frozen is None]
+        stores = {id(objects[k]._store): objects[k]._store for k in bound}
+        if len(stores) == 1 and len(bound) == len(objects):
+            import torch
+            store = next(iter(stores.values()))
+            idx = torch.as_tensor(np.asarray([o._slot for o in objects], np.int32), device=store.device)
+            store.noise_apply(idx, len(objects), noise)
+            return
+        for o, nz in zip(objects, noise):
+            o.pos = o.pos + nz
+
+    def start(self, objects):
+        """The reference's stand-alone test helper (reference :207-218): look, move to the next sector, repeat."""
+        num_steps = int(self.azimuth_range / self.azimuth_speed * self.elevation_range / self.elevation_speed)
+        seen = []
+        for _ in range(num_steps):
+            seen.append(self.find_visible_objects(objects))
+            self.move_to_next_sector()
+        return seen
 
     def move_to_next_sector_circular(self):
         self.current_azimuth, self.current_elevation = scan_next(

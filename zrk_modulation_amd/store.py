@@ -169,6 +169,25 @@ class EntityStore:
         return self._det_idx
 
     # -- population -------------------------------------------------------------------------
+    def _happend(self, name, vals):
+        """Append to a host mirror column in amortised O(1) per row (the public attribute is a view of a buffer that
+        doubles): a scenario loaded one object at a time stays linear in the number of objects."""
+        vals = np.asarray(vals)
+        bufs = self.__dict__.setdefault("_hbuf", {})
+        cur = getattr(self, name)
+        n = len(cur)
+        buf = bufs.get(name)
+        if buf is None or buf.dtype != cur.dtype or not (n == 0 or np.shares_memory(buf, cur)):
+            buf = cur                                   # somebody rebound the attribute: start from what it holds
+        need = n + len(vals)
+        if need > len(buf):
+            grown = np.empty((max(need, 2 * len(buf), 1024),) + cur.shape[1:], cur.dtype)
+            grown[:n] = cur
+            buf = grown
+        buf[n:need] = vals
+        bufs[name] = buf
+        setattr(self, name, buf[:need])
+
     def add_entities(self, ids, start_pos, velocity, start_time, kind=0, pos0=None, list_index=None):
         """Append rows (host side); they reach the device at the next flush().  `list_index` (all rows
         or none, for the whole life of the store) says where each row sits in AirEnv's list when the
@@ -180,15 +199,15 @@ class EntityStore:
         ids = np.broadcast_to(np.asarray(ids, np.int64), (k,))
         p0 = sp if pos0 is None else np.asarray(pos0, np.float64).reshape(k, 3)
         first = self.n
-        self.h_ids = np.concatenate([self.h_ids, ids])
-        self.h_kind = np.concatenate([self.h_kind, np.full(k, kind, np.uint8)])
-        self.h_sp = np.concatenate([self.h_sp, sp]); self.h_vel = np.concatenate([self.h_vel, vel])
-        self.h_t0 = np.concatenate([self.h_t0, t0]); self.h_pos0 = np.concatenate([self.h_pos0, p0])
-        self.h_alive = np.concatenate([self.h_alive, np.ones(k, np.uint8)])
+        self._happend("h_ids", ids); self._happend("h_kind", np.full(k, kind, np.uint8))
+        self._happend("h_sp", sp); self._happend("h_vel", vel); self._happend("h_t0", t0); self._happend("h_pos0", p0)
+        self._happend("h_alive", np.ones(k, np.uint8))
         if list_index is not None:
             assert self.h_lidx is not None or first == 0, "list_index must be given for every row or for none"
             li = np.asarray(list_index, np.int32).reshape(k)
-            self.h_lidx = li.copy() if self.h_lidx is None else np.concatenate([self.h_lidx, li])
+            if self.h_lidx is None:
+                self.h_lidx = np.zeros(0, np.int32)
+            self._happend("h_lidx", li)
         else:
             assert self.h_lidx is None, "list_index must be given for every row or for none"
         if self.slots_of_id is not None and k <= 4096:
@@ -229,17 +248,17 @@ class EntityStore:
         """The next k table rows were written on the device (zrk_launch_salvo): count them in; the host mirrors
         take what the caller knows of them (nothing is uploaded)."""
         z3 = np.zeros((k, 3))
-        self.h_ids = np.concatenate([self.h_ids, np.asarray(ids, np.int64) if ids is not None else np.full(k, -1, np.int64)])
-        self.h_kind = np.concatenate([self.h_kind, np.full(k, kind, np.uint8)])
+        self._happend("h_ids", np.asarray(ids, np.int64) if ids is not None else np.full(k, -1, np.int64))
+        self._happend("h_kind", np.full(k, kind, np.uint8))
         sp = np.asarray(start_pos, np.float64).reshape(k, 3) if start_pos is not None else z3
-        self.h_sp = np.concatenate([self.h_sp, sp])
-        self.h_vel = np.concatenate([self.h_vel, np.asarray(velocity, np.float64).reshape(k, 3) if velocity is not None else z3])
-        self.h_t0 = np.concatenate([self.h_t0, np.broadcast_to(np.asarray(start_time, np.float64), (k,))])
-        self.h_pos0 = np.concatenate([self.h_pos0, sp])
-        self.h_alive = np.concatenate([self.h_alive, np.ones(k, np.uint8)])
+        self._happend("h_sp", sp)
+        self._happend("h_vel", np.asarray(velocity, np.float64).reshape(k, 3) if velocity is not None else z3)
+        self._happend("h_t0", np.broadcast_to(np.asarray(start_time, np.float64), (k,)))
+        self._happend("h_pos0", sp)
+        self._happend("h_alive", np.ones(k, np.uint8))
         if self.h_lidx is not None:
             li = np.asarray(list_index, np.int32) if list_index is not None else np.arange(self.n, self.n + k, dtype=np.int32)
-            self.h_lidx = np.concatenate([self.h_lidx, li])
+            self._happend("h_lidx", li)
         self.slots_of_id = None
         self.n += k
         self.n_uploaded += k
@@ -318,9 +337,9 @@ class EntityStore:
             self._snap[key] = self.d_pos[buf][:, :self.n_uploaded].T.contiguous().cpu().numpy()
         return self._snap[key]
 
-    def write_pos(self, slot, value):
+    def write_pos(self, slot, value, which="cur"):
         v = torch.as_tensor(np.asarray(value, np.float64).reshape(3), device=self.device)
-        self.d_pos[self.cur][:, int(slot)] = v
+        self.d_pos[self.cur if which == "cur" else self.cur ^ 1][:, int(slot)] = v
         self._bump()
 
     # -- kernels ------------------------------------------------------------------------------
