@@ -366,17 +366,20 @@ def main():
             return max(max(xchg["x"].counts(0)), max(xchg["x"].counts(1)))
         return max(max(e.counts()) for e in xchg["ex"])
 
-    # every tick's sweep is timed when the run is short, every 8th otherwise (one C call covers all ticks)
-    stride = 1 if args.steps <= 64 else 8
+    # every other tick's sweep is timed when the run is short, every 8th otherwise; the events are only recorded
+    # inside the timed region and read after it (one C call covers all ticks)
+    stride = 2 if args.steps <= 64 else 8
     if exchanging and not c_side:
         stride = 64                      # ticks driven one call at a time: reading the events drains the stream
+    deferred = not (exchanging and not c_side)
 
     def run_ticks(k, sweep_ms=None):
+        ps = (-stride if deferred else stride) if sweep_ms is not None else 1
         if not exchanging:
-            eng.run(k, sweep_ms=sweep_ms, prof_stride=stride)
+            eng.run(k, sweep_ms=None if deferred else sweep_ms, prof_stride=ps)
             return
         if c_side:
-            eng.run(k, sweep_ms=sweep_ms, prof_stride=stride, exchange=xchg["x"])
+            eng.run(k, sweep_ms=None if deferred else sweep_ms, prof_stride=ps, exchange=xchg["x"])
             return
         for j in range(k):               # rehearsal path: the exchange goes through torch.distributed, tick by tick
             b = xchg["tick"] & 1
@@ -399,15 +402,16 @@ def main():
 
     if exchanging:
         size_exchange(eng.store.cap)
-    # clocks: ~100 ms of an unrelated kernel (the noise self-test) before the warm-up steps, see the docstring
-    spin = torch.zeros(3 << 20, dtype=torch.float64, device=device)
-    t_spin = time.perf_counter()
-    st0 = eng.store
-    while (time.perf_counter() - t_spin) * 1e3 < SPINUP_MS:
-        for _ in range(8):
-            st0.ctx.check(st0.lib.zrk_selftest_noise(st0.ctx.handle, 1, 1, 3, 0, spin.data_ptr(), 1 << 20, None), "spin-up")
-        torch.cuda.synchronize(device)
-    del spin
+    def spin_up():
+        """~100 ms of an unrelated kernel (the noise self-test) so that the clocks are up when the timed steps start, as
+        they are inside any run longer than a few milliseconds (see the docstring)."""
+        buf = torch.zeros(3 << 20, dtype=torch.float64, device=device)
+        st0 = eng.store
+        t_spin = time.perf_counter()
+        while (time.perf_counter() - t_spin) * 1e3 < SPINUP_MS:
+            for _ in range(8):
+                st0.ctx.check(st0.lib.zrk_selftest_noise(st0.ctx.handle, 1, 1, 3, 0, buf.data_ptr(), 1 << 20, None), "spin-up")
+            torch.cuda.synchronize(device)
 
     run_ticks(args.warmup)
     overflow = False
@@ -421,6 +425,7 @@ def main():
     barrier()
     live0 = eng.alive_count()
     sweep_ms = np.zeros((args.steps + stride - 1) // stride, np.float32)
+    spin_up()
     barrier()
     t0 = time.perf_counter()
     run_ticks(args.steps, sweep_ms)
@@ -428,6 +433,8 @@ def main():
         drain_exchange()
     barrier()
     elapsed = time.perf_counter() - t0
+    if deferred:
+        sweep_ms[:] = eng.read_sweep_ms(len(sweep_ms))
     live1 = eng.alive_count()
     eng.store.compact_status()           # outside the timing: a compaction that did not run to completion raises here
     if exchanging:

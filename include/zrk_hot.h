@@ -357,6 +357,10 @@ int zrk_run_ticks_ensemble(zrk_ctx *ctx, const zrk_entities *ents, const zrk_mis
                            const zrk_ensemble *ens /* HOST */, void *workspace, int32_t *det_idx, int64_t det_stride,
                            int32_t *det_cnt, int K, float *sweep_ms /* HOST, may be NULL */, int prof_stride, void *stream);
 
+/* zrk_run_ticks* with prof_stride < 0 (sweep_ms may be NULL) only records the event pairs, every -prof_stride-th tick,
+ * and returns without synchronising; this reads the first n durations [ms] afterwards (it waits for them). */
+int zrk_read_sweep_ms(zrk_ctx *ctx, float *sweep_ms /* HOST out */, int n);
+
 /* Numerics self-test hooks used by tests/: y[i] = op(a[i], b[i]) in device binary64.
  * op: 0 sqrt(a), 1 a/b, 2 atan2(a,b), 3 asin(a), 4 fma-chain norm of (a,b,0). */
 int zrk_selftest_math(zrk_ctx *ctx, int op, const double *a, const double *b, double *y /* DEVICE */,

@@ -1806,6 +1806,7 @@ struct zrk_ctx {
         return d2_val[r];
     }
     std::vector<hipEvent_t> tev;       // timing events of zrk_run_ticks, reused
+    int tev_pending = 0;               // event pairs recorded by a deferred-profile call, not read yet
     const void *ring_key = nullptr;    // mask buffers zrk_run_ticks has been alternating between ...
     int64_t ring_age = 0;              // ... for this many consecutive ticks (>= 1: the next one starts cleared)
 };
@@ -2451,16 +2452,20 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         hipLaunchKernelGGL(k_ensemble_derive, dim3(nblocks((int64_t)now.S * ZRK_MAX_RADARS, kCompBlock)), dim3(kCompBlock), 0, s, now);
         if (int rc0 = check_launch(ctx, "k_ensemble_derive")) return rc0;
     }
-    const int stride = prof_stride > 0 ? prof_stride : 1;
-    const int n_prof = sweep_ms ? (K + stride - 1) / stride : 0;
+    // prof_stride < 0: record the events only; zrk_read_sweep_ms collects the times later (keeps the synchronisation and
+    // the reads out of a region the caller is timing)
+    const bool deferred = prof_stride < 0;
+    const int stride = prof_stride > 0 ? prof_stride : (prof_stride < 0 ? -prof_stride : 1);
+    const int n_prof = (sweep_ms || deferred) ? (K + stride - 1) / stride : 0;
     if (n_prof && !ensure_events(ctx, n_prof)) return fail(ctx, ZRK_E_HIP, "hipEventCreate");
+    ctx->tev_pending = deferred ? n_prof : 0;
     hipEvent_t *ev = n_prof ? ctx->tev.data() : nullptr;
     // the tail of an exchanged list carries this tick's detonations: [count, rows ...]
     const int64_t ev_words = (xio && xio->ev_capacity > 0) ? 1 + (int64_t)xio->ev_capacity : 0;
     int rc = 0;
     for (int k = 0; k < K && rc == 0; ++k) {
         st->cur ^= 1;
-        const bool prof = sweep_ms && (k % stride == 0);
+        const bool prof = n_prof && (k % stride == 0);
         if (prof && hipEventRecord(ev[2 * (k / stride)], s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "hipEventRecord"); break; }
         const int slot = (int)(st->tick & 1u);
         int64_t *list = xio ? xio->send[slot] : packed;
@@ -2534,7 +2539,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         st->time_ms += st->dt_ms;                                            // Manager.py:140
         st->tick += 1;
     }
-    if (n_prof) {
+    if (n_prof && !deferred) {
         if (hipStreamSynchronize(s) != hipSuccess && rc == 0) rc = fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
         for (int k = 0; k < n_prof; ++k) {
             float ms = 0.f;
@@ -2574,6 +2579,18 @@ ZRK_API int64_t zrk_ensemble_table_bytes(int scenarios)
 }
 
 ZRK_API double zrk_d2_threshold(double max_distance) { return d2_threshold(max_distance); }
+
+ZRK_API int zrk_read_sweep_ms(zrk_ctx *ctx, float *sweep_ms, int n)
+{
+    if (!ctx || !sweep_ms || n < 0) return fail(ctx, ZRK_E_INVALID, "zrk_read_sweep_ms: null argument");
+    if (n > ctx->tev_pending) return fail(ctx, ZRK_E_INVALID, "zrk_read_sweep_ms: fewer events were recorded");
+    for (int k = 0; k < n; ++k) {
+        if (hipEventSynchronize(ctx->tev[2 * k + 1]) != hipSuccess ||
+            hipEventElapsedTime(&sweep_ms[k], ctx->tev[2 * k], ctx->tev[2 * k + 1]) != hipSuccess)
+            return fail(ctx, ZRK_E_HIP, "zrk_read_sweep_ms: event not readable");
+    }
+    return 0;
+}
 
 ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int64_t m, zrk_loop *st,
                           zrk_radar *radars, const zrk_scan *scan, int R, void *workspace, int32_t *det_idx,

@@ -335,6 +335,14 @@ class HotPathEngine:
         st.n_stepped = st.n_uploaded
         st._bump()
 
+    def read_sweep_ms(self, n):
+        """Durations [ms] of the sweeps a run(..., prof_stride < 0) call recorded events around (waits for them)."""
+        C = self._C if hasattr(self, "_C") else __import__("ctypes")
+        out = np.zeros(int(n), np.float32)
+        st = self.store
+        st.ctx.check(st.lib.zrk_read_sweep_ms(st.ctx.handle, out.ctypes.data_as(C.POINTER(C.c_float)), int(n)), "zrk_read_sweep_ms")
+        return out
+
     # results (each synchronises) ---------------------------------------------------------------
     def alive_count(self):
         return int(self.store.d_alive[:self.store.n_uploaded].sum().item())
