@@ -13,6 +13,7 @@ Workloads (BASELINE.json `configs`):
   C3 (default)  configs[2]: 1e6 AirObjects, 16 radars, 1e4 missiles in flight per GPU -- the configuration
                 north_star quotes the HBM-roofline target on.  With N > 1 every rank holds such a shard (weak scaling).
   C2            configs[1]: 1e5 / 4 / 1e3 (launch-bound; weak scaling).
+  C3x4          C3's scene with 4e6 AirObjects: past the 256 MiB Infinity Cache, for the HBM reading of the roofline.
   C4            configs[3]: ONE seeded population of 1e7, rank g owns [g*1e7/N, (g+1)*1e7/N) (strong scaling).
   C5            configs[4]: Monte-Carlo ensemble, 128 independent scenarios x 1e4 targets per GPU in one batched table
                 (no exchange; weak scaling).
@@ -56,7 +57,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5", "tiny", "tiny4", "tiny5"])
+    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C3x4", "C4", "C5", "tiny", "tiny4", "tiny5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--selfcheck-launch", action="store_true",

@@ -280,11 +280,13 @@ __host__ __device__ inline void derive_radar(const zrk_radar &hr, double d2_max,
     // width <= 180: inside <=> cross(e_lo,p) > 0 and cross(p,e_hi) > 0; wider: either one, which is
     // min(-c1,-c2) < 0, so the edges are stored negated and az_sgn = -1 flips the minimum back
     h.az_sgn = (hi - lo <= 180.0) ? 1.f : -1.f;
-    h.elx = h.az_sgn * (float)cos(lo * deg); h.ely = h.az_sgn * (float)sin(lo * deg);
-    h.ehx = h.az_sgn * (float)cos(hi * deg); h.ehy = h.az_sgn * (float)sin(hi * deg);
+    double s_lo, c_lo, s_hi, c_hi;
+    sincos(lo * deg, &s_lo, &c_lo);
+    sincos(hi * deg, &s_hi, &c_hi);
     c.az_sgn = exact_only ? 0.0 : (double)h.az_sgn;        // ZRK_F_EXACT_ONLY: the reference's formula and nothing else
-    c.elx = (double)h.az_sgn * cos(lo * deg); c.ely = (double)h.az_sgn * sin(lo * deg);
-    c.ehx = (double)h.az_sgn * cos(hi * deg); c.ehy = (double)h.az_sgn * sin(hi * deg);
+    c.elx = (double)h.az_sgn * c_lo; c.ely = (double)h.az_sgn * s_lo;
+    c.ehx = (double)h.az_sgn * c_hi; c.ehy = (double)h.az_sgn * s_hi;
+    h.elx = (float)c.elx; h.ely = (float)c.ely; h.ehx = (float)c.ehx; h.ehy = (float)c.ehy;
     // elevation: dz >= 0 -> el = theta in [0,90];  dz < 0 -> el = 180 + theta in [90,180]
     const double lo_u = fmax(c.el_lo, 0.0), hi_u = fmin(c.el_hi, 90.0);
     if (lo_u <= hi_u) {
@@ -1349,28 +1351,25 @@ struct EnsembleArgs {
 
 __device__ void ensemble_derive(const EnsembleArgs &E, int part)
 {
+    // one thread per radar in use, densely (records of slots beyond R are never read: the classification masks them)
     const int64_t g = (int64_t)part * blockDim.x + threadIdx.x;
-    if (g >= (int64_t)E.S * ZRK_MAX_RADARS) return;
-    const int sc = (int)(g / ZRK_MAX_RADARS), r = (int)(g % ZRK_MAX_RADARS);
+    if (g >= (int64_t)E.S * E.R) return;
+    const int sc = (int)(g / E.R), r = (int)(g % E.R);
     RadarBlock *rb = E.table_out + sc;
-    RadarPre pre = RadarPre{};
-    pre.d2_out = -1.f;                                  // beyond R: nobody is a candidate
-    if (r < E.R) {
-        zrk_radar rd = E.state[(int64_t)sc * E.R + r];
-        if (E.advance) {
-            scan_advance_one(rd, E.scan[(int64_t)sc * E.R + r]);
-            E.state[(int64_t)sc * E.R + r] = rd;
-        }
-        RadarHot hot;
-        RadarCold cold;
-        derive_radar(rd, E.d2max[(int64_t)sc * E.R + r], (E.flags & ZRK_F_EXACT_ONLY) != 0, hot, cold);
-        derive_pre(rd, hot, (E.flags & ZRK_F_PHILOX) != 0, r, pre);
-        rb->cold[r] = cold;
-        const uint32_t *hwords = (const uint32_t *)&hot;
-        for (int k = 0; k < 20; ++k) rb->hotw[r][k] = hwords[k];
+    zrk_radar rd = E.state[g];
+    if (E.advance) {
+        scan_advance_one(rd, E.scan[g]);
+        E.state[g] = rd;
     }
+    RadarHot hot;
+    RadarCold cold;
+    RadarPre pre;
+    derive_radar(rd, E.d2max[g], (E.flags & ZRK_F_EXACT_ONLY) != 0, hot, cold);
+    derive_pre(rd, hot, (E.flags & ZRK_F_PHILOX) != 0, r, pre);
+    rb->cold[r] = cold;
+    const uint32_t *hwords = (const uint32_t *)&hot;
     const uint32_t *pwords = (const uint32_t *)&pre;
-    for (int k = 0; k < 20; ++k) rb->prew[r][k] = pwords[k];
+    for (int k = 0; k < 20; ++k) { rb->hotw[r][k] = hwords[k]; rb->prew[r][k] = pwords[k]; }
 }
 
 __global__ __launch_bounds__(kCompBlock) void k_ensemble_derive(const EnsembleArgs E) { ensemble_derive(E, (int)blockIdx.x); }
@@ -2070,11 +2069,14 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         if (++ctx->epoch == 0) ctx->epoch = 1;
         int lanes = 1;
         while (lanes < R + 1) lanes <<= 1;
-        // Workgroups that all fit on the device at once may wait for each other in blockIdx order; beyond that
-        // only tickets guarantee that whoever is waited for is already running.
-        // (in practice workgroups are dispatched in index order, which is what makes waiting in index order safe on an
-        // idle device; a union list means other ranks' collectives share the device, so there nothing is assumed)
-        int by_ticket = nbf > 2 * (int64_t)ctx->cus || packed != nullptr;
+        // Waiting in blockIdx order is safe because workgroups are DISPATCHED in blockIdx order: whoever is waited for
+        // got its slot before the waiter did, whatever else shares the device (another rank's kernels, a collective).
+        // HIP does not promise that order; this part does it, and the loop does not rest on it blindly: a wait that
+        // runs out raises the workspace's error word (zrk_compact_status, checked by HotPathEngine.detections() and
+        // after bench.py's timed region).  Grids that cannot be resident at once even alone take tickets from an atomic
+        // counter instead (about 5 us of serialised atomics at 500 workgroups), which needs no assumption at all;
+        // ZRK_COMPACT_ORDER=ticket forces that everywhere.
+        int by_ticket = nbf > 2 * (int64_t)ctx->cus;
         if (ctx->env_order >= 0) by_ticket = ctx->env_order;
         CompactArgs C;
         C.vis = vis_mask; C.zero_next = zero_next; C.n = n; C.R = R; C.nb = (int)nbf; C.items = items; C.lanes = lanes;
@@ -2086,7 +2088,7 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         EnsembleArgs E;
         std::memset(&E, 0, sizeof(E));
         if (ens) E = ens->next;
-        const int eparts = ens ? nblocks((int64_t)E.S * ZRK_MAX_RADARS, kCompBlock) : 0;
+        const int eparts = ens ? nblocks((int64_t)E.S * E.R, kCompBlock) : 0;
         hipLaunchKernelGGL(k_compact_fused, dim3((int)nbf + (M.m > 0 ? 1 : 0) + (O.nb > 0 ? 1 : 0) + eparts), dim3(kCompBlock), 0, s,
                            C, by_ticket, M, O, E);
         return check_launch(ctx, "k_compact_fused");
@@ -2449,7 +2451,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         // the records of the first tick of this call, from the angles as they stand
         EnsembleArgs now = EL.next;
         now.advance = 0; now.table_out = ens_tables[st->tick & 1u];
-        hipLaunchKernelGGL(k_ensemble_derive, dim3(nblocks((int64_t)now.S * ZRK_MAX_RADARS, kCompBlock)), dim3(kCompBlock), 0, s, now);
+        hipLaunchKernelGGL(k_ensemble_derive, dim3(std::max(1, nblocks((int64_t)now.S * now.R, kCompBlock))), dim3(kCompBlock), 0, s, now);
         if (int rc0 = check_launch(ctx, "k_ensemble_derive")) return rc0;
     }
     // prof_stride < 0: record the events only; zrk_read_sweep_ms collects the times later (keeps the synchronisation and

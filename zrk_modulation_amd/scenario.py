@@ -10,6 +10,8 @@ WORKLOADS = {
     "C2": (100_000, 4, 1_000),
     "C3": (1_000_000, 16, 10_000),
     "C4": (10_000_000, 16, 10_000),           # ONE population of 1e7, cut into contiguous shards (strong scaling)
+    "C3x4": (4_000_000, 16, 10_000),          # C3's scene at four times the rows: the per-tick footprint no longer fits
+                                              # the 256 MiB Infinity Cache, so the sweep's bytes really come from HBM
     "tiny": (4_096, 4, 64),
     "tiny4": (16_384, 4, 64),                 # C4's mechanics at test size
 }
@@ -18,7 +20,7 @@ ENSEMBLES = {
     "C5": (128, 10_000, 4, 100),
     "tiny5": (6, 1_000, 3, 10),
 }
-SEEDS = {"C2": 1236, "C3": 1237, "C4": 1238, "C5": 1239, "tiny": 1234, "tiny4": 1235, "tiny5": 1233}
+SEEDS = {"C2": 1236, "C3": 1237, "C3x4": 1237, "C4": 1238, "C5": 1239, "tiny": 1234, "tiny4": 1235, "tiny5": 1233}
 STRONG = ("C4", "tiny4")
 CHUNK = 62_500                                # rows per independently seeded chunk of a sharded population
 
