@@ -1374,8 +1374,23 @@ __device__ void ensemble_derive(const EnsembleArgs &E, int part)
 
 __global__ __launch_bounds__(kCompBlock) void k_ensemble_derive(const EnsembleArgs E) { ensemble_derive(E, (int)blockIdx.x); }
 
+// One scenario: the host derived the records; this puts them where the sweep's scalar and vector loads find them in
+// ordinary (cacheable) device memory instead of the kernel-argument segment.
+struct PutArgs {
+    uint32_t *dst;               // NULL: nothing to put
+    RadarBlock rb;
+};
+
+__device__ void put_radar_block(const PutArgs &U)
+{
+    const uint32_t *src = (const uint32_t *)&U.rb;
+    for (int k = threadIdx.x; k < (int)(sizeof(RadarBlock) / 4); k += blockDim.x) U.dst[k] = src[k];
+}
+
+__global__ __launch_bounds__(256) void k_put_radar_block(const PutArgs U) { put_radar_block(U); }
+
 __global__ __launch_bounds__(kCompBlock) void k_compact_fused(const CompactArgs C, int by_ticket, const MissileArgs M,
-                                                              const OrderArgs O, const EnsembleArgs E)
+                                                              const OrderArgs O, const EnsembleArgs E, const PutArgs U)
 {
     __shared__ int s_wave[kCompBlock / 64];
     __shared__ CompactShared<kCompBlock> S;
@@ -1383,7 +1398,8 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_fused(const CompactArgs 
         int extra = (int)blockIdx.x - C.nb;
         if (M.m > 0 && extra-- == 0) { missile_finish_entry(s_wave, M); return; }
         if (O.nb > 0 && extra-- == 0) { build_order(s_wave, O); return; }
-        if (E.S > 0) ensemble_derive(E, extra);
+        if (E.S > 0) { ensemble_derive(E, extra); return; }
+        if (U.dst) put_radar_block(U);              // one scenario: the next tick's records, derived by the host
         return;
     }
     compact_block<kCompBlock>(S, C, by_ticket);
@@ -1857,7 +1873,7 @@ Workspace carve(void *ws, int nb, int64_t n_max)
     w.offs = w.counts + (int64_t)(ZRK_MAX_RADARS + 1) * nb;
     w.cost = w.counts + ((2 * (int64_t)(ZRK_MAX_RADARS + 1) * comp_blocks(n_max) + 63) & ~(int64_t)63);
     w.order = w.cost + order_ints(n_max);
-    w.boxes = (WaveBox *)(w.order + order_ints(n_max));
+    w.boxes = (WaveBox *)((char *)(w.order + order_ints(n_max)) + 2 * sizeof(RadarBlock));   // (two RadarBlocks in front)
     return w;
 }
 
@@ -1920,8 +1936,9 @@ ZRK_API const char *zrk_last_error(zrk_ctx *ctx) { return ctx ? ctx->err.c_str()
 ZRK_API int64_t zrk_workspace_bytes(int64_t n_max)
 {
     if (n_max < 0) return ZRK_E_INVALID;
-    return kFusedBytes + (2 * order_ints(n_max) + box_ints(n_max) + 64 + 64 + 2 * (int64_t)(ZRK_MAX_RADARS + 1) * comp_blocks(n_max)) *
-                             (int64_t)sizeof(int32_t);
+    return kFusedBytes + 2 * (int64_t)sizeof(RadarBlock) +
+           (2 * order_ints(n_max) + box_ints(n_max) + 64 + 64 + 2 * (int64_t)(ZRK_MAX_RADARS + 1) * comp_blocks(n_max)) *
+               (int64_t)sizeof(int32_t);
 }
 
 namespace {
@@ -1948,6 +1965,24 @@ MissileArgs missile_args(const zrk_entities *e, int cur, const zrk_missiles *mis
     return M;
 }
 
+// The records of one scenario's radars, derived on the host from their current angles.
+void fill_radar_block(zrk_ctx *ctx, const zrk_radar *radars, int R, uint32_t flags, RadarBlock &rb)
+{
+    std::memset(&rb, 0, sizeof(rb));
+    for (int r = 0; r < ZRK_MAX_RADARS; ++r) {
+        RadarPre pre;
+        std::memset(&pre, 0, sizeof(pre));
+        pre.d2_out = -1.f;                                  // beyond R: nobody is a candidate
+        if (r < R) {
+            RadarHot hot;
+            derive_radar(radars[r], ctx->d2_of(radars[r].max_distance, r), (flags & ZRK_F_EXACT_ONLY) != 0, hot, rb.cold[r]);
+            std::memcpy(rb.hotw[r], &hot, sizeof(hot));
+            derive_pre(radars[r], hot, (flags & ZRK_F_PHILOX) != 0, r, pre);
+        }
+        std::memcpy(rb.prew[r], &pre, sizeof(pre));
+    }
+}
+
 // What a batched ensemble adds to the two launches of a tick.
 struct EnsLaunch {
     const char *rb_table;          // this tick's records, [S] RadarBlock
@@ -1960,9 +1995,9 @@ struct EnsLaunch {
 int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_t time_ms, const zrk_radar *radars,
                  int R, uint32_t flags, uint64_t seed, uint64_t tick, int64_t gid0, void *workspace, void *stream,
                  const MissileArgs &M, uint32_t *vis = nullptr, int32_t *cost = nullptr, const int32_t *order = nullptr,
-                 WaveBox *boxes = nullptr, const EnsLaunch *ens = nullptr)
+                 WaveBox *boxes = nullptr, const EnsLaunch *ens = nullptr, const RadarBlock *rb_device = nullptr)
 {
-    if (!ctx || !e || !workspace || (R > 0 && !radars && !ens)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
+    if (!ctx || !e || !workspace || (R > 0 && !radars && !ens && !rb_device)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
     if (R < 0 || R > ZRK_MAX_RADARS)
         return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: radar count out of range");
     if (n < 0 || n > e->capacity || (cur != 0 && cur != 1)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: n/cur out of range");
@@ -1982,19 +2017,12 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
     P.bps_magic = ens ? (uint32_t)((0x100000000ull + (uint64_t)ens->bps - 1) / (uint64_t)ens->bps) : 0u;
     if (ctx->diag & 1u) P.flags |= kNoInside;
     if (ctx->diag & 2u) P.flags |= kNoBoxCache;
-    std::memset(&P.rb, 0, sizeof(P.rb));
-    for (int r = 0; r < ZRK_MAX_RADARS && !ens; ++r) {
-        RadarPre pre;
-        std::memset(&pre, 0, sizeof(pre));
-        pre.d2_out = -1.f;                                  // beyond R: nobody is a candidate
-        if (r < R) {
-            RadarHot hot;
-            derive_radar(radars[r], ctx->d2_of(radars[r].max_distance, r), (flags & ZRK_F_EXACT_ONLY) != 0, hot, P.rb.cold[r]);
-            std::memcpy(P.rb.hotw[r], &hot, sizeof(hot));
-            derive_pre(radars[r], hot, (flags & ZRK_F_PHILOX) != 0, r, pre);
-        }
-        std::memcpy(P.rb.prew[r], &pre, sizeof(pre));
-    }
+    // the records: in the kernel-argument segment (a stand-alone sweep), or already in device memory -- an ensemble's
+    // table, or the block the previous tick's compaction launch put there (zrk_run_ticks), which the sweep's loads find
+    // in cacheable memory instead of re-fetching the argument segment in every workgroup
+    if (rb_device) P.rb_table = (const char *)rb_device;
+    if (ens || rb_device) std::memset(&P.rb, 0, sizeof(P.rb));
+    else fill_radar_block(ctx, radars, R, flags, P.rb);
     const dim3 grid(P.nb + P.mb);                           // leading workgroups step the missiles
     using Kernel = void (*)(const SweepParams, const MissileArgs);
     static const Kernel variants[8] = {
@@ -2034,7 +2062,7 @@ bool compacts_in_one_launch(const zrk_ctx *ctx, int64_t n)
 int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int32_t base_index, void *workspace,
                    int32_t *det_idx, int64_t det_stride, int32_t *det_cnt, int64_t *packed, int64_t packed_capacity,
                    int64_t gid0, void *stream, const MissileArgs &M, uint32_t *zero_next, const OrderArgs &O,
-                   bool union_bits = false, const EnsLaunch *ens = nullptr)
+                   bool union_bits = false, const EnsLaunch *ens = nullptr, const PutArgs *put = nullptr)
 {
     if (!ctx || !vis_mask || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_compact: null argument");
     if ((det_idx && !det_cnt) || (!det_idx && !packed)) return fail(ctx, ZRK_E_INVALID, "zrk_compact: no output requested");
@@ -2088,9 +2116,10 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         EnsembleArgs E;
         std::memset(&E, 0, sizeof(E));
         if (ens) E = ens->next;
-        const int eparts = ens ? nblocks((int64_t)E.S * E.R, kCompBlock) : 0;
+        const int eparts = ens ? nblocks((int64_t)E.S * E.R, kCompBlock) : ((put && put->dst) ? 1 : 0);
+        static PutArgs no_put;                       // (zero-initialised: dst == NULL)
         hipLaunchKernelGGL(k_compact_fused, dim3((int)nbf + (M.m > 0 ? 1 : 0) + (O.nb > 0 ? 1 : 0) + eparts), dim3(kCompBlock), 0, s,
-                           C, by_ticket, M, O, E);
+                           C, by_ticket, M, O, E, (put && !ens) ? *put : no_put);
         return check_launch(ctx, "k_compact_fused");
     }
     const int nb = nblocks(n, kCompBlock);
@@ -2457,6 +2486,22 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     // prof_stride < 0: record the events only; zrk_read_sweep_ms collects the times later (keeps the synchronisation and
     // the reads out of a region the caller is timing)
     const bool deferred = prof_stride < 0;
+    // one scenario with compaction every tick: the radar records go through device memory (two blocks in the workspace,
+    // alternating); the first of this call by a launch of its own, the later ones by the previous tick's compaction
+    PutArgs put;
+    put.dst = nullptr;
+    RadarBlock *rb_dev[2] = {nullptr, nullptr};
+    const bool rb_through_memory = !ens && R > 0 && radars && (det_idx || packed || xio) && st->n > 0 &&
+                                   compacts_in_one_launch(ctx, st->n) && K > 0;
+    if (rb_through_memory) {
+        Workspace w0 = carve(workspace, 0, e->capacity);
+        rb_dev[0] = (RadarBlock *)((char *)w0.boxes - 2 * sizeof(RadarBlock));
+        rb_dev[1] = rb_dev[0] + 1;
+        fill_radar_block(ctx, radars, R, st->flags, put.rb);
+        put.dst = (uint32_t *)rb_dev[st->tick & 1u];
+        hipLaunchKernelGGL(k_put_radar_block, dim3(1), dim3(256), 0, s, put);
+        if (int rc0 = check_launch(ctx, "k_put_radar_block")) return rc0;
+    }
     const int stride = prof_stride > 0 ? prof_stride : (prof_stride < 0 ? -prof_stride : 1);
     const int n_prof = (sweep_ms || deferred) ? (K + stride - 1) / stride : 0;
     if (n_prof && !ensure_events(ctx, n_prof)) return fail(ctx, ZRK_E_HIP, "hipEventCreate");
@@ -2516,7 +2561,13 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (!ordering) ctx->order_ready = false;
         rc = launch_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse, st->seed,
                           st->tick, st->gid0, workspace, stream, M, vis_now, ordering ? w.cost : nullptr,
-                          (ordering && ctx->order_ready) ? w.order : nullptr, w.boxes, ens ? &EL : nullptr);
+                          (ordering && ctx->order_ready) ? w.order : nullptr, w.boxes, ens ? &EL : nullptr,
+                          rb_through_memory ? rb_dev[st->tick & 1u] : nullptr);
+        if (!ens) zrk_scan_advance(radars, scan, R);                          // Radar.py:205 (an ensemble's: on the device)
+        if (rb_through_memory) {                                             // the next tick's records ride with this compaction
+            fill_radar_block(ctx, radars, R, st->flags, put.rb);
+            put.dst = (uint32_t *)rb_dev[(st->tick + 1) & 1u];
+        }
         if (prof && rc == 0 && hipEventRecord(ev[2 * (k / stride) + 1], s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipEventRecord");
         // this slot's list was last sent two ticks ago: that collective must have read it before it is rewritten
         if (rc == 0 && xio && zrk_exchange_wait(xio->x, slot, stream) != 0) rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
@@ -2524,7 +2575,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, list,
                                 list_words, st->gid0, stream, M, vis_next,
                                 ordering ? OrderArgs{w.cost, w.order, nbs, 0} : OrderArgs{nullptr, nullptr, 0, 0},
-                                (st->flags & ZRK_F_UNION_BITS) != 0, ens ? &EL : nullptr);
+                                (st->flags & ZRK_F_UNION_BITS) != 0, ens ? &EL : nullptr, rb_through_memory ? &put : nullptr);
         if (rc == 0 && ordering) ctx->order_ready = true;
         if (rc == 0 && m > 0 && !fused) rc = zrk_missile_step(ctx, e, st->cur, mis, m, st->time_ms, st->dt_ms, 1, stream);
         if (rc == 0 && ev_words && !fused) {
@@ -2537,7 +2588,6 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         // the collective of this tick, behind the compaction on RCCL's own stream: it overlaps the next tick's sweep
         if (rc == 0 && xio && zrk_exchange_all_gather(xio->x, slot, list, xio->recv[slot], xio->words, stream) != 0)
             rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
-        if (!ens) zrk_scan_advance(radars, scan, R);                          // Radar.py:205 (an ensemble's: on the device)
         st->time_ms += st->dt_ms;                                            // Manager.py:140
         st->tick += 1;
     }
