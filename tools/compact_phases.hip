@@ -42,7 +42,10 @@ int main(int argc, char **argv)
         C.vis = dvis; C.zero_next = dzero; C.n = n; C.R = R; C.nb = nb; C.items = items; C.lanes = lanes; C.epoch = (uint32_t)(rep + 1);
         C.base_index = 0; C.ctl = w.ctl; C.agg = w.agg; C.det_idx = det; C.det_stride = n; C.det_cnt = cnt; C.packed = packed;
         C.packed_capacity = n + 1; C.gid0 = 0;
-        hipLaunchKernelGGL(k_compact_fused, dim3(nb), dim3(kCompBlock), 0, 0, C, by_ticket, M, OrderArgs{nullptr, nullptr, 0, 0});
+        EnsembleArgs E; std::memset(&E, 0, sizeof(E));
+        static PutArgs U;
+        C.seg_blocks = 0; C._pad1 = 0; C.seg_slots = 0;
+        hipLaunchKernelGGL(k_compact_fused, dim3(nb), dim3(kCompBlock), 0, 0, C, by_ticket, M, OrderArgs{nullptr, nullptr, 0, 0}, E, U);
         if (rep == 29) hipEventRecord(e1, 0);
     }
     hipDeviceSynchronize();
