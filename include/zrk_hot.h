@@ -234,6 +234,26 @@ int zrk_launch_salvo(zrk_ctx *ctx, const zrk_entities *ents, int cur, const zrk_
                      const zrk_launch_req *req /* DEVICE */, zrk_launch_res *res /* DEVICE */, int64_t k,
                      int64_t time_ms, int32_t list_base, int32_t *count_out /* DEVICE */, void *stream);
 
+/*
+ * Track association of the command post for all detections of a tick.
+ *   replaces: the `link_object` calls of CombatControlPoint.step (modules/CCP.py:171-219, made in the order of
+ *             modules/CCP.py:414-429) -- the part of the command post that is quadratic in the reference.
+ * Detection d (in processing order: radar after radar, list order, every object once) has position det_pos[d]
+ * (obj.pos as the command post sees it) and speed det_speed[d] (obj.speed_mod).  Track t (target tracks first, then
+ * missile tracks, each in the order the command post's dictionaries hold them) has the reference position trk_ref[t]
+ * (track.target.prev_pos; for a missile track missile.prev_pos, or missile.pos where that is None) and the time
+ * trk_upd[t] of its last update [s].  A track updated at now_s is skipped; a detection takes the strictly nearest
+ * track whose distance lies within [max(0, speed * (age - slack_s)), max(0, speed * (age + slack_s))], age = now_s -
+ * trk_upd[t] (slack_s = POSSIBLE_TARGET_RADIUS * dt, modules/constants.py:31); a track taken by an earlier detection of
+ * the tick is gone for the later ones.  match[d] = index of the track, or -1 (NEW_TARGET).  Synchronises the
+ * stream (it reads a counter back after every resolution round).
+ */
+int zrk_ccp_link(zrk_ctx *ctx, const double *det_pos /* DEVICE [D][3] */, const double *det_speed /* DEVICE [D] */,
+                 int64_t D, const double *trk_ref /* DEVICE [T][3] */, const double *trk_upd /* DEVICE [T] */, int64_t T,
+                 double now_s, double slack_s, int32_t *match /* DEVICE [D] out */,
+                 void *scratch /* DEVICE, zrk_ccp_scratch_bytes(D, T) */, void *stream);
+int64_t zrk_ccp_scratch_bytes(int64_t D, int64_t T);
+
 /* Static scan parameters of one radar (modules/Radar.py:13-42): what
  * move_to_next_sector_circular reads besides the current angles. */
 typedef struct {

@@ -66,6 +66,8 @@ def lib():
     L.zo_noise_apply.argtypes = [i64, i32p, dp, i64, dp]
     L.zo_scan_next.restype = None
     L.zo_scan_next.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp]
+    L.zo_ccp_link.restype = None
+    L.zo_ccp_link.argtypes = [i64, dp, dp, i64, dp, dp, C.c_double, C.c_double, i32p, dp]
     L.zo_launch_solve.restype = C.c_int
     L.zo_launch_solve.argtypes = [dp, dp, dp, C.c_double, C.c_double, C.c_double, dp, dp]
     L.zo_philox_noise.restype = None
@@ -133,6 +135,21 @@ def launch_solve(tp, mp, tvu, tsm, v0, period):
     rc = lib().zo_launch_solve(dptr(tp), dptr(mp), dptr(tvu), float(tsm), float(v0), float(period),
                                dptr(V), C.byref(t))
     return rc, V, t.value
+
+
+def ccp_link(det_pos, det_speed, trk_ref, trk_upd, now_s, slack_s):
+    """CombatControlPoint.link_object for all detections of a tick, sequentially (reference modules/CCP.py:171-219)."""
+    det_pos = np.ascontiguousarray(det_pos, np.float64).reshape(-1, 3)
+    trk_ref = np.ascontiguousarray(trk_ref, np.float64).reshape(-1, 3)
+    D, T = len(det_pos), len(trk_ref)
+    det_speed = np.ascontiguousarray(det_speed, np.float64).reshape(D)
+    trk_upd = np.ascontiguousarray(trk_upd, np.float64).reshape(T)
+    match = np.full(max(D, 1), -1, np.int32)
+    scratch = np.zeros(max(T, 1))
+    pad = lambda a: a if a.size else np.zeros(3)          # noqa: E731  (ctypes wants a buffer)
+    lib().zo_ccp_link(D, dptr(pad(det_pos)), dptr(pad(det_speed)), T, dptr(pad(trk_ref)), dptr(pad(trk_upd)), float(now_s),
+                      float(slack_s), i32ptr(match), dptr(scratch))
+    return match[:D]
 
 
 def philox_noise(seed, tick, ordinal, entity):

@@ -384,3 +384,35 @@ ZO_API int64_t zo_compact_bit(int64_t n, const uint32_t *vis_mask, int r, int32_
         if ((vis_mask[i] >> r) & 1u) out_idx[k++] = base + (int32_t)i;
     return k;
 }
+
+/* ------------------------------------------------------------------------- *
+ * CombatControlPoint.link_object for every detection of a tick, in the order
+ * CombatControlPoint.step makes the calls (modules/CCP.py:171-219, :414-429):
+ * the strictly nearest track -- scan order = index order: target tracks, then
+ * missile tracks -- whose distance lies in [max(0, v (age - slack)),
+ * max(0, v (age + slack))] (calc_range, :176-186), tracks updated "now"
+ * skipped (:188, :203); a match updates the track (old_target / old_rocket,
+ * :338-366), so it is out of every later detection's scan.  match[d] = track
+ * index or -1 (NEW_TARGET).  np.linalg.norm as elsewhere: sqrt of the fma chain.
+ * ------------------------------------------------------------------------- */
+ZO_API void zo_ccp_link(int64_t D, const double *det_pos, const double *det_speed, int64_t T, const double *trk_ref,
+                        const double *trk_upd_in, double now_s, double slack_s, int32_t *match, double *upd_scratch)
+{
+    for (int64_t t = 0; t < T; ++t) upd_scratch[t] = trk_upd_in[t];
+    for (int64_t d = 0; d < D; ++d) {
+        double best = INFINITY;
+        int32_t m = -1;
+        for (int64_t t = 0; t < T; ++t) {
+            if (upd_scratch[t] == now_s) continue;
+            double age = now_s - upd_scratch[t];
+            double lo = det_speed[d] * (age - slack_s), hi = det_speed[d] * (age + slack_s);
+            if (!(lo > 0.0)) lo = 0.0;
+            if (!(hi > 0.0)) hi = 0.0;
+            double dist = zo_norm3(trk_ref[3 * t] - det_pos[3 * d], trk_ref[3 * t + 1] - det_pos[3 * d + 1],
+                                   trk_ref[3 * t + 2] - det_pos[3 * d + 2]);
+            if (dist < best && lo <= dist && dist <= hi) { best = dist; m = (int32_t)t; }
+        }
+        match[d] = m;
+        if (m >= 0) upd_scratch[m] = now_s;
+    }
+}

@@ -36,3 +36,35 @@ def test_known_answers_of_stock_runs():
     fx = Fixture("stock_simulation_config_copy_seed0")
     assert fx.n_ticks == 200 and sum(fx.histogram.values()) == 800 and len(fx.found_ids) == 100
     assert len(fx.detonations) == 0
+
+
+def test_oracle_association_equals_the_reference_loop_in_numpy():
+    """oracle/zrk_oracle.c::zo_ccp_link is the reference's link_object loop (modules/CCP.py:171-219, :414-429): pinned
+    here against that loop written out with numpy exactly as the reference writes it (np.linalg.norm, max(0, .),
+    strict <), on this host's numpy -- the one the golden fixtures come from."""
+    from oracle import oracle as O
+    g = np.random.Generator(np.random.PCG64(1))
+    T, D = 70, 60
+    trk = g.uniform(-300, 300, (T, 3))
+    det = np.where(g.uniform(size=(D, 1)) < 0.8, trk[g.integers(0, T, D)] + g.normal(0, 30, (D, 3)), g.uniform(-300, 300, (D, 3)))
+    sp = g.uniform(50, 900, D)
+    now, slack = 12.34, 1.0
+    upd = now - g.choice([0.01, 0.02, 0.5, 3.0], T)
+    upd[g.uniform(size=T) < 0.1] = now
+    got = O.ccp_link(det, sp, trk, upd, now, slack)
+    u = upd.copy()
+    want = np.full(D, -1, np.int32)
+    for d in range(D):
+        best, m = float("inf"), -1
+        for t in range(T):
+            if u[t] == now:
+                continue
+            age = now - u[t]
+            lo, hi = max(0, sp[d] * (age - slack)), max(0, sp[d] * (age + slack))
+            dist = np.linalg.norm(trk[t] - det[d])
+            if dist < best and lo <= dist <= hi:
+                best, m = dist, t
+        want[d] = m
+        if m >= 0:
+            u[m] = now
+    assert np.array_equal(got, want) and (want >= 0).sum() > 20

@@ -201,6 +201,9 @@ _PROTOTYPES = {
     "zrk_launch_salvo": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.c_int, C.POINTER(ZrkMissiles), C.c_int64,
                                    C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
                                    C.c_void_p]),
+    "zrk_ccp_link": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                               C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "zrk_ccp_scratch_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "zrk_selftest_math": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                     C.c_void_p]),
     "zrk_selftest_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64, C.c_void_p,

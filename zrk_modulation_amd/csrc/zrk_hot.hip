@@ -1745,6 +1745,137 @@ __global__ __launch_bounds__(1024) void k_launch_append(const zrk_launch_req *__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Track association of the command post: CombatControlPoint.link_object
+// (modules/CCP.py:171-219) for ALL detections of a tick, with the result the reference's sequential loop
+// (modules/CCP.py:414-429) produces.  For one detection the reference scans the target tracks, then the missile
+// tracks, and keeps the strictly nearest one whose distance lies in an annulus [speed * (age - slack),
+// speed * (age + slack)] clipped at 0, skipping tracks updated this tick; a match updates the track, which takes it
+// out of every later detection's scan.  So the tick is a greedy matching with removal, in detection order: the
+// pairwise part (every detection against every track) is independent per detection and runs LDS-tiled below; the
+// order-dependent part only ever chooses among a detection's few in-gate candidates and is resolved in rounds.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCcpK = 8;                       // in-gate candidates kept per detection (nearest first)
+constexpr int kCcpTile = 1024;                 // tracks staged in LDS per step
+
+struct CcpCand {
+    double dist[kCcpK];
+    int32_t idx[kCcpK];
+    int32_t n;                                 // candidates kept
+    int32_t total;                             // candidates in gate (> kCcpK: the list is a prefix)
+};
+
+// One thread per detection; the tracks stream through LDS in tiles.  `taken` (may be NULL) excludes tracks already
+// given away (the re-scan of a detection whose kept candidates were all taken); `only` (may be NULL) restricts the
+// pass to the listed detections.
+__global__ __launch_bounds__(256) void k_ccp_candidates(const double *__restrict__ det_pos, const double *__restrict__ det_speed,
+                                                        int64_t D, const double *__restrict__ trk_ref,
+                                                        const double *__restrict__ trk_upd, int64_t T, double now_s,
+                                                        double slack_s, const uint8_t *__restrict__ taken,
+                                                        const uint8_t *__restrict__ only, CcpCand *__restrict__ out)
+{
+    __shared__ double s_ref[3][kCcpTile];
+    __shared__ double s_upd[kCcpTile];
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool mine = d < D && (!only || only[d]);
+    double px = 0.0, py = 0.0, pz = 0.0, sp = 0.0;
+    if (mine) { px = det_pos[3 * d]; py = det_pos[3 * d + 1]; pz = det_pos[3 * d + 2]; sp = det_speed[d]; }
+    CcpCand c;
+    c.n = 0; c.total = 0;
+#pragma unroll
+    for (int k = 0; k < kCcpK; ++k) { c.dist[k] = __builtin_inf(); c.idx[k] = -1; }
+    for (int64_t base = 0; base < T; base += kCcpTile) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < kCcpTile; j += 256) {
+            const int64_t t = base + j;
+            const bool ok = t < T && !(taken && taken[t]);
+            s_ref[0][j] = ok ? trk_ref[3 * t] : 0.0; s_ref[1][j] = ok ? trk_ref[3 * t + 1] : 0.0;
+            s_ref[2][j] = ok ? trk_ref[3 * t + 2] : 0.0;
+            s_upd[j] = ok ? trk_upd[t] : now_s;               // updated "now": skipped, modules/CCP.py:188, :203
+        }
+        __syncthreads();
+        if (!mine) continue;
+        const int lim = (int)((T - base < kCcpTile) ? (T - base) : kCcpTile);
+        for (int j = 0; j < lim; ++j) {
+            const double upd = s_upd[j];
+            if (upd == now_s) continue;
+            // calc_range, modules/CCP.py:176-186: np.linalg.norm(track_pos - detected.pos), the two clipped ranges
+            const double dx = s_ref[0][j] - px, dy = s_ref[1][j] - py, dz = s_ref[2][j] - pz;
+            const double dist = sqrt(dot3(dx, dy, dz, dx, dy, dz));
+            const double age = now_s - upd;
+            double lo = sp * (age - slack_s), hi = sp * (age + slack_s);
+            lo = (lo > 0.0) ? lo : 0.0; hi = (hi > 0.0) ? hi : 0.0;
+            if (!(lo <= dist && dist <= hi)) continue;
+            c.total += 1;
+            // keep the kCcpK nearest, earlier track first among equals (the scan's strict `<`)
+            if (c.n < kCcpK || dist < c.dist[kCcpK - 1]) {
+                int pos = (c.n < kCcpK) ? c.n : kCcpK - 1;
+#pragma unroll
+                for (int k = kCcpK - 1; k > 0; --k) {
+                    if (k <= pos && c.dist[k - 1] > dist) { c.dist[k] = c.dist[k - 1]; c.idx[k] = c.idx[k - 1]; pos = k - 1; }
+                }
+                c.dist[pos] = dist; c.idx[pos] = (int32_t)(base + j);
+                if (c.n < kCcpK) c.n += 1;
+            }
+        }
+    }
+    if (mine) out[d] = c;
+}
+
+// One round of the order-dependent part.  Phase 0: every unresolved detection names the first candidate of its list
+// that nobody has been given yet and registers, for every such candidate still in its list, the smallest index of an
+// unresolved detection interested in it.  Phase 1: a detection whose named track has nobody earlier interested in it
+// takes it for good -- no earlier detection can ever claim it, and nothing nearer in its own list is free.
+__global__ void k_ccp_round(int phase, int64_t D, const CcpCand *__restrict__ cand, uint8_t *taken, int32_t *interest,
+                            int32_t *match, uint8_t *state /* 0 unresolved, 1 resolved, 2 needs a re-scan */, int32_t *counters)
+{
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D || state[d] == 1) return;
+    if (state[d] == 2) {                         // waiting for its re-scan: still holds everybody behind it
+        if (phase == 0) atomicMin(&counters[2], (int32_t)d);
+        return;
+    }
+    const CcpCand &c = cand[d];
+    int first = -1;
+    for (int k = 0; k < c.n; ++k) {
+        const int t = c.idx[k];
+        if (taken[t]) continue;
+        if (first < 0) first = t;
+        if (phase == 0) atomicMin(&interest[t], (int32_t)d);
+    }
+    // a detection whose kept list is only a prefix of what is in its gate may yet turn to tracks it has not named:
+    // nobody behind it takes anything for good before it is settled
+    if (phase == 0) {
+        if (c.total > c.n) atomicMin(&counters[2], (int32_t)d);
+        return;
+    }
+    if ((int32_t)d > counters[2]) { atomicAdd(&counters[0], 1); return; }
+    if (first < 0) {
+        if (c.total > c.n) { state[d] = 2; atomicAdd(&counters[1], 1); }      // the kept prefix is used up: look again
+        else { match[d] = -1; state[d] = 1; }                                 // NEW_TARGET
+        return;
+    }
+    if (interest[first] == (int32_t)d) { match[d] = first; state[d] = 1; taken[first] = 1; }
+    else atomicAdd(&counters[0], 1);                                          // still waiting for somebody earlier
+}
+
+__global__ void k_ccp_rescan_prepare(int64_t D, uint8_t *only, uint8_t *state)
+{
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    const bool again = only[d] == 2;
+    only[d] = again ? 1 : 0;
+    if (again) state[d] = 0;
+}
+
+__global__ void k_ccp_reset_interest(int64_t D, const CcpCand *__restrict__ cand, const uint8_t *__restrict__ state, int32_t *interest)
+{
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D || state[d] == 1) return;
+    const CcpCand &c = cand[d];
+    for (int k = 0; k < c.n; ++k) interest[c.idx[k]] = 0x7FFFFFFF;
+}
+
 __global__ void k_selftest_math(int op, const double *a, const double *b, double *y, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2258,6 +2389,59 @@ ZRK_API int zrk_launch_salvo(zrk_ctx *ctx, const zrk_entities *e, int cur, const
                        e->capacity, n, list_base, (int32_t *)mis->slot, (int32_t *)mis->target, (double *)mis->radius, mis->period,
                        mis->status, m, (double)time_ms / 1000.0, count_out);
     return check_launch(ctx, "k_launch_append");
+}
+
+namespace {
+inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+}
+
+ZRK_API int64_t zrk_ccp_scratch_bytes(int64_t D, int64_t T)
+{
+    if (D < 0 || T < 0) return ZRK_E_INVALID;
+    return align256(D * (int64_t)sizeof(CcpCand)) + align256(T) + align256(4 * T) + align256(D) + align256(D) + 256;
+}
+
+ZRK_API int zrk_ccp_link(zrk_ctx *ctx, const double *det_pos, const double *det_speed, int64_t D, const double *trk_ref,
+                         const double *trk_upd, int64_t T, double now_s, double slack_s, int32_t *match, void *scratch,
+                         void *stream)
+{
+    if (!ctx || D < 0 || T < 0 || (D > 0 && (!det_pos || !det_speed || !match || !scratch)) || (T > 0 && (!trk_ref || !trk_upd)))
+        return fail(ctx, ZRK_E_INVALID, "zrk_ccp_link: null argument");
+    if (D == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    char *p = (char *)scratch;
+    CcpCand *cand = (CcpCand *)p;            p += align256(D * (int64_t)sizeof(CcpCand));
+    uint8_t *taken = (uint8_t *)p;           p += align256(T);
+    int32_t *interest = (int32_t *)p;        p += align256(4 * T);
+    uint8_t *state = (uint8_t *)p;           p += align256(D);
+    uint8_t *only = (uint8_t *)p;            p += align256(D);
+    int32_t *counters = (int32_t *)p;
+    if (hipMemsetAsync(taken, 0, (size_t)align256(T), s) != hipSuccess || hipMemsetAsync(state, 0, (size_t)align256(D), s) != hipSuccess ||
+        hipMemsetAsync(interest, 0x7F, (size_t)align256(4 * T), s) != hipSuccess)
+        return fail(ctx, ZRK_E_HIP, "zrk_ccp_link: memset");
+    const int gd = nblocks(D, 256);
+    hipLaunchKernelGGL(k_ccp_candidates, dim3(gd), dim3(256), 0, s, det_pos, det_speed, D, trk_ref, trk_upd, T, now_s, slack_s,
+                       (const uint8_t *)nullptr, (const uint8_t *)nullptr, cand);
+    for (int round = 0; round < 1000000; ++round) {
+        if (hipMemsetAsync(counters, 0, 8, s) != hipSuccess || hipMemsetAsync(counters + 2, 0x7F, 4, s) != hipSuccess)
+            return fail(ctx, ZRK_E_HIP, "zrk_ccp_link: memset");
+        hipLaunchKernelGGL(k_ccp_round, dim3(gd), dim3(256), 0, s, 0, D, cand, taken, interest, match, state, counters);
+        hipLaunchKernelGGL(k_ccp_round, dim3(gd), dim3(256), 0, s, 1, D, cand, taken, interest, match, state, counters);
+        hipLaunchKernelGGL(k_ccp_reset_interest, dim3(gd), dim3(256), 0, s, D, cand, state, interest);
+        int32_t h[2] = {0, 0};
+        if (hipMemcpyAsync(h, counters, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+            return fail(ctx, ZRK_E_HIP, "zrk_ccp_link: reading the round's counters");
+        if (h[0] == 0 && h[1] == 0) break;
+        if (h[1] > 0) {
+            // every detection left has used up its kept candidates although more were in gate: scan again for those,
+            // without the tracks that are gone (state 2 -> `only`, back to unresolved)
+            if (hipMemcpyAsync(only, state, (size_t)D, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "zrk_ccp_link: copy");
+            hipLaunchKernelGGL(k_ccp_rescan_prepare, dim3(gd), dim3(256), 0, s, D, only, state);
+            hipLaunchKernelGGL(k_ccp_candidates, dim3(gd), dim3(256), 0, s, det_pos, det_speed, D, trk_ref, trk_upd, T, now_s, slack_s,
+                               (const uint8_t *)taken, (const uint8_t *)only, cand);
+        }
+    }
+    return check_launch(ctx, "zrk_ccp_link");
 }
 
 ZRK_API int zrk_selftest_math(zrk_ctx *ctx, int op, const double *a, const double *b, double *y, int64_t n, void *stream)

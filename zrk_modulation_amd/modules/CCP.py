@@ -1,6 +1,8 @@
 """Combat control point: track association and launch decisions (behavioural counterpart of
-reference modules/CCP.py:15-431; host-side scalar logic, outside the accelerated path -- SURVEY.md
-section 8f lists it as the next thing to move to the device).
+reference modules/CCP.py:15-431).  The bookkeeping and the messages are host-side scalar logic as in the reference;
+the part that is quadratic there -- `link_object` for every detection against every track (reference :171-219) -- runs
+on the device for all detections of a tick at once when the objects live in a device table
+(zrk_modulation_amd/association.py, zrk_ccp_link), with the result of the reference's sequential loop.
 
 What it consumes from the hot path every tick: AllObjectsMessage / FoundObjectsMessage per radar and
 the entity handles inside them (.id .pos .prev_pos .speed_mod .type).  Observable quirks of the
@@ -134,6 +136,43 @@ class CombatControlPoint(BaseModel):
                 best, verdict, match = dist, OLD_ROCKET, mid
         return verdict, match
 
+    def _link_all(self, objs):
+        """link_object for every detection of the tick, in order: [(verdict, matched id | None)].  On the device when the
+        detections are rows of a device table (one call: the pairwise distances and the order-dependent resolution,
+        zrk_ccp_link); otherwise -- plain host objects -- the reference's loop, one link_object at a time as the caller
+        applies the results."""
+        import os
+        store = getattr(objs[0], "_store", None) if objs else None
+        if store is None or os.environ.get("ZRK_CCP_HOST") or any(getattr(o, "_store", None) is None for o in objs):
+            return None
+        now_s = self._now_s()
+        t_keys, m_keys = list(self._target_dict), list(self._missile_dict)
+        refs, upds = [], []
+        for k in t_keys:
+            tr = self._target_dict[k]
+            ref = tr.target.prev_pos
+            if ref is None and tr.upd_time != now_s:
+                return None                       # the reference would fail on `None - pos` here: let the host loop do so
+            refs.append(ref if ref is not None else np.zeros(3)); upds.append(tr.upd_time)
+        for k in m_keys:
+            tr = self._missile_dict[k]
+            ref = tr.missile.prev_pos
+            refs.append(tr.missile.pos if ref is None else ref); upds.append(tr.upd_time)
+        from ..association import link_all
+        slack = POSSIBLE_TARGET_RADIUS * to_seconds(self._manager.time.get_dt())
+        match = link_all(store.ctx, store.device, np.asarray([o.pos for o in objs], np.float64).reshape(-1, 3),
+                         np.asarray([o.speed_mod for o in objs], np.float64),
+                         np.asarray(refs, np.float64).reshape(-1, 3), np.asarray(upds, np.float64), now_s, slack)
+        out = []
+        for m in match:
+            if m < 0:
+                out.append((NEW_TARGET, None))
+            elif m < len(t_keys):
+                out.append((OLD_TARGET, t_keys[m]))
+            else:
+                out.append((OLD_ROCKET, m_keys[m - len(t_keys)]))
+        return out
+
     # outbound ----------------------------------------------------------------------------------
     def send_update_msg_to_radar(self, target, missile_id, radar_id):
         self._manager.add_message(CPPUpdateTargetRadarMessage(
@@ -203,19 +242,25 @@ class CombatControlPoint(BaseModel):
                     to_draw.append([obj.id, kind, obj.pos])
                     seen_ids.append(obj.id)
 
-        processed = []
+        processed, seen, dets = [], set(), []
         for msg in mgr.give_messages_by_type(MessageType.FOUND_OBJECTS):
             radar_id = msg.sender_id
             for obj in msg.visible_objects:
-                if obj.id in processed:
+                if obj.id in seen:
                     continue
+                seen.add(obj.id)
                 processed.append(obj.id)
-                verdict, old_id = self.link_object(obj)
-                if verdict == NEW_TARGET:
-                    self.new_target(obj, radar_id)
-                elif verdict == OLD_TARGET:
-                    self.old_target(obj, old_id, radar_id)
-                elif verdict == OLD_ROCKET:
-                    self.old_rocket(obj, old_id)
+                dets.append((obj, radar_id))
+        # every verdict of the tick at once on the device; a verdict depends on earlier ones only through tracks they
+        # took (updated "now", hence skipped), which the device resolution reproduces
+        verdicts = self._link_all([o for o, _ in dets]) if dets else []
+        for k, (obj, radar_id) in enumerate(dets):
+            verdict, old_id = verdicts[k] if verdicts is not None else self.link_object(obj)
+            if verdict == NEW_TARGET:
+                self.new_target(obj, radar_id)
+            elif verdict == OLD_TARGET:
+                self.old_target(obj, old_id, radar_id)
+            elif verdict == OLD_ROCKET:
+                self.old_rocket(obj, old_id)
 
         self.send_objects_to_GUI(to_draw, processed)
