@@ -328,34 +328,55 @@ def main():
         eng, info = build_ensemble(args.workload, rank, world, device)
     else:
         eng, info = build_engine(args.workload, rank, world, device)
-    exchanging = world > 1 and not ensemble
-    c_side = exchanging and backend == "nccl"
+    # ZRK_BENCH_FORCE_EXCHANGE=1: the N > 1 control flow (C-side exchange, list sizing, overflow report) on ONE rank, for
+    # boxes with one GPU: RCCL runs with a one-rank communicator, nothing crosses a link
+    exchanging = (world > 1 or bool(os.environ.get("ZRK_BENCH_FORCE_EXCHANGE"))) and not ensemble
+    state = {"c_side": exchanging and backend == "nccl"}     # may fall back to the Python exchange at set-up
     xchg = {"x": None, "ex": [], "buf": [], "work": [None, None], "tick": 0, "entries": 0, "words": 0}
     ev_cap = max(64, info["m"]) if exchanging else 0
 
     def coll_device(t):
         return t.to(device) if backend == "nccl" else t.cpu()
 
+    def all_reduce(t, op):
+        if world > 1:
+            dist.all_reduce(t, op=op)
+
     def size_exchange(entries):
         """Lists for up to `entries` seen objects per rank, in the wire format of zrk_compact_bits (count, n, one
         bit per slot, 16-bit masks): a quarter of the bytes of (index, mask) pairs."""
         from zrk_modulation_amd.exchange import DetectionExchange, RcclExchange, union_bits_words
         n_slots = coll_device(torch.tensor([int(eng.store.cap)], dtype=torch.int64))
-        dist.all_reduce(n_slots, op=dist.ReduceOp.MAX)
+        all_reduce(n_slots, dist.ReduceOp.MAX)
         words = union_bits_words(int(n_slots.item()), info["R"], entries)
         offsets = [g * info["stride"] for g in range(world)]
-        if c_side:
-            if xchg["x"] is not None:
-                xchg["x"].close()
-            xchg["x"] = RcclExchange(words, device, info["R"], offsets=offsets, ev_capacity=ev_cap)
-        else:
+        made = False
+        if state["c_side"] and xchg["x"] is not None:
+            torch.cuda.synchronize(device)
+            xchg["x"].resize(words)                      # same communicator, new buffers
+            made = True
+        elif state["c_side"]:
+            try:
+                xchg["x"] = RcclExchange(words, device, info["R"], offsets=offsets, ev_capacity=ev_cap)
+                made = True
+            except Exception as exc:                     # the library's own communicator could not be set up here
+                print(f"[bench rank {rank}] C-side exchange unavailable ({exc}); falling back to torch.distributed", file=sys.stderr)
+        if state["c_side"]:
+            ok = coll_device(torch.tensor([1 if made else 0], dtype=torch.int64))
+            all_reduce(ok, dist.ReduceOp.MIN)               # every rank takes the same path
+            if int(ok.item()) == 0:
+                if xchg["x"] is not None:
+                    xchg["x"].close()
+                    xchg["x"] = None
+                state["c_side"] = False
+        if not state["c_side"]:
             xchg["ex"] = [DetectionExchange(words, device, fmt="bits", offsets=offsets, R=info["R"]) for _ in range(2)]
             xchg["buf"] = [torch.zeros(words, dtype=torch.int64, device=device) for _ in range(2)]
             xchg["work"] = [None, None]
         xchg["entries"], xchg["words"] = int(entries), int(words)
 
     def drain_exchange():
-        if c_side and xchg["x"] is not None:
+        if state["c_side"] and xchg["x"] is not None:
             xchg["x"].sync()
         for k, w in enumerate(xchg["work"]):
             if w is not None:
@@ -363,23 +384,26 @@ def main():
                 xchg["work"][k] = None
 
     def max_count():
-        if c_side:
+        if state["c_side"]:
             return max(max(xchg["x"].counts(0)), max(xchg["x"].counts(1)))
         return max(max(e.counts()) for e in xchg["ex"])
+
+    if exchanging:
+        size_exchange(eng.store.cap)     # (may settle for the Python exchange: decided before anything depends on it)
 
     # every other tick's sweep is timed when the run is short, every 8th otherwise; the events are only recorded
     # inside the timed region and read after it (one C call covers all ticks)
     stride = 2 if args.steps <= 64 else 8
-    if exchanging and not c_side:
+    if exchanging and not state["c_side"]:
         stride = 64                      # ticks driven one call at a time: reading the events drains the stream
-    deferred = not (exchanging and not c_side)
+    deferred = not (exchanging and not state["c_side"])
 
     def run_ticks(k, sweep_ms=None):
         ps = (-stride if deferred else stride) if sweep_ms is not None else 1
         if not exchanging:
             eng.run(k, sweep_ms=None if deferred else sweep_ms, prof_stride=ps)
             return
-        if c_side:
+        if state["c_side"]:
             eng.run(k, sweep_ms=None if deferred else sweep_ms, prof_stride=ps, exchange=xchg["x"])
             return
         for j in range(k):               # rehearsal path: the exchange goes through torch.distributed, tick by tick
@@ -401,8 +425,6 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    if exchanging:
-        size_exchange(eng.store.cap)
     def spin_up():
         """~100 ms of an unrelated kernel (the noise self-test) so that the clocks are up when the timed steps start, as
         they are inside any run longer than a few milliseconds (see the docstring)."""
@@ -421,7 +443,7 @@ def main():
         # sectors round their scan period, which a full warm-up covers; an overflow is reported)
         drain_exchange()
         seen = coll_device(torch.tensor([max_count()], dtype=torch.int64))
-        dist.all_reduce(seen, op=dist.ReduceOp.MAX)
+        all_reduce(seen, dist.ReduceOp.MAX)
         size_exchange(int(seen.item() * 1.25) + 1024)
     barrier()
     live0 = eng.alive_count()
@@ -439,13 +461,12 @@ def main():
     live1 = eng.alive_count()
     eng.store.compact_status()           # outside the timing: a compaction that did not run to completion raises here
     if exchanging:
-        overflow = xchg["x"].overflowed() if c_side else any(e.overflowed() for e in xchg["ex"])
+        overflow = xchg["x"].overflowed() if state["c_side"] else any(e.overflowed() for e in xchg["ex"])
 
     el = coll_device(torch.tensor([elapsed], dtype=torch.float64))
     units = coll_device(torch.tensor([float(min(live0, live1)) * args.steps], dtype=torch.float64))
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(units, op=dist.ReduceOp.SUM)
+    all_reduce(el, dist.ReduceOp.MAX)
+    all_reduce(units, dist.ReduceOp.SUM)
     elapsed = float(el.item()); total_units = float(units.item())
 
     if rank == 0:
@@ -466,7 +487,7 @@ def main():
         what += ", dt=10 ms, Philox measurement noise, "
         if exchanging:
             what += ("union compaction in the bitmap wire format + per-tick RCCL all-gather of the detection list and the "
-                     "detonation events, " + ("issued from the C side, overlapped with the next sweep" if c_side
+                     "detonation events, " + ("issued from the C side, overlapped with the next sweep" if state["c_side"]
                                               else "through torch.distributed (rehearsal backend)"))
         else:
             what += "per-radar compaction"
@@ -488,9 +509,9 @@ def main():
             "setup": {"clock_spinup_ms": SPINUP_MS},
         }
         if exchanging:
-            out["config"]["exchange"] = "rccl, C side" if c_side else f"torch.distributed {backend}"
+            out["config"]["exchange"] = "rccl, C side" if state["c_side"] else f"torch.distributed {backend}"
             out["config"]["exchange_entries_per_rank"] = xchg["entries"]
-            out["config"]["exchange_bytes_per_rank"] = 8 * (xchg["words"] + (1 + ev_cap if c_side else 0))
+            out["config"]["exchange_bytes_per_rank"] = 8 * (xchg["words"] + (1 + ev_cap if state["c_side"] else 0))
             out["config"]["exchange_overflow"] = bool(overflow)
         if world == 1 and not args.no_cpu_baseline and not ensemble:
             out["cpu_baseline"] = cpu_baseline(info, eng, args.cpu_budget)
@@ -499,10 +520,10 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    if xchg["x"] is not None:
+        xchg["x"].close()
     if world > 1:
         dist.barrier()
-        if xchg["x"] is not None:
-            xchg["x"].close()
         dist.destroy_process_group()
 
 

@@ -37,3 +37,13 @@ def test_two_ranks_started_by_the_gpus_flag(workload, scaling):
     assert rec["n_gpus"] == 2 and rec["scaling"] == scaling
     assert rec["config"]["exchange_overflow"] is False
     assert rec["value"] > 0
+
+
+def test_exchange_control_flow_on_one_rank_with_real_rccl():
+    """ZRK_BENCH_FORCE_EXCHANGE: everything bench.py does for N > 1 -- the library's own RCCL communicator, list sizing after
+    warm-up, the per-tick all-gather from the C side, the overflow report -- with a one-rank communicator."""
+    rec = _bench(["--workload", "tiny", "--steps", "16", "--warmup", "40", "--no-cpu-baseline"],
+                 env={"ZRK_BENCH_FORCE_EXCHANGE": "1"})
+    assert rec["n_gpus"] == 1 and rec["config"]["exchange"] == "rccl, C side"
+    assert rec["config"]["exchange_overflow"] is False and rec["config"]["exchange_entries_per_rank"] > 0
+    assert rec["value"] > 0

@@ -13,6 +13,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cfloat>
 #include <cmath>
 #include <cstddef>
@@ -117,7 +122,9 @@ struct SweepParams {
     uint64_t seed, tick;
     int64_t gid0;
     int32_t R, nb;              // nb: sweep workgroups, behind the mb leading workgroups that step the missiles
-    int32_t mb, _pad0;
+    int32_t mb;
+    uint32_t flag_value;        // written to *flag by the first workgroup as it starts (see zrk_exchange: hand-over by flag)
+    uint32_t *flag;
     WaveBox *boxes;             // per-block box records (NULL: none kept), see WaveBox
     // batched ensemble of independent scenarios (zrk_run_ticks_ensemble): scenario s owns rows_ps consecutive rows
     // (bps row blocks), its radar records are block s of rb_table, its noise key is seeds[s]; lists restart per scenario
@@ -705,6 +712,10 @@ __device__ __forceinline__ void sweep_rows(const SweepParams &P, const char *rbp
 template <bool PHILOX, bool ADVANCE, bool LIDX>
 __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, const MissileArgs M)
 {
+    // the previous tick's compaction is over and visible once this grid starts: tell the exchange stream, which waits
+    // for this word instead of an event (an event record costs the compute stream a barrier packet per tick)
+    if (P.flag && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(P.flag, P.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((int)blockIdx.x < P.mb) {              // leading workgroups: Missile.step for every in-flight row (a long
         // dependent chain -- dispatched first, it is over long before the sweep's last wave is)
         const int64_t row = (int64_t)blockIdx.x * ZRK_BLOCK + threadIdx.x;
@@ -2126,7 +2137,8 @@ struct EnsLaunch {
 int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_t time_ms, const zrk_radar *radars,
                  int R, uint32_t flags, uint64_t seed, uint64_t tick, int64_t gid0, void *workspace, void *stream,
                  const MissileArgs &M, uint32_t *vis = nullptr, int32_t *cost = nullptr, const int32_t *order = nullptr,
-                 WaveBox *boxes = nullptr, const EnsLaunch *ens = nullptr, const RadarBlock *rb_device = nullptr)
+                 WaveBox *boxes = nullptr, const EnsLaunch *ens = nullptr, const RadarBlock *rb_device = nullptr,
+                 uint32_t *flag = nullptr, uint32_t flag_value = 0)
 {
     if (!ctx || !e || !workspace || (R > 0 && !radars && !ens && !rb_device)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
     if (R < 0 || R > ZRK_MAX_RADARS)
@@ -2141,7 +2153,7 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
     P.t = (double)time_ms / 1000.0;                 // to_seconds, modules/AirObject.py:5-7
     P.seed = seed; P.tick = tick; P.gid0 = gid0;
     P.R = R; P.nb = nblocks(n, ZRK_BLOCK); P.flags = flags;
-    P.mb = nblocks(M.m, ZRK_BLOCK); P._pad0 = 0;
+    P.mb = nblocks(M.m, ZRK_BLOCK); P.flag = flag; P.flag_value = flag_value;
     P.boxes = boxes;
     P.rb_table = ens ? ens->rb_table : nullptr; P.seeds = ens ? ens->seeds : nullptr;
     P.rows_ps = ens ? ens->rows_ps : 0; P.bps = ens ? ens->bps : 0;
@@ -2519,8 +2531,78 @@ struct zrk_exchange {
     hipStream_t cstream = nullptr;
     hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
     bool posted[2] = {false, false};
+    // hand-over by flag (zrk_run_ticks_x): a word of signal memory that the NEXT tick's sweep raises to `seq` as it starts;
+    // the exchange stream waits for the value (hipStreamWaitValue32).  NULL: the device cannot, events are used
+    uint32_t *flag = nullptr;
+    uint32_t seq = 0;
+    // ... and those collectives are issued by a thread of the exchange's own: waiting for the value, the RCCL call and the
+    // event record take the calling thread longer than the two launches of a tick, and the device would wait for its host
+    struct PostItem { int slot; const int64_t *send; int64_t *recv; int64_t words; uint32_t value; };
+    static constexpr uint64_t kRing = 8;
+    PostItem ring[kRing];
+    std::atomic<uint64_t> head{0}, tail{0};             // items handed to the thread / items it has issued
+    uint64_t item_no[2] = {0, 0};                       // per slot: `head` after its last item went in
+    std::thread poster;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<bool> asleep{false}, stop{false};
+    std::atomic<int> post_rc{0};
+    std::string post_err;                               // written by the thread before post_rc, read after
     std::string err;
 };
+
+namespace {
+
+int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, int64_t *recv, int64_t words, uint32_t value);
+
+void exchange_poster_main(zrk_exchange *x)
+{
+    if (hipSetDevice(x->device) != hipSuccess) { x->post_err = "hipSetDevice failed in the exchange thread"; x->post_rc.store(ZRK_E_HIP); }
+    auto idle_since = std::chrono::steady_clock::now();
+    for (;;) {
+        const uint64_t t = x->tail.load(std::memory_order_relaxed);
+        if (x->head.load(std::memory_order_acquire) != t) {
+            const zrk_exchange::PostItem it = x->ring[t % zrk_exchange::kRing];
+            if (x->post_rc.load() == 0 && exchange_post_behind_flag(x, it.slot, it.send, it.recv, it.words, it.value) != 0) {
+                x->post_err = x->err;
+                x->post_rc.store(ZRK_E_HIP);
+            }
+            x->tail.store(t + 1, std::memory_order_release);
+            idle_since = std::chrono::steady_clock::now();
+            continue;
+        }
+        if (x->stop.load()) return;
+        if (std::chrono::steady_clock::now() - idle_since < std::chrono::microseconds(300)) {
+            __builtin_ia32_pause();
+            continue;
+        }
+        std::unique_lock<std::mutex> lk(x->mu);         // nothing for a while: sleep (the bounded wait covers a lost wake-up)
+        x->asleep.store(true);
+        if (x->head.load(std::memory_order_acquire) == x->tail.load() && !x->stop.load())
+            x->cv.wait_for(lk, std::chrono::milliseconds(1));
+        x->asleep.store(false);
+    }
+}
+
+void exchange_enqueue(zrk_exchange *x, const zrk_exchange::PostItem &it)
+{
+    const uint64_t h = x->head.load(std::memory_order_relaxed);
+    while (h - x->tail.load(std::memory_order_acquire) >= zrk_exchange::kRing) __builtin_ia32_pause();
+    x->ring[h % zrk_exchange::kRing] = it;
+    x->head.store(h + 1, std::memory_order_release);
+    x->item_no[it.slot] = h + 1;
+    if (x->asleep.load()) { std::lock_guard<std::mutex> lk(x->mu); x->cv.notify_one(); }
+}
+
+// everything handed to the thread has been issued on the exchange stream (0), or the thread's failure
+int exchange_drain(zrk_exchange *x, uint64_t upto)
+{
+    while (x->tail.load(std::memory_order_acquire) < upto) __builtin_ia32_pause();
+    if (x->post_rc.load() != 0) { x->err = x->post_err; return ZRK_E_HIP; }
+    return 0;
+}
+
+}  // namespace
 
 ZRK_API int zrk_exchange_unique_id(const char *rccl_path, zrk_rccl_id *id)
 {
@@ -2553,12 +2635,32 @@ ZRK_API int zrk_exchange_create(const char *rccl_path, const zrk_rccl_id *id, in
         ok = hipEventCreateWithFlags(&x->ready[k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&x->done[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) { x->err = "stream / event creation failed"; return ZRK_E_HIP; }
+    int can_wait_value = 0;
+    const char *force_events = std::getenv("ZRK_EXCHANGE_EVENTS");
+    if (!(force_events && force_events[0] == '1') &&
+        hipDeviceGetAttribute(&can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can_wait_value) {
+        const char *dg = std::getenv("ZRK_EXCHANGE_DIAG");
+        const bool device_word = dg && (std::atoi(dg) & 8);
+        if ((device_word ? hipMalloc((void **)&x->flag, 8) : hipExtMallocWithFlags((void **)&x->flag, 8, hipMallocSignalMemory)) != hipSuccess ||
+            hipMemset(x->flag, 0, 8) != hipSuccess) {
+            (void)hipGetLastError();
+            if (x->flag) (void)hipFree(x->flag);
+            x->flag = nullptr;                         // events then
+        }
+    }
+    const char *no_thread = std::getenv("ZRK_EXCHANGE_THREAD");
+    if (x->flag && !(no_thread && no_thread[0] == '0')) x->poster = std::thread(exchange_poster_main, x);
     return 0;
 }
 
 ZRK_API void zrk_exchange_destroy(zrk_exchange *x)
 {
     if (!x) return;
+    if (x->poster.joinable()) {
+        x->stop.store(true);
+        { std::lock_guard<std::mutex> lk(x->mu); x->cv.notify_one(); }
+        x->poster.join();
+    }
     if (x->cstream) (void)hipStreamSynchronize(x->cstream);
     if (x->comm) (void)x->api.CommDestroy(x->comm);
     for (int k = 0; k < 2; ++k) {
@@ -2566,6 +2668,7 @@ ZRK_API void zrk_exchange_destroy(zrk_exchange *x)
         if (x->done[k]) (void)hipEventDestroy(x->done[k]);
     }
     if (x->cstream) (void)hipStreamDestroy(x->cstream);
+    if (x->flag) (void)hipFree(x->flag);
     delete x;
 }
 
@@ -2574,6 +2677,7 @@ ZRK_API const char *zrk_exchange_last_error(zrk_exchange *x) { return x ? x->err
 ZRK_API int zrk_exchange_all_gather(zrk_exchange *x, int slot, const int64_t *send, int64_t *recv, int64_t words, void *stream)
 {
     if (!x || !x->comm || !send || !recv || words <= 0 || (slot != 0 && slot != 1)) return ZRK_E_INVALID;
+    if (exchange_drain(x, x->head.load()) != 0) return ZRK_E_HIP;      // behind whatever the exchange's thread still had to issue
     if (hipEventRecord(x->ready[slot], (hipStream_t)stream) != hipSuccess ||
         hipStreamWaitEvent(x->cstream, x->ready[slot], 0) != hipSuccess) { x->err = "event hand-over to the exchange stream failed"; return ZRK_E_HIP; }
     const int rc = x->api.AllGather(send, recv, (size_t)words, kNcclInt64, x->comm, x->cstream);
@@ -2583,17 +2687,74 @@ ZRK_API int zrk_exchange_all_gather(zrk_exchange *x, int slot, const int64_t *se
     return 0;
 }
 
+namespace {
+
+__global__ void k_raise_flag(uint32_t *flag, uint32_t value)
+{
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// One lane waits for the word to reach `value` (sleeping between looks); gives up after about a second and says so.
+__global__ void k_wait_flag(const uint32_t *flag, uint32_t value, uint32_t *gave_up)
+{
+    for (int spins = 0; spins < (1 << 20); ++spins) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= value) return;
+        __builtin_amdgcn_s_sleep(32);
+    }
+    __hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The collective of a list whose producer has no event behind it: the exchange stream waits until the flag word
+// reaches `value`, which a kernel launched BEHIND the producer on the compute stream writes as it starts.
+int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, int64_t *recv, int64_t words, uint32_t value)
+{
+    static const int diag = [] { const char *v = std::getenv("ZRK_EXCHANGE_DIAG"); return v ? std::atoi(v) : 0; }();
+    if (diag & 8) {
+        hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, x->cstream, x->flag, value, x->flag + 1);
+        if (hipGetLastError() != hipSuccess) { x->err = "k_wait_flag launch failed"; return ZRK_E_HIP; }
+    } else
+    if (!(diag & 1) && hipStreamWaitValue32(x->cstream, x->flag, value, hipStreamWaitValueGte, 0xFFFFFFFFu) != hipSuccess) {
+        x->err = "hipStreamWaitValue32 failed"; return ZRK_E_HIP;
+    }
+    const int rc = (diag & 2) ? 0 : x->api.AllGather(send, recv, (size_t)words, kNcclInt64, x->comm, x->cstream);
+    if (rc != 0) { x->err = std::string("ncclAllGather: ") + (x->api.GetErrorString ? x->api.GetErrorString(rc) : "error"); return ZRK_E_HIP; }
+    if (!(diag & 4)) {
+        if (hipEventRecord(x->done[slot], x->cstream) != hipSuccess) { x->err = "hipEventRecord failed"; return ZRK_E_HIP; }
+        x->posted[slot] = true;
+    }
+    return 0;
+}
+
+}  // namespace
+
 ZRK_API int zrk_exchange_wait(zrk_exchange *x, int slot, void *stream)
 {
     if (!x || (slot != 0 && slot != 1)) return ZRK_E_INVALID;
+    if (exchange_drain(x, x->item_no[slot]) != 0) return ZRK_E_HIP;    // its collective has been issued (by the exchange's thread)
     if (!x->posted[slot]) return 0;
-    if (hipStreamWaitEvent((hipStream_t)stream, x->done[slot], 0) != hipSuccess) { x->err = "hipStreamWaitEvent failed"; return ZRK_E_HIP; }
-    return 0;
+    // usually that collective is long over (it was posted two ticks ago): then the host knows, and the stream is spared a
+    // barrier packet, which costs it more than the wait it would do
+    if (hipEventQuery(x->done[slot]) == hipSuccess) return 0;
+    // not yet -- mostly because the host runs ticks ahead of the device.  Waiting HERE (the host is then at most two ticks
+    // ahead, which still keeps a launch queued behind the running one) is cheaper than a wait in the stream: that is a
+    // barrier packet in front of every compaction, ~5 us of idle device each
+    static const bool in_stream = [] { const char *v = std::getenv("ZRK_EXCHANGE_WAIT_IN_STREAM"); return v && v[0] == '1'; }();
+    if (in_stream) {
+        if (hipStreamWaitEvent((hipStream_t)stream, x->done[slot], 0) != hipSuccess) { x->err = "hipStreamWaitEvent failed"; return ZRK_E_HIP; }
+        return 0;
+    }
+    while (true) {
+        const hipError_t q = hipEventQuery(x->done[slot]);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) { x->err = "hipEventQuery failed"; return ZRK_E_HIP; }
+        __builtin_ia32_pause();
+    }
 }
 
 ZRK_API int zrk_exchange_sync(zrk_exchange *x)
 {
     if (!x) return ZRK_E_INVALID;
+    if (exchange_drain(x, x->head.load()) != 0) return ZRK_E_HIP;
     if (hipStreamSynchronize(x->cstream) != hipSuccess) { x->err = "hipStreamSynchronize failed"; return ZRK_E_HIP; }
     return 0;
 }
@@ -2693,6 +2854,16 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     hipEvent_t *ev = n_prof ? ctx->tev.data() : nullptr;
     // the tail of an exchanged list carries this tick's detonations: [count, rows ...]
     const int64_t ev_words = (xio && xio->ev_capacity > 0) ? 1 + (int64_t)xio->ev_capacity : 0;
+    // hand-over of a tick's list to the exchange stream: by the flag the next tick's sweep raises (no packet of its own on
+    // the compute stream), the last tick of the call -- which has no next sweep -- by an event
+    zrk_exchange *fx = (xio && xio->x->flag) ? xio->x : nullptr;
+    if (fx && fx->seq > 0x7FFF0000u) {                   // far from wrapping: the comparison is on 32 bits
+        if (hipStreamSynchronize(fx->cstream) != hipSuccess) return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
+        hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, s, fx->flag, 0u);
+        if (hipStreamSynchronize(s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
+        fx->seq = 0;
+    }
+    struct { bool on; int slot; int64_t *list; uint32_t value; } pend = {false, 0, nullptr, 0u};
     int rc = 0;
     for (int k = 0; k < K && rc == 0; ++k) {
         st->cur ^= 1;
@@ -2746,7 +2917,18 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         rc = launch_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse, st->seed,
                           st->tick, st->gid0, workspace, stream, M, vis_now, ordering ? w.cost : nullptr,
                           (ordering && ctx->order_ready) ? w.order : nullptr, w.boxes, ens ? &EL : nullptr,
-                          rb_through_memory ? rb_dev[st->tick & 1u] : nullptr);
+                          rb_through_memory ? rb_dev[st->tick & 1u] : nullptr, pend.on ? fx->flag : nullptr, pend.value);
+        if (pend.on) {                                                       // the previous tick's collective, behind this sweep's start
+            if (rc == 0 && !(st->n > 0 || M.m > 0)) {                        // (no sweep was launched: raise the flag by itself)
+                hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, s, fx->flag, pend.value);
+                rc = check_launch(ctx, "k_raise_flag");
+            }
+            if (rc == 0 && fx->poster.joinable())
+                exchange_enqueue(fx, zrk_exchange::PostItem{pend.slot, pend.list, xio->recv[pend.slot], xio->words, pend.value});
+            else if (rc == 0 && exchange_post_behind_flag(fx, pend.slot, pend.list, xio->recv[pend.slot], xio->words, pend.value) != 0)
+                rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(fx));
+            pend.on = false;
+        }
         if (!ens) zrk_scan_advance(radars, scan, R);                          // Radar.py:205 (an ensemble's: on the device)
         if (rb_through_memory) {                                             // the next tick's records ride with this compaction
             fill_radar_block(ctx, radars, R, st->flags, put.rb);
@@ -2770,8 +2952,11 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             } else if (hipMemsetAsync(list + list_words, 0, sizeof(int64_t), s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "memset events");
         }
         // the collective of this tick, behind the compaction on RCCL's own stream: it overlaps the next tick's sweep
-        if (rc == 0 && xio && zrk_exchange_all_gather(xio->x, slot, list, xio->recv[slot], xio->words, stream) != 0)
-            rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
+        if (rc == 0 && xio) {
+            if (fx && k + 1 < K) { pend.on = true; pend.slot = slot; pend.list = list; pend.value = ++fx->seq; }
+            else if (zrk_exchange_all_gather(xio->x, slot, list, xio->recv[slot], xio->words, stream) != 0)
+                rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
+        }
         st->time_ms += st->dt_ms;                                            // Manager.py:140
         st->tick += 1;
     }

@@ -102,30 +102,45 @@ class RcclExchange:
         path = rccl_library_path()
         cpath = path.encode() if path else None
         uid = _lib.ZrkRcclId()
+        made = 1
         if self.rank == 0:
-            rc = self.lib.zrk_exchange_unique_id(cpath, C.byref(uid))
-            if rc != 0:
-                raise _lib.ZrkError(f"zrk_exchange_unique_id failed ({rc}): RCCL could not be loaded from {path}")
+            made = 1 if self.lib.zrk_exchange_unique_id(cpath, C.byref(uid)) == 0 else 0
         if self.world > 1:
+            # rank 0's id and whether it got one travel together, so that every rank goes on or gives up alike (a rank
+            # that raised alone would leave the others waiting in the communicator's rendezvous)
             backend = dist.get_backend(group)
-            t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone()
+            t = torch.frombuffer(bytearray(bytes(uid) + bytes([made])), dtype=torch.uint8).clone()
             t = t.to(self.device) if backend == "nccl" else t
             dist.broadcast(t, src=0, group=group)
-            C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+            raw = t.cpu().numpy().tobytes()
+            C.memmove(C.byref(uid), raw[:128], 128)
+            made = raw[128]
+        if not made:
+            raise _lib.ZrkError(f"zrk_exchange_unique_id failed on rank 0: RCCL could not be loaded from {path}")
         h = C.c_void_p()
         rc = self.lib.zrk_exchange_create(cpath, C.byref(uid), self.world, self.rank, self.device.index or 0, C.byref(h))
         self.handle = h
         if rc != 0:
             msg = self.lib.zrk_exchange_last_error(h) if h.value else b""
             raise _lib.ZrkError(f"zrk_exchange_create failed ({rc}): {msg.decode() if msg else ''}")
+        self._lib_mod = _lib
+        self._allocate()
+
+    def _allocate(self):
         self.send = [torch.zeros(self.words, dtype=torch.int64, device=self.device) for _ in range(2)]
         self.recv = [torch.zeros(self.world, self.words, dtype=torch.int64, device=self.device) for _ in range(2)]
-        io = _lib.ZrkExchangeIo()
-        io.x = h
+        io = self._lib_mod.ZrkExchangeIo()
+        io.x = self.handle
         io.send[0], io.send[1] = self.send[0].data_ptr(), self.send[1].data_ptr()
         io.recv[0], io.recv[1] = self.recv[0].data_ptr(), self.recv[1].data_ptr()
         io.words, io.ev_capacity = self.words, self.ev_capacity
         self.io = io
+
+    def resize(self, words):
+        """New list size (same on every rank), same communicator: waits for what is in flight, then new buffers."""
+        self.sync()
+        self.words = int(words) + (1 + self.ev_capacity if self.ev_capacity else 0)
+        self._allocate()
 
     def sync(self):
         rc = self.lib.zrk_exchange_sync(self.handle)
