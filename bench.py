@@ -391,9 +391,9 @@ def main():
     if exchanging:
         size_exchange(eng.store.cap)     # (may settle for the Python exchange: decided before anything depends on it)
 
-    # every other tick's sweep is timed when the run is short, every 8th otherwise; the events are only recorded
-    # inside the timed region and read after it (one C call covers all ticks)
-    stride = 2 if args.steps <= 64 else 8
+    # every 4th tick's sweep is timed when the run is short, every 8th otherwise (a timed launch costs the stream ~4 us,
+    # whether the events ride on the dispatch or are recorded around it); the events are read after the timed region
+    stride = int(os.environ.get("ZRK_BENCH_STRIDE", 0)) or (4 if args.steps <= 64 else 8)
     if exchanging and not state["c_side"]:
         stride = 64                      # ticks driven one call at a time: reading the events drains the stream
     deferred = not (exchanging and not state["c_side"])

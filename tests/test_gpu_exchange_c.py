@@ -47,16 +47,30 @@ def test_c_side_exchange_carries_the_same_list_and_events_as_the_plain_loop():
     x.close()
 
 
-def test_k_ticks_per_call_with_the_exchange():
+@pytest.mark.parametrize("env", [{}, {"ZRK_EXCHANGE_THREAD": "0"}, {"ZRK_EXCHANGE_EVENTS": "1"}, {"ZRK_EXCHANGE_WAIT_IN_STREAM": "1"}],
+                         ids=["flag+thread", "flag", "events", "wait-in-stream"])
+def test_k_ticks_per_call_with_the_exchange(env, monkeypatch):
+    """Inside one call the lists of all ticks but the last are handed over by the flag the next sweep raises (and
+    issued by the exchange's own thread), the last one by an event: both slots must hold what the plain loop found."""
     from zrk_modulation_amd.exchange import RcclExchange, union_bits_words
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     n, R, m = 20_000, 4, 100
     eng_a, _, _ = _engines(n, R, m, 5)
     eng_b, _, _ = _engines(n, R, m, 5)
     x = RcclExchange(union_bits_words(eng_b.store.cap, R, eng_b.store.cap), eng_b.store.device, R, offsets=[0], ev_capacity=128)
-    eng_a.run(9)
-    eng_b.run(9, exchange=x)           # tick 8 went through slot 0
-    idx, msk = x.merged(0)
     st = eng_a.store
-    vis = st.vis()[:st.n_uploaded].cpu().numpy().view(np.uint32)
-    assert np.array_equal(idx.cpu().numpy(), np.nonzero(vis)[0])
+    for calls in range(3):
+        eng_b.run(9, exchange=x)       # an odd count: the last tick of the call alternates between the slots
+        x.sync()
+        last = (9 * (calls + 1) - 1) & 1
+        eng_a.run(8)
+        vis = st.vis()[:st.n_uploaded].cpu().numpy().view(np.uint32)
+        idx, msk = x.merged(last ^ 1)  # the second last tick: handed over by the flag
+        assert np.array_equal(idx.cpu().numpy(), np.nonzero(vis)[0]), f"call {calls}: list of the second last tick differs"
+        assert np.array_equal(msk.cpu().numpy().astype(np.uint32), vis[np.nonzero(vis)[0]])
+        eng_a.run(1)
+        vis = st.vis()[:st.n_uploaded].cpu().numpy().view(np.uint32)
+        idx, msk = x.merged(last)      # the last tick: by the event
+        assert np.array_equal(idx.cpu().numpy(), np.nonzero(vis)[0]), f"call {calls}: list of the last tick differs"
     x.close()

@@ -11,6 +11,7 @@
 // passed by value in the kernel-argument segment, so every wave reads it through the scalar
 // cache into SGPRs; an LDS tile of radars would only add a copy.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     // the previous tick's compaction is over and visible once this grid starts: tell the exchange stream, which waits
     // for this word instead of an event (an event record costs the compute stream a barrier packet per tick)
     if (P.flag && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(P.flag, P.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(P.flag, P.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((int)blockIdx.x < P.mb) {              // leading workgroups: Missile.step for every in-flight row (a long
         // dependent chain -- dispatched first, it is over long before the sweep's last wave is)
         const int64_t row = (int64_t)blockIdx.x * ZRK_BLOCK + threadIdx.x;
@@ -1947,6 +1948,7 @@ struct zrk_ctx {
     int env_items = 0;                 // ZRK_COMPACT_ITEMS (0: automatic), read once: getenv per launch costs microseconds
     int env_order = -1;                // ZRK_COMPACT_ORDER: 0 "block", 1 anything else, -1 automatic
     uint32_t diag = 0;                 // ZRK_DIAG: bit 0 no "certainly visible" shortcut, bit 1 no box records
+    bool time_on_dispatch = true;      // ZRK_TIME_BY_RECORDS=1: time sweeps between two recorded events instead
     const void *box_ws = nullptr;      // workspace whose box records belong to ...
     const void *box_key = nullptr;     // ... this table (its start_pos column) ...
     int64_t box_n = 0;                 // ... up to this many rows
@@ -2041,6 +2043,7 @@ ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
     c->order_enabled = true; c->diag = 0; c->env_items = 0; c->env_order = -1;
     if (const char *v = std::getenv("ZRK_SWEEP_ORDER")) c->order_enabled = std::atoi(v) != 0;
     if (const char *v = std::getenv("ZRK_DIAG")) c->diag = (uint32_t)std::strtoul(v, nullptr, 0);
+    { const char *v = std::getenv("ZRK_TIME_BY_RECORDS"); c->time_on_dispatch = !(v && v[0] == '1'); }
     if (const char *v = std::getenv("ZRK_COMPACT_ITEMS")) c->env_items = std::max(1, std::atoi(v));
     if (const char *v = std::getenv("ZRK_COMPACT_ORDER")) c->env_order = std::strcmp(v, "block") != 0;
     c->fused_max_blocks = kFusedMaxBlocks;
@@ -2138,7 +2141,7 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
                  int R, uint32_t flags, uint64_t seed, uint64_t tick, int64_t gid0, void *workspace, void *stream,
                  const MissileArgs &M, uint32_t *vis = nullptr, int32_t *cost = nullptr, const int32_t *order = nullptr,
                  WaveBox *boxes = nullptr, const EnsLaunch *ens = nullptr, const RadarBlock *rb_device = nullptr,
-                 uint32_t *flag = nullptr, uint32_t flag_value = 0)
+                 uint32_t *flag = nullptr, uint32_t flag_value = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
 {
     if (!ctx || !e || !workspace || (R > 0 && !radars && !ens && !rb_device)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
     if (R < 0 || R > ZRK_MAX_RADARS)
@@ -2173,7 +2176,10 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
         k_tick_sweep<true, true, false>,   k_tick_sweep<false, false, true>, k_tick_sweep<true, false, true>,
         k_tick_sweep<false, true, true>,   k_tick_sweep<true, true, true>};
     const int which = ((flags & ZRK_F_PHILOX) ? 1 : 0) | ((flags & ZRK_F_ADVANCE) ? 2 : 0) | (P.lidx ? 4 : 0);
-    hipLaunchKernelGGL(variants[which], grid, dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
+    // timed: the events ride on the dispatch itself (they read the kernel's own begin and end stamps, and cost the stream
+    // no packet of their own -- a pair of hipEventRecord calls around the launch costs ~3 us of idle device each)
+    if (ev_start && ev_stop) hipExtLaunchKernelGGL(variants[which], grid, dim3(ZRK_BLOCK), 0, (hipStream_t)stream, ev_start, ev_stop, 0, P, M);
+    else hipLaunchKernelGGL(variants[which], grid, dim3(ZRK_BLOCK), 0, (hipStream_t)stream, P, M);
     return check_launch(ctx, "k_tick_sweep");
 }
 
@@ -2531,10 +2537,12 @@ struct zrk_exchange {
     hipStream_t cstream = nullptr;
     hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
     bool posted[2] = {false, false};
-    // hand-over by flag (zrk_run_ticks_x): a word of signal memory that the NEXT tick's sweep raises to `seq` as it starts;
-    // the exchange stream waits for the value (hipStreamWaitValue32).  NULL: the device cannot, events are used
+    // hand-over by flag (zrk_run_ticks_x): a word of device memory that the NEXT tick's sweep raises to `seq` as it starts;
+    // a one-lane kernel on the exchange stream waits for the value (flag[1]: it gave up).  NULL (ZRK_EXCHANGE_EVENTS=1):
+    // an event per tick on the compute stream instead
     uint32_t *flag = nullptr;
     uint32_t seq = 0;
+    bool wait_in_stream = false;                        // ZRK_EXCHANGE_WAIT_IN_STREAM=1, see zrk_exchange_wait
     // ... and those collectives are issued by a thread of the exchange's own: waiting for the value, the RCCL call and the
     // event record take the calling thread longer than the two launches of a tick, and the device would wait for its host
     struct PostItem { int slot; const int64_t *send; int64_t *recv; int64_t words; uint32_t value; };
@@ -2572,7 +2580,7 @@ void exchange_poster_main(zrk_exchange *x)
             continue;
         }
         if (x->stop.load()) return;
-        if (std::chrono::steady_clock::now() - idle_since < std::chrono::microseconds(300)) {
+        if (std::chrono::steady_clock::now() - idle_since < std::chrono::milliseconds(50)) {
             __builtin_ia32_pause();
             continue;
         }
@@ -2635,17 +2643,12 @@ ZRK_API int zrk_exchange_create(const char *rccl_path, const zrk_rccl_id *id, in
         ok = hipEventCreateWithFlags(&x->ready[k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&x->done[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) { x->err = "stream / event creation failed"; return ZRK_E_HIP; }
-    int can_wait_value = 0;
+    const char *in_stream = std::getenv("ZRK_EXCHANGE_WAIT_IN_STREAM");
+    x->wait_in_stream = in_stream && in_stream[0] == '1';
     const char *force_events = std::getenv("ZRK_EXCHANGE_EVENTS");
-    if (!(force_events && force_events[0] == '1') &&
-        hipDeviceGetAttribute(&can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can_wait_value) {
-        const char *dg = std::getenv("ZRK_EXCHANGE_DIAG");
-        const bool device_word = dg && (std::atoi(dg) & 8);
-        if ((device_word ? hipMalloc((void **)&x->flag, 8) : hipExtMallocWithFlags((void **)&x->flag, 8, hipMallocSignalMemory)) != hipSuccess ||
-            hipMemset(x->flag, 0, 8) != hipSuccess) {
-            (void)hipGetLastError();
-            if (x->flag) (void)hipFree(x->flag);
-            x->flag = nullptr;                         // events then
+    if (!(force_events && force_events[0] == '1')) {
+        if (hipMalloc((void **)&x->flag, 8) != hipSuccess || hipMemset(x->flag, 0, 8) != hipSuccess) {
+            x->err = "the exchange's flag words could not be allocated"; return ZRK_E_HIP;
         }
     }
     const char *no_thread = std::getenv("ZRK_EXCHANGE_THREAD");
@@ -2691,10 +2694,11 @@ namespace {
 
 __global__ void k_raise_flag(uint32_t *flag, uint32_t value)
 {
-    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One lane waits for the word to reach `value` (sleeping between looks); gives up after about a second and says so.
+// One lane waits for the word to reach `value` (sleeping between looks); gives up after a few seconds and says so
+// (zrk_exchange_sync reports it) rather than hold the device for ever.
 __global__ void k_wait_flag(const uint32_t *flag, uint32_t value, uint32_t *gave_up)
 {
     for (int spins = 0; spins < (1 << 20); ++spins) {
@@ -2708,20 +2712,14 @@ __global__ void k_wait_flag(const uint32_t *flag, uint32_t value, uint32_t *gave
 // reaches `value`, which a kernel launched BEHIND the producer on the compute stream writes as it starts.
 int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, int64_t *recv, int64_t words, uint32_t value)
 {
-    static const int diag = [] { const char *v = std::getenv("ZRK_EXCHANGE_DIAG"); return v ? std::atoi(v) : 0; }();
-    if (diag & 8) {
-        hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, x->cstream, x->flag, value, x->flag + 1);
-        if (hipGetLastError() != hipSuccess) { x->err = "k_wait_flag launch failed"; return ZRK_E_HIP; }
-    } else
-    if (!(diag & 1) && hipStreamWaitValue32(x->cstream, x->flag, value, hipStreamWaitValueGte, 0xFFFFFFFFu) != hipSuccess) {
-        x->err = "hipStreamWaitValue32 failed"; return ZRK_E_HIP;
-    }
-    const int rc = (diag & 2) ? 0 : x->api.AllGather(send, recv, (size_t)words, kNcclInt64, x->comm, x->cstream);
+    // (a wait kernel of our own on a word of device memory: hipStreamWaitValue32 on signal memory does the same
+    // job but cost the compute stream 3.5 us a tick in the measurement, this costs it nothing measurable)
+    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, x->cstream, x->flag, value, x->flag + 1);
+    if (hipGetLastError() != hipSuccess) { x->err = "k_wait_flag launch failed"; return ZRK_E_HIP; }
+    const int rc = x->api.AllGather(send, recv, (size_t)words, kNcclInt64, x->comm, x->cstream);
     if (rc != 0) { x->err = std::string("ncclAllGather: ") + (x->api.GetErrorString ? x->api.GetErrorString(rc) : "error"); return ZRK_E_HIP; }
-    if (!(diag & 4)) {
-        if (hipEventRecord(x->done[slot], x->cstream) != hipSuccess) { x->err = "hipEventRecord failed"; return ZRK_E_HIP; }
-        x->posted[slot] = true;
-    }
+    if (hipEventRecord(x->done[slot], x->cstream) != hipSuccess) { x->err = "hipEventRecord failed"; return ZRK_E_HIP; }
+    x->posted[slot] = true;
     return 0;
 }
 
@@ -2738,8 +2736,7 @@ ZRK_API int zrk_exchange_wait(zrk_exchange *x, int slot, void *stream)
     // not yet -- mostly because the host runs ticks ahead of the device.  Waiting HERE (the host is then at most two ticks
     // ahead, which still keeps a launch queued behind the running one) is cheaper than a wait in the stream: that is a
     // barrier packet in front of every compaction, ~5 us of idle device each
-    static const bool in_stream = [] { const char *v = std::getenv("ZRK_EXCHANGE_WAIT_IN_STREAM"); return v && v[0] == '1'; }();
-    if (in_stream) {
+    if (x->wait_in_stream) {
         if (hipStreamWaitEvent((hipStream_t)stream, x->done[slot], 0) != hipSuccess) { x->err = "hipStreamWaitEvent failed"; return ZRK_E_HIP; }
         return 0;
     }
@@ -2756,6 +2753,11 @@ ZRK_API int zrk_exchange_sync(zrk_exchange *x)
     if (!x) return ZRK_E_INVALID;
     if (exchange_drain(x, x->head.load()) != 0) return ZRK_E_HIP;
     if (hipStreamSynchronize(x->cstream) != hipSuccess) { x->err = "hipStreamSynchronize failed"; return ZRK_E_HIP; }
+    if (x->flag) {
+        uint32_t gave_up = 0;
+        if (hipMemcpy(&gave_up, x->flag + 1, sizeof(gave_up), hipMemcpyDeviceToHost) != hipSuccess) { x->err = "hipMemcpy failed"; return ZRK_E_HIP; }
+        if (gave_up) { x->err = "the exchange stream gave up waiting for a sweep to raise its flag: that collective sent an unfinished list"; return ZRK_E_HIP; }
+    }
     return 0;
 }
 
@@ -2868,7 +2870,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     for (int k = 0; k < K && rc == 0; ++k) {
         st->cur ^= 1;
         const bool prof = n_prof && (k % stride == 0);
-        if (prof && hipEventRecord(ev[2 * (k / stride)], s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "hipEventRecord"); break; }
+        const bool on_dispatch = prof && ctx->time_on_dispatch && (st->n > 0 || (m > 0 && m <= 1024 * (int64_t)kMissileItems));
+        if (prof && !on_dispatch && hipEventRecord(ev[2 * (k / stride)], s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "hipEventRecord"); break; }
         const int slot = (int)(st->tick & 1u);
         int64_t *list = xio ? xio->send[slot] : packed;
         const int64_t list_words = xio ? xio->words - ev_words : packed_capacity;
@@ -2917,7 +2920,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         rc = launch_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse, st->seed,
                           st->tick, st->gid0, workspace, stream, M, vis_now, ordering ? w.cost : nullptr,
                           (ordering && ctx->order_ready) ? w.order : nullptr, w.boxes, ens ? &EL : nullptr,
-                          rb_through_memory ? rb_dev[st->tick & 1u] : nullptr, pend.on ? fx->flag : nullptr, pend.value);
+                          rb_through_memory ? rb_dev[st->tick & 1u] : nullptr, pend.on ? fx->flag : nullptr, pend.value,
+                          on_dispatch ? ev[2 * (k / stride)] : nullptr, on_dispatch ? ev[2 * (k / stride) + 1] : nullptr);
         if (pend.on) {                                                       // the previous tick's collective, behind this sweep's start
             if (rc == 0 && !(st->n > 0 || M.m > 0)) {                        // (no sweep was launched: raise the flag by itself)
                 hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, s, fx->flag, pend.value);
@@ -2934,7 +2938,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             fill_radar_block(ctx, radars, R, st->flags, put.rb);
             put.dst = (uint32_t *)rb_dev[(st->tick + 1) & 1u];
         }
-        if (prof && rc == 0 && hipEventRecord(ev[2 * (k / stride) + 1], s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipEventRecord");
+        if (prof && !on_dispatch && rc == 0 && hipEventRecord(ev[2 * (k / stride) + 1], s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipEventRecord");
         // this slot's list was last sent two ticks ago: that collective must have read it before it is rewritten
         if (rc == 0 && xio && zrk_exchange_wait(xio->x, slot, stream) != 0) rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
         if (rc == 0 && (det_idx || list))
