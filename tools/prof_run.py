@@ -15,9 +15,16 @@ R = int(sys.argv[3]) if len(sys.argv) > 3 else int(os.environ.get("PROF_R", 16))
 m = int(sys.argv[4]) if len(sys.argv) > 4 else int(os.environ.get("PROF_M", 10_000))
 ids, sp, vel, t0 = S.synthetic_targets(n, 1237)
 eng = HotPathEngine(device="cuda:0", dt_ms=10, seed=1237, noise="philox")
-eng.load(ids, sp, vel, t0, S.synthetic_radars(R), missile_capacity=m).enable_lists()
+radars = S.synthetic_radars(R)
+if os.environ.get("PROF_RANGE"):          # e.g. 1: nobody is ever in range, every wave takes the light path
+    for r in radars:
+        r["max_distance"] = float(os.environ["PROF_RANGE"])
+eng.load(ids, sp, vel, t0, radars, missile_capacity=m).enable_lists()
 if m:
-    eng.launch_missiles(S.missile_targets(n, m))
+    tg = S.missile_targets(n, m)
+    if os.environ.get("PROF_TGT_NEAR"):     # all missiles against a few neighbouring rows: their gathers share cache lines
+        tg = (tg % 64).astype(tg.dtype)
+    eng.launch_missiles(tg)
 eng.run(ticks)
 torch.cuda.synchronize()
 eng.store.compact_status()
