@@ -1,0 +1,93 @@
+"""Overlap mode of zrk_run_ticks (ZRK_OVERLAP=1): the lists of tick t are compacted on a side stream beside the sweep of
+tick t + 1, the tombstones / dispatch order / radar records stay on the compute stream as a small launch of their own.
+The tick-by-tick loop is checked against the oracle elsewhere (test_gpu_engine.py); here the overlapped loop, in calls
+of several ticks, must leave exactly what that loop leaves: position bits of both buffers, flags, masks of the last
+tick, every list, the ordered events, the missile table."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(eng):
+    st = eng.store
+    n, m = st.n_uploaded, st.m
+    torch.cuda.synchronize()
+    eng.store.compact_status()
+    ne = int(st.dm_evn.item())
+    out = dict(pos_cur=st.host_pos("cur").view(np.uint64), pos_prev=st.host_pos("prev").view(np.uint64),
+               alive=st.d_alive[:n].cpu().numpy(), vis=st.vis()[:n].cpu().numpy(),
+               period=st.dm_period[:m].cpu().numpy().view(np.uint64), status=st.dm_status[:m].cpu().numpy(),
+               ev_m=st.dm_evm[:ne].cpu().numpy(), ev_t=st.dm_evt[:ne].cpu().numpy(), ne=np.array([ne]),
+               radar=np.array(eng.radar_state()))
+    for r, lst in enumerate(eng.detections()):
+        out[f"list{r}"] = lst
+    return out
+
+
+def _same(a, b, what):
+    assert a.keys() == b.keys()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), f"{what}: {k} differs"
+
+
+@pytest.mark.parametrize("n,R,m,noise", [(40_000, 6, 300, "philox"), (40_000, 6, 300, "off"), (3_000, 16, 0, "philox"),
+                                         (700_000, 5, 2_000, "philox")],
+                         ids=["mid", "mid-no-noise", "small-no-missiles", "multi-round-grid"])
+def test_overlapped_loop_leaves_what_the_tick_by_tick_loop_leaves(n, R, m, noise, monkeypatch):
+    from tests.test_gpu_engine import _engine
+    monkeypatch.setenv("ZRK_OVERLAP", "0")
+    ref, _, launched = _engine(n, R, m, seed=21, noise=noise)
+    monkeypatch.setenv("ZRK_OVERLAP", "1")
+    ovl, _, _ = _engine(n, R, m, seed=21, noise=noise)
+    assert m == 0 or launched > 50
+    total_events = 0
+    for calls, K in enumerate([5, 4, 9, 1, 6, 2, 7]):            # (calls of fewer than four ticks take the plain loop)
+        for _ in range(K):
+            ref.run(1)
+        ovl.run(K)
+        a, b = _state(ref), _state(ovl)
+        _same(a, b, f"after call {calls} of {K} ticks")
+        total_events += int(a["ne"][0])
+    assert m == 0 or total_events > 0
+    assert np.count_nonzero(a["vis"]) > 0
+
+
+def test_overlap_with_the_exchange_on_one_rank(monkeypatch):
+    """The same with the list going through the C-side all-gather (one rank): compaction, events tail and the collective
+    share the side stream; the merged list and the events of the second last and the last tick of a call are the plain
+    loop's."""
+    from tests.test_gpu_engine import _engine
+    from zrk_modulation_amd.exchange import RcclExchange, union_bits_words
+    n, R, m = 30_000, 6, 400
+    monkeypatch.setenv("ZRK_OVERLAP", "0")
+    ref, _, _ = _engine(n, R, m, seed=11, noise="philox")
+    monkeypatch.setenv("ZRK_OVERLAP", "1")
+    ovl, _, _ = _engine(n, R, m, seed=11, noise="philox")
+    ovl.gid0 = ovl.loop.gid0 = 0
+    x = RcclExchange(union_bits_words(ovl.store.cap, R, ovl.store.cap), ovl.store.device, R, offsets=[0], ev_capacity=512)
+    st = ref.store
+    lidx = st.d_lidx.cpu().numpy() if st.d_lidx is not None else None
+    to_list = (lambda r: int(lidx[r])) if lidx is not None else (lambda r: int(r))
+    tick = 0
+    seen_events = 0
+    for K in (7, 5, 8):
+        ovl.run(K, exchange=x)
+        x.sync()
+        for back in (1, 0):                                      # second last tick, then the last one
+            ref.run(K - 1 if back else 1)
+            slot = (tick + (K - 2 if back else K - 1)) & 1
+            vis = st.vis()[:st.n_uploaded].cpu().numpy().view(np.uint32)
+            idx, msk = x.merged(slot)
+            want = np.nonzero(vis)[0]
+            assert np.array_equal(idx.cpu().numpy(), want), f"K={K} back={back}: union list differs"
+            assert np.array_equal(msk.cpu().numpy().astype(np.uint32), vis[want])
+            ne = int(st.dm_evn.item())
+            rows_m, rows_t = st.dm_evm[:ne].cpu().numpy(), st.dm_evt[:ne].cpu().numpy()
+            assert x.events(slot) == [(to_list(a), -1 if b < 0 else to_list(b)) for a, b in zip(rows_m, rows_t)]
+            seen_events += ne
+        tick += K
+    assert seen_events > 0
+    _same(_state(ref), _state(ovl), "after the exchanged calls")
+    x.close()

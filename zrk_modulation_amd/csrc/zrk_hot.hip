@@ -927,6 +927,7 @@ constexpr int kScanThreads = 1024;
 constexpr int kScanItems = 4;
 
 __device__ void missile_finish_entry(int *s_wave, const MissileArgs &M);
+__device__ void missile_kills(const MissileArgs &M, int part);
 
 __global__ __launch_bounds__(kScanThreads) void k_scan_counts(const int32_t *__restrict__ counts,
                                                               int32_t *__restrict__ offs,
@@ -1097,41 +1098,64 @@ constexpr int kSpinLimit = 1 << 22;
 // (Sorting by cost instead of two classes measured the same.)
 __device__ void build_order(int *s_wave, const OrderArgs &O)
 {
-    __shared__ int s_heavy, s_carry[2];
+    // Each thread takes kPer CONSECUTIVE row blocks (one pair of 16-byte loads), so that a single scan over the threads
+    // ranks the expensive blocks, and the cheap ones behind them, in block order.  Tables of more than kPer x blockDim
+    // row blocks take further rounds, and a counting pass first (the cheap blocks start behind ALL expensive ones).
+    constexpr int kPer = 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    int mine = 0;
-    for (int b = tid; b < O.nb; b += blockDim.x) mine += O.cost[b] > 0;
-    for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d);
-    if (lane == 0) s_wave[wave] = mine;
-    __syncthreads();
-    if (tid == 0) {
-        int h = 0;
-        for (int w = 0; w < nw; ++w) h += s_wave[w];
-        s_heavy = h; s_carry[0] = 0; s_carry[1] = 0;
+    const int per_round = kPer * (int)blockDim.x;
+    const int rounds = (O.nb + per_round - 1) / per_round;
+    int heavy_total = 0;
+    if (rounds > 1) {
+        int mine = 0;
+        for (int b = tid; b < O.nb; b += blockDim.x) mine += O.cost[b] > 0;
+        for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d);
+        if (lane == 0) s_wave[wave] = mine;
+        __syncthreads();
+        for (int w = 0; w < nw; ++w) heavy_total += s_wave[w];
+        __syncthreads();
     }
-    __syncthreads();
-    const int heavy_total = s_heavy;
-    for (int base = 0; base < O.nb; base += blockDim.x) {
-        const int b = base + tid;
-        const bool in = b < O.nb;
-        const bool hv = in && O.cost[b] > 0;
-        if (in) O.cost[b] = 0;
-        const unsigned long long bh = __ballot(hv), bl = __ballot(in && !hv);
-        __syncthreads();                                      // s_wave free again
-        if (lane == 0) s_wave[wave] = (int)__popcll(bh) | ((int)__popcll(bl) << 16);
-        __syncthreads();
-        int oh = s_carry[0], ol = s_carry[1], th = 0, tl = 0;
-        for (int w = 0; w < nw; ++w) {
-            const int v = s_wave[w], vh = v & 0xFFFF, vl = v >> 16;
-            if (w < wave) { oh += vh; ol += vl; }
-            th += vh; tl += vl;
+    int carry_h = 0, carry_l = 0;
+    for (int r = 0; r < rounds; ++r) {
+        const int b0 = r * per_round + tid * kPer;
+        int c[kPer];
+        if (b0 + kPer <= O.nb) {
+            const int4 lo = *(const int4 *)(O.cost + b0), hi = *(const int4 *)(O.cost + b0 + 4);
+            c[0] = lo.x; c[1] = lo.y; c[2] = lo.z; c[3] = lo.w; c[4] = hi.x; c[5] = hi.y; c[6] = hi.z; c[7] = hi.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) c[k] = (b0 + k < O.nb) ? O.cost[b0 + k] : 0;
         }
-        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        if (hv) O.order[oh + (int)__popcll(bh & below)] = b;
-        else if (in) O.order[heavy_total + ol + (int)__popcll(bl & below)] = b;
+        int h = 0, l = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const bool in = b0 + k < O.nb;
+            h += in && c[k] > 0;
+            l += in && !(c[k] > 0);
+        }
+        const int v = h | (l << 16);                           // (at most kPer x 1024 of either: 14 bits)
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
-        if (tid == 0) { s_carry[0] += th; s_carry[1] += tl; }
-        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < nw; ++w) { if (w < wave) before += s_wave[w]; total += s_wave[w]; }
+        if (rounds == 1) heavy_total = total & 0xFFFF;
+        const int excl = before + incl - v;
+        int oh = carry_h + (excl & 0xFFFF), ol = heavy_total + carry_l + (excl >> 16);
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            if (b0 + k < O.nb) {
+                if (c[k] > 0) O.order[oh++] = b0 + k; else O.order[ol++] = b0 + k;
+                O.cost[b0 + k] = 0;
+            }
+        }
+        carry_h += total & 0xFFFF; carry_l += total >> 16;
+        __syncthreads();                                       // s_wave free again
     }
 }
 
@@ -1417,6 +1441,22 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_fused(const CompactArgs 
     compact_block<kCompBlock>(S, C, by_ticket);
 }
 
+// Overlap mode of zrk_run_ticks: what the NEXT sweep needs of a tick's second launch -- the tombstones, the dispatch
+// order, the radar records -- as a launch of its own (a dozen workgroups) on the compute stream, while the lists and
+// the ordered events are compacted on a side stream beside the next sweep.
+__global__ __launch_bounds__(kCompBlock) void k_tick_small(const MissileArgs M, const OrderArgs O, const EnsembleArgs E,
+                                                           const PutArgs U)
+{
+    __shared__ int s_wave[kCompBlock / 64];
+    int extra = (int)blockIdx.x;
+    if (O.nb > 0 && extra-- == 0) { build_order(s_wave, O); return; }
+    const int kparts = (int)((M.m + kCompBlock - 1) / kCompBlock);
+    if (extra < kparts) { missile_kills(M, extra); return; }
+    extra -= kparts;
+    if (E.S > 0) { if ((int64_t)extra * kCompBlock < (int64_t)E.S * E.R) ensemble_derive(E, extra); return; }
+    if (U.dst && extra == 0) put_radar_block(U);
+}
+
 // SectorRadar.smooth_objects with supplied draws: pos[idx[j]] += noise[j].
 __global__ void k_noise_apply(double *__restrict__ pos, int64_t cap, const int32_t *__restrict__ idx,
                               int32_t idx_base, const double *__restrict__ noise, int64_t k)
@@ -1556,6 +1596,19 @@ __global__ __launch_bounds__(1024) void k_missile_finish(const uint8_t *__restri
     __shared__ int s_wave[16];
     missile_finish_block(s_wave, ev_code, m_slot, m_tgt, m, ev_missile, ev_target, ev_count, apply, alive, pos_cur,
                          pos_prev, cap);
+}
+
+// Overlap mode: the tombstones of this tick's detonations, unordered (one thread per missile row, any number of
+// workgroups); the ordered event list, nobody's input on the compute stream, is built on the side stream.
+__device__ void missile_kills(const MissileArgs &M, int part)
+{
+    const int64_t row = (int64_t)part * blockDim.x + threadIdx.x;
+    if (row >= M.m) return;
+    const uint8_t code = M.ev_code[row];
+    const int32_t ms = M.m_slot[row], ts = M.m_tgt[row];
+    if (!code) return;
+    kill_one(M.alive, M.pos_cur, M.pos_prev, M.cap, ms);
+    if (code == 1) kill_one(M.alive, M.pos_cur, M.pos_prev, M.cap, ts);
 }
 
 __device__ void missile_finish_entry(int *s_wave, const MissileArgs &M)
@@ -1935,6 +1988,55 @@ double d2_threshold(double m)
 
 }  // namespace
 
+// Overlap mode of zrk_run_ticks: the side stream on which a tick's lists are compacted beside the next tick's sweep,
+// and the thread that issues its work (waiting for a flag word, the compaction, in an exchange the collective behind it,
+// an event) so that the calling thread is left with the two launches of the compute stream.
+struct zrk_exchange;
+struct SideItem {
+    hipStream_t stream;
+    uint32_t flag_value;            // flag[0] >= this: the tick's two launches on the compute stream are over (raised by
+                                    // the first thread of the next sweep, or by a launch of its own behind the last tick)
+    CompactArgs C;
+    int by_ticket;
+    MissileArgs M;                  // apply == 0: the ordered event list only (and the events in the list's tail)
+    zrk_exchange *x;                // non-NULL: all-gather the list behind the compaction ...
+    int xslot;
+    const int64_t *send;
+    int64_t *recv;
+    int64_t words;
+    int done_slot;                  // done[done_slot] is recorded last
+};
+
+struct Side {
+    hipStream_t stream = nullptr;   // (an exchange's own stream is used instead of this one when there is one)
+    uint32_t *flag = nullptr;       // device words: [0] see SideItem; [2] a wait gave up
+    uint32_t seq = 0;
+    // mask buffers of its own for all ticks of a call but the last (whose masks the caller may read): each is all zero
+    // except between the sweep that writes it and the compaction that reads and clears it; slot kMasks stands for the
+    // caller's buffer of the last tick
+    static constexpr int kMasks = 3;
+    uint32_t *masks[kMasks] = {nullptr, nullptr, nullptr};
+    int64_t mask_rows = 0;
+    // ... and, with the same lifetimes, the per-row event codes of the missile phase (written by a tick's sweep, read by
+    // its tombstones on the compute stream and by its event list on the side stream, beside the next sweep)
+    uint8_t *codes[kMasks] = {nullptr, nullptr, nullptr};
+    int64_t code_rows = 0;
+    bool masks_dirty = false;       // a call failed half-way: clear them before the next use
+    uint64_t mask_pos = 0;
+    hipEvent_t done[kMasks + 1] = {nullptr, nullptr, nullptr, nullptr};
+    bool posted[kMasks + 1] = {false, false, false, false};
+    uint64_t item_no[kMasks + 1] = {0, 0, 0, 0};
+    static constexpr uint64_t kRing = 8;
+    SideItem ring[kRing];
+    std::atomic<uint64_t> head{0}, tail{0};
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<bool> asleep{false}, stop{false};
+    std::atomic<int> rc{0};
+    std::string err;
+};
+
 struct zrk_ctx {
     int device;
     int cus = 256;                     // compute units of the device
@@ -1967,7 +2069,10 @@ struct zrk_ctx {
     std::vector<hipEvent_t> tev;       // timing events of zrk_run_ticks, reused
     int tev_pending = 0;               // event pairs recorded by a deferred-profile call, not read yet
     const void *ring_key = nullptr;    // mask buffers zrk_run_ticks has been alternating between ...
-    int64_t ring_age = 0;              // ... for this many consecutive ticks (>= 1: the next one starts cleared)
+    bool ring_clean[2] = {false, false};   // ... and whether each is all zero when its next sweep starts
+    Side *side = nullptr;              // overlap mode, created on first use
+    int overlap = 1;                   // ZRK_OVERLAP: 0 never, 1 (default) for calls of at least overlap_min ticks
+    int overlap_min = 4;
 };
 
 namespace {
@@ -2044,6 +2149,8 @@ ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
     if (const char *v = std::getenv("ZRK_SWEEP_ORDER")) c->order_enabled = std::atoi(v) != 0;
     if (const char *v = std::getenv("ZRK_DIAG")) c->diag = (uint32_t)std::strtoul(v, nullptr, 0);
     { const char *v = std::getenv("ZRK_TIME_BY_RECORDS"); c->time_on_dispatch = !(v && v[0] == '1'); }
+    { const char *v = std::getenv("ZRK_OVERLAP"); c->overlap = v ? std::atoi(v) : 1; }
+    { const char *v = std::getenv("ZRK_OVERLAP_MIN"); c->overlap_min = v ? std::max(2, std::atoi(v)) : 4; }
     if (const char *v = std::getenv("ZRK_COMPACT_ITEMS")) c->env_items = std::max(1, std::atoi(v));
     if (const char *v = std::getenv("ZRK_COMPACT_ORDER")) c->env_order = std::strcmp(v, "block") != 0;
     c->fused_max_blocks = kFusedMaxBlocks;
@@ -2069,9 +2176,12 @@ ZRK_API int zrk_ctx_create(int device, zrk_ctx **out)
     return 0;
 }
 
+namespace { void side_destroy(Side *sd); }
+
 ZRK_API void zrk_ctx_destroy(zrk_ctx *ctx)
 {
     if (!ctx) return;
+    side_destroy(ctx->side);
     for (hipEvent_t e : ctx->tev) (void)hipEventDestroy(e);
     delete ctx;
 }
@@ -2211,7 +2321,8 @@ bool compacts_in_one_launch(const zrk_ctx *ctx, int64_t n)
 int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int32_t base_index, void *workspace,
                    int32_t *det_idx, int64_t det_stride, int32_t *det_cnt, int64_t *packed, int64_t packed_capacity,
                    int64_t gid0, void *stream, const MissileArgs &M, uint32_t *zero_next, const OrderArgs &O,
-                   bool union_bits = false, const EnsLaunch *ens = nullptr, const PutArgs *put = nullptr)
+                   bool union_bits = false, const EnsLaunch *ens = nullptr, const PutArgs *put = nullptr,
+                   SideItem *defer = nullptr)
 {
     if (!ctx || !vis_mask || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_compact: null argument");
     if ((det_idx && !det_cnt) || (!det_idx && !packed)) return fail(ctx, ZRK_E_INVALID, "zrk_compact: no output requested");
@@ -2265,12 +2376,17 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         EnsembleArgs E;
         std::memset(&E, 0, sizeof(E));
         if (ens) E = ens->next;
+        if (defer) {                                 // overlap mode: the side stream's thread launches it (lists only)
+            defer->C = C; defer->by_ticket = by_ticket;
+            return 0;
+        }
         const int eparts = ens ? nblocks((int64_t)E.S * E.R, kCompBlock) : ((put && put->dst) ? 1 : 0);
         static PutArgs no_put;                       // (zero-initialised: dst == NULL)
         hipLaunchKernelGGL(k_compact_fused, dim3((int)nbf + (M.m > 0 ? 1 : 0) + (O.nb > 0 ? 1 : 0) + eparts), dim3(kCompBlock), 0, s,
                            C, by_ticket, M, O, E, (put && !ens) ? *put : no_put);
         return check_launch(ctx, "k_compact_fused");
     }
+    if (defer) return fail(ctx, ZRK_E_INVALID, "zrk_compact: overlap mode needs the single-launch compaction");
     const int nb = nblocks(n, kCompBlock);
     Workspace w = carve(workspace, nb, n);
     hipLaunchKernelGGL(k_count_blocks, dim3(nb), dim3(kCompBlock), 0, s, vis_mask, n, R, nb, w.counts);
@@ -2313,6 +2429,12 @@ ZRK_API int zrk_compact_status(zrk_ctx *ctx, void *workspace, void *stream)
     hipStream_t s = (hipStream_t)stream;
     if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(ctl, workspace, sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess)
         return fail(ctx, ZRK_E_HIP, "zrk_compact_status: copy failed");
+    if (ctx->side) {                               // overlap mode: did a wait on the side stream run out?
+        uint32_t gave_up = 0;
+        if (hipMemcpy(&gave_up, ctx->side->flag + 2, sizeof(gave_up), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(ctx, ZRK_E_HIP, "zrk_compact_status: copy failed");
+        if (gave_up) return fail(ctx, ZRK_E_STATE, "zrk_run_ticks: the side stream gave up waiting for a sweep to finish; its lists are not valid");
+    }
     if (ctx->fused_ws != workspace) return 0;      // never used with this context
     if (ctl[2] == 0 && ctl[0] == 0 && ctl[1] == 0) return 0;
     ctx->fused_ws = nullptr;                       // cleared again on the next use
@@ -2764,6 +2886,120 @@ ZRK_API int zrk_exchange_sync(zrk_exchange *x)
 
 namespace {
 
+// ---- overlap mode: the side stream and its thread --------------------------------------------------------------
+
+int side_issue(Side *sd, const SideItem &it)
+{
+    static PutArgs no_put;                               // (zero-initialised: dst == NULL)
+    EnsembleArgs no_ens;
+    std::memset(&no_ens, 0, sizeof(no_ens));
+    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, it.stream, sd->flag, it.flag_value, sd->flag + 2);
+    hipLaunchKernelGGL(k_compact_fused, dim3(it.C.nb + (it.M.m > 0 ? 1 : 0)), dim3(kCompBlock), 0, it.stream, it.C, it.by_ticket, it.M,
+                       OrderArgs{nullptr, nullptr, 0, 0}, no_ens, no_put);
+    if (hipGetLastError() != hipSuccess) { sd->err = "side stream: compaction launch failed"; return ZRK_E_HIP; }
+    if (it.x) {
+        const int rc = it.x->api.AllGather(it.send, it.recv, (size_t)it.words, kNcclInt64, it.x->comm, it.stream);
+        if (rc != 0) {
+            sd->err = std::string("ncclAllGather: ") + (it.x->api.GetErrorString ? it.x->api.GetErrorString(rc) : "error");
+            return ZRK_E_HIP;
+        }
+        if (hipEventRecord(it.x->done[it.xslot], it.stream) != hipSuccess) { sd->err = "side stream: hipEventRecord failed"; return ZRK_E_HIP; }
+        it.x->posted[it.xslot] = true;
+    }
+    if (hipEventRecord(sd->done[it.done_slot], it.stream) != hipSuccess) { sd->err = "side stream: hipEventRecord failed"; return ZRK_E_HIP; }
+    sd->posted[it.done_slot] = true;
+    return 0;
+}
+
+void side_main(Side *sd, int device)
+{
+    if (hipSetDevice(device) != hipSuccess) { sd->err = "hipSetDevice failed in the side stream's thread"; sd->rc.store(ZRK_E_HIP); }
+    auto idle_since = std::chrono::steady_clock::now();
+    for (;;) {
+        const uint64_t t = sd->tail.load(std::memory_order_relaxed);
+        if (sd->head.load(std::memory_order_acquire) != t) {
+            const SideItem it = sd->ring[t % Side::kRing];
+            if (sd->rc.load() == 0) { const int rc = side_issue(sd, it); if (rc != 0) sd->rc.store(rc); }
+            sd->tail.store(t + 1, std::memory_order_release);
+            idle_since = std::chrono::steady_clock::now();
+            continue;
+        }
+        if (sd->stop.load()) return;
+        if (std::chrono::steady_clock::now() - idle_since < std::chrono::milliseconds(50)) { __builtin_ia32_pause(); continue; }
+        std::unique_lock<std::mutex> lk(sd->mu);
+        sd->asleep.store(true);
+        if (sd->head.load(std::memory_order_acquire) == sd->tail.load() && !sd->stop.load()) sd->cv.wait_for(lk, std::chrono::milliseconds(1));
+        sd->asleep.store(false);
+    }
+}
+
+Side *side_of(zrk_ctx *ctx)
+{
+    if (ctx->side) return ctx->side;
+    Side *sd = new Side;
+    bool ok = hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void **)&sd->flag, 16) == hipSuccess && hipMemset(sd->flag, 0, 16) == hipSuccess;
+    for (int k = 0; k <= Side::kMasks && ok; ++k) ok = hipEventCreateWithFlags(&sd->done[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        for (int k = 0; k <= Side::kMasks; ++k) if (sd->done[k]) (void)hipEventDestroy(sd->done[k]);
+        if (sd->flag) (void)hipFree(sd->flag);
+        if (sd->stream) (void)hipStreamDestroy(sd->stream);
+        delete sd;
+        return nullptr;
+    }
+    sd->worker = std::thread(side_main, sd, ctx->device);
+    ctx->side = sd;
+    return sd;
+}
+
+void side_enqueue(Side *sd, const SideItem &it)
+{
+    const uint64_t h = sd->head.load(std::memory_order_relaxed);
+    while (h - sd->tail.load(std::memory_order_acquire) >= Side::kRing) __builtin_ia32_pause();
+    sd->ring[h % Side::kRing] = it;
+    sd->head.store(h + 1, std::memory_order_release);
+    sd->item_no[it.done_slot] = h + 1;
+    if (sd->asleep.load()) { std::lock_guard<std::mutex> lk(sd->mu); sd->cv.notify_one(); }
+}
+
+// Everything up to item number `upto` has been issued (0), or the thread's failure.
+int side_drain(zrk_ctx *ctx, Side *sd, uint64_t upto)
+{
+    while (sd->tail.load(std::memory_order_acquire) < upto) __builtin_ia32_pause();
+    if (sd->rc.load() != 0) return fail(ctx, sd->rc.load(), sd->err);
+    return 0;
+}
+
+// The compaction that last used mask buffer `slot` is over (the host waits: see zrk_exchange_wait for why not the stream).
+int side_wait(zrk_ctx *ctx, Side *sd, int slot)
+{
+    if (int rc = side_drain(ctx, sd, sd->item_no[slot])) return rc;
+    if (!sd->posted[slot]) return 0;
+    for (;;) {
+        const hipError_t q = hipEventQuery(sd->done[slot]);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) return fail(ctx, ZRK_E_HIP, "side stream: hipEventQuery failed");
+        __builtin_ia32_pause();
+    }
+}
+
+void side_destroy(Side *sd)
+{
+    if (!sd) return;
+    if (sd->worker.joinable()) {
+        sd->stop.store(true);
+        { std::lock_guard<std::mutex> lk(sd->mu); sd->cv.notify_one(); }
+        sd->worker.join();
+    }
+    if (sd->stream) { (void)hipStreamSynchronize(sd->stream); (void)hipStreamDestroy(sd->stream); }
+    for (int k = 0; k <= Side::kMasks; ++k) if (sd->done[k]) (void)hipEventDestroy(sd->done[k]);
+    for (int k = 0; k < Side::kMasks; ++k) if (sd->masks[k]) (void)hipFree(sd->masks[k]);
+    for (int k = 0; k < Side::kMasks; ++k) if (sd->codes[k]) (void)hipFree(sd->codes[k]);
+    if (sd->flag) (void)hipFree(sd->flag);
+    delete sd;
+}
+
 // Timing events of zrk_run_ticks: created once per context and reused (the multi-rank loop calls with K = 1).
 bool ensure_events(zrk_ctx *ctx, int pairs)
 {
@@ -2858,7 +3094,57 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     const int64_t ev_words = (xio && xio->ev_capacity > 0) ? 1 + (int64_t)xio->ev_capacity : 0;
     // hand-over of a tick's list to the exchange stream: by the flag the next tick's sweep raises (no packet of its own on
     // the compute stream), the last tick of the call -- which has no next sweep -- by an event
-    zrk_exchange *fx = (xio && xio->x->flag) ? xio->x : nullptr;
+    // Overlap mode: the lists of tick t are compacted on a side stream beside the sweep of tick t + 1; what that sweep
+    // needs of the tick's second launch (tombstones, events, dispatch order, radar records) stays on the compute stream
+    // as k_tick_small.  For calls of a few ticks at least: the last tick's compaction has nothing to run beside.
+    Side *sd = nullptr;
+    if (ctx->overlap > 0 && K >= ctx->overlap_min && (det_idx || packed || xio) && st->n > 0 && R > 0 && e->vis_mask_alt &&
+        (ens || rb_through_memory) && (m == 0 || m <= 1024 * (int64_t)kMissileItems)) {
+        sd = side_of(ctx);
+        if (!sd) return fail(ctx, ZRK_E_HIP, "zrk_run_ticks: the side stream could not be created");
+        if (xio && exchange_drain(xio->x, xio->x->head.load()) != 0) return fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
+        if (sd->mask_rows < e->capacity || sd->masks_dirty) {
+            if (int rc0 = side_drain(ctx, sd, sd->head.load())) return rc0;
+            if (hipStreamSynchronize(sd->stream) != hipSuccess || (xio && hipStreamSynchronize(xio->x->cstream) != hipSuccess))
+                return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
+            for (int k = 0; k < Side::kMasks; ++k) {
+                if (sd->mask_rows < e->capacity) {
+                    if (sd->masks[k]) (void)hipFree(sd->masks[k]);
+                    sd->masks[k] = nullptr;
+                    if (hipMalloc((void **)&sd->masks[k], sizeof(uint32_t) * (size_t)e->capacity) != hipSuccess)
+                        return fail(ctx, ZRK_E_HIP, "zrk_run_ticks: the side stream's mask buffers could not be allocated");
+                }
+                if (hipMemsetAsync(sd->masks[k], 0, sizeof(uint32_t) * (size_t)e->capacity, s) != hipSuccess)
+                    return fail(ctx, ZRK_E_HIP, "memset masks");
+            }
+            sd->mask_rows = e->capacity; sd->masks_dirty = false;
+            for (int k = 0; k <= Side::kMasks; ++k) { sd->posted[k] = false; sd->item_no[k] = 0; }
+        }
+        if (m > sd->code_rows) {
+            if (int rc0 = side_drain(ctx, sd, sd->head.load())) return rc0;
+            if (hipStreamSynchronize(sd->stream) != hipSuccess || (xio && hipStreamSynchronize(xio->x->cstream) != hipSuccess))
+                return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
+            const int64_t rows = std::max<int64_t>(2 * m, 4096);
+            for (int k = 0; k < Side::kMasks; ++k) {
+                if (sd->codes[k]) (void)hipFree(sd->codes[k]);
+                sd->codes[k] = nullptr;
+                if (hipMalloc((void **)&sd->codes[k], (size_t)rows) != hipSuccess)
+                    return fail(ctx, ZRK_E_HIP, "zrk_run_ticks: the side stream's event-code buffers could not be allocated");
+            }
+            sd->code_rows = rows;
+        }
+        if (sd->seq > 0x7FFF0000u) {                     // far from wrapping: the comparison is on 32 bits
+            if (int rc0 = side_drain(ctx, sd, sd->head.load())) return rc0;
+            if (hipStreamSynchronize(xio ? xio->x->cstream : sd->stream) != hipSuccess || hipStreamSynchronize(sd->stream) != hipSuccess)
+                return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
+            hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, s, sd->flag, 0u);
+            if (hipStreamSynchronize(s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
+            sd->seq = 0;
+        }
+    }
+    hipStream_t side_stream = sd ? (xio ? xio->x->cstream : sd->stream) : nullptr;
+    int side_last = -1;
+    zrk_exchange *fx = (!sd && xio && xio->x->flag) ? xio->x : nullptr;
     if (fx && fx->seq > 0x7FFF0000u) {                   // far from wrapping: the comparison is on 32 bits
         if (hipStreamSynchronize(fx->cstream) != hipSuccess) return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
         hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, s, fx->flag, 0u);
@@ -2887,12 +3173,23 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         // writes densely; from then on the pair belongs to this loop, also between calls (a caller that
         // writes them itself must pass other buffers or call with vis_mask_alt = NULL).
         const bool two_vis = e->vis_mask_alt && (det_idx || list) && st->n > 0 && R > 0;
-        if (ctx->ring_key != (const void *)e->vis_mask || !two_vis) { ctx->ring_key = e->vis_mask; ctx->ring_age = 0; }
+        if (ctx->ring_key != (const void *)e->vis_mask || !two_vis) {
+            ctx->ring_key = e->vis_mask; ctx->ring_clean[0] = ctx->ring_clean[1] = false;
+        }
         if (two_vis) st->vis_cur ^= 1; else st->vis_cur = 0;
         uint32_t *vis_now = st->vis_cur ? e->vis_mask_alt : e->vis_mask;
         uint32_t *vis_next = two_vis ? (st->vis_cur ? e->vis_mask : e->vis_mask_alt) : nullptr;
-        const uint32_t sparse = (two_vis && ctx->ring_age > 0) ? kSparseVis : 0u;
-        if (two_vis) ctx->ring_age += 1;
+        uint32_t sparse = (two_vis && ctx->ring_clean[st->vis_cur]) ? kSparseVis : 0u;
+        int side_slot = Side::kMasks;                     // overlap mode: the last tick's masks go where the caller can read them
+        if (sd && k + 1 < K) {
+            // ... the others into one of the side stream's own buffers: clean, once the compaction that used it three
+            // ticks ago is through (the host waits, see zrk_exchange_wait for why not the stream)
+            side_slot = (int)(sd->mask_pos++ % Side::kMasks);
+            vis_now = sd->masks[side_slot];
+            sparse = kSparseVis;
+        }
+        if (sd && (rc = side_wait(ctx, sd, side_slot)) != 0) break;
+        if (sd && side_slot < Side::kMasks && M.m > 0) M.ev_code = sd->codes[side_slot];
         // next tick's dispatch order: built by this tick's compaction from the costs this tick's sweep records
         const int nbs = nblocks(st->n, ZRK_BLOCK);
         // (a grid that is resident all at once has no "last": eight workgroups of four waves fit a compute unit)
@@ -2920,7 +3217,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         rc = launch_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse, st->seed,
                           st->tick, st->gid0, workspace, stream, M, vis_now, ordering ? w.cost : nullptr,
                           (ordering && ctx->order_ready) ? w.order : nullptr, w.boxes, ens ? &EL : nullptr,
-                          rb_through_memory ? rb_dev[st->tick & 1u] : nullptr, pend.on ? fx->flag : nullptr, pend.value,
+                          rb_through_memory ? rb_dev[st->tick & 1u] : nullptr,
+                          pend.on ? fx->flag : ((sd && k > 0) ? sd->flag : nullptr), pend.on ? pend.value : (sd ? sd->seq : 0u),
                           on_dispatch ? ev[2 * (k / stride)] : nullptr, on_dispatch ? ev[2 * (k / stride) + 1] : nullptr);
         if (pend.on) {                                                       // the previous tick's collective, behind this sweep's start
             if (rc == 0 && !(st->n > 0 || M.m > 0)) {                        // (no sweep was launched: raise the flag by itself)
@@ -2939,8 +3237,42 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             put.dst = (uint32_t *)rb_dev[(st->tick + 1) & 1u];
         }
         if (prof && !on_dispatch && rc == 0 && hipEventRecord(ev[2 * (k / stride) + 1], s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipEventRecord");
+        if (sd) {
+            if (rc != 0) break;
+            // compute stream: what the next sweep needs (the next sweep's first thread, or the launch behind the loop,
+            // releases the side stream: beside this small launch the compaction would only be in its way)
+            EnsembleArgs E0;
+            std::memset(&E0, 0, sizeof(E0));
+            static PutArgs no_put;
+            const OrderArgs O = ordering ? OrderArgs{w.cost, w.order, nbs, 0} : OrderArgs{nullptr, nullptr, 0, 0};
+            const int eparts = ens ? nblocks((int64_t)EL.next.S * EL.next.R, kCompBlock) : (rb_through_memory ? 1 : 0);
+            const int small_grid = std::max(1, nblocks(M.m, kCompBlock) + (O.nb > 0 ? 1 : 0) + eparts);
+            SideItem it;
+            std::memset((void *)&it, 0, sizeof(it));
+            // (the single-launch workspace's first-use clearing, if any, goes to the compute stream, ahead of the flag)
+            rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, list, list_words,
+                                st->gid0, stream, no_missiles(), (side_slot < Side::kMasks) ? vis_now : nullptr, OrderArgs{nullptr, nullptr, 0, 0},
+                                (st->flags & ZRK_F_UNION_BITS) != 0, ens ? &EL : nullptr, nullptr, &it);
+            if (rc != 0) break;
+            const uint32_t v = ++sd->seq;
+            hipLaunchKernelGGL(k_tick_small, dim3(small_grid), dim3(kCompBlock), 0, s, M, O, ens ? EL.next : E0,
+                               (rb_through_memory && !ens) ? put : no_put);
+            if ((rc = check_launch(ctx, "k_tick_small")) != 0) break;
+            if (ordering) ctx->order_ready = true;
+            if (ev_words && !fused && hipMemsetAsync(list + list_words, 0, sizeof(int64_t), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset events"); break; }
+            it.stream = side_stream; it.flag_value = v; it.done_slot = side_slot;
+            it.M = M; it.M.apply = 0;
+            if (xio) { it.x = xio->x; it.xslot = slot; it.send = list; it.recv = xio->recv[slot]; it.words = xio->words; }
+            side_enqueue(sd, it);
+            side_last = side_slot;
+            if (side_slot == Side::kMasks) ctx->ring_clean[st->vis_cur] = false;
+            st->time_ms += st->dt_ms;
+            st->tick += 1;
+            continue;
+        }
         // this slot's list was last sent two ticks ago: that collective must have read it before it is rewritten
         if (rc == 0 && xio && zrk_exchange_wait(xio->x, slot, stream) != 0) rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
+        if (rc == 0 && two_vis) { ctx->ring_clean[st->vis_cur] = false; ctx->ring_clean[st->vis_cur ^ 1] = true; }
         if (rc == 0 && (det_idx || list))
             rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, list,
                                 list_words, st->gid0, stream, M, vis_next,
@@ -2963,6 +3295,19 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         }
         st->time_ms += st->dt_ms;                                            // Manager.py:140
         st->tick += 1;
+    }
+    if (sd) {
+        // the events in the last list's tail are complete once something behind its k_tick_small has started; then the
+        // side stream's work is issued to the last item, and the compute stream takes it in: the lists are the caller's
+        if (rc == 0 && side_last >= 0) {
+            hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, s, sd->flag, sd->seq);
+            rc = check_launch(ctx, "k_raise_flag");
+        }
+        const int rc_side = side_drain(ctx, sd, sd->head.load());
+        if (rc == 0) rc = rc_side;
+        if (rc != 0) sd->masks_dirty = true;
+        if (rc == 0 && side_last >= 0 && sd->posted[side_last] && hipStreamWaitEvent(s, sd->done[side_last], 0) != hipSuccess)
+            rc = fail(ctx, ZRK_E_HIP, "hipStreamWaitEvent");
     }
     if (n_prof && !deferred) {
         if (hipStreamSynchronize(s) != hipSuccess && rc == 0) rc = fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
