@@ -116,8 +116,10 @@ struct SweepParams {
     const int32_t *lidx;        // list index of each table row (NULL: the table is in list order)
     double *pos;
     uint32_t *vis;              // indexed by LIST index
-    int32_t *cost;              // per row block: radars its waves had to walk this tick (NULL: not recorded)
     const int32_t *order;       // row block of each workgroup, expensive ones first (NULL: identity)
+    int32_t *order_next;        // the same for the next tick, built as this sweep goes (NULL: not built), see below
+    uint32_t *order_ctr;        // kOrderRegions pairs (expensive / cheap row blocks recorded so far), kOrderCtrStride words apart
+    uint32_t *order_ctr_next;   // the next tick's set, cleared here
     int64_t n, cap;
     double t;
     uint64_t seed, tick;
@@ -162,14 +164,18 @@ struct MissileArgs {
 
 // Dispatch order of the next sweep.  The sweep's duration is set by the expensive waves (rows inside some
 // sector: ten-odd radars walked one after the other, noise drawn) that start last; which row blocks are
-// expensive changes slowly from tick to tick (the sectors turn a few degrees), so each sweep leaves its
-// per-block cost behind and an extra workgroup of the compaction turns it into next tick's order: blocks
-// that cost anything first.  Purely a schedule: every block is swept exactly once whatever the order says.
-struct OrderArgs {
-    int32_t *cost;
-    int32_t *order;
-    int32_t nb, _pad;
-};
+// expensive changes slowly from tick to tick (the sectors turn a few degrees), so each sweep leaves next tick's
+// order behind as it goes: the first wave of every workgroup takes a number from one of two counters -- blocks with
+// a radar to walk count up from the front of a list, the others down from its end -- and writes its block there.
+// Four thousand atomics on two words would take 50 us (they serialise at ~12 ns each), so the list is kOrderRegions
+// interleaved lists (workgroup bid belongs to list bid % kOrderRegions, whose q-th entry is entry q * kOrderRegions +
+// bid % kOrderRegions of the whole), each with a pair of counters on cache lines of their own: expensive blocks still
+// come first, list by list.  Purely a schedule: every block is swept exactly once whatever the order says (and
+// whichever order the workgroups happened to take their numbers in).  A launch of its own for this (sorting the
+// per-block costs) took 2.7 us of every tick on the compute stream.
+constexpr int kOrderRegions = 64;
+constexpr int kOrderCtrStride = 32;                     // words between counters: 128 bytes
+constexpr int kOrderCtrSet = kOrderRegions * 2 * kOrderCtrStride;
 
 __device__ __forceinline__ double dot3(double ax, double ay, double az, double bx, double by, double bz)
 {
@@ -883,7 +889,14 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     ZRK_WAVE_PROBE(wave, 7, (long long)(walked | (__builtin_popcount(c.inside) << 8) | (__builtin_popcount(c.plane) << 16) | ((int)have << 24)));
     uint32_t mask = 0u;
     if (walked) sweep_rows<PHILOX>(P, rbp, seed, c, li, live, x, y, z, mask, wave);
-    if (P.cost && walked && (tid & 63) == 0) atomicAdd(&P.cost[blk], walked);
+    // (the number is asked for here and used at the very end: its round trip hides behind the rows' stores)
+    int next_slot = -1;
+    if (P.order_next && tid == 0) {
+        const int reg = bid % kOrderRegions, reg_n = (P.nb - reg + kOrderRegions - 1) / kOrderRegions;
+        const int k = (int)atomicAdd(P.order_ctr + (reg * 2 + (walked ? 0 : 1)) * kOrderCtrStride, 1u);
+        next_slot = (walked ? k : reg_n - 1 - k) * kOrderRegions + reg;
+    }
+    if (P.order_next && bid == 0 && tid < 2 * kOrderRegions) P.order_ctr_next[tid * kOrderCtrStride] = 0u;
     ZRK_WAVE_PROBE(wave, 2, wall_clock64());
     ZRK_WAVE_PROBE(wave, 4, (long long)__popcll(__ballot(mask != 0)));
     if (live && (PHILOX || ADVANCE)) {
@@ -892,6 +905,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     // sparse mode: the buffer is known to be all zero (the previous tick's compaction cleared it), so only
     // detections are written -- list-indexed stores are scattered when the table is spatially sorted
     if (i < P.n && (mask || !(P.flags & kSparseVis))) P.vis[(int64_t)scen * P.rows_ps + li] = mask;
+    if (P.order_next && tid == 0 && (unsigned)next_slot < (unsigned)P.nb) P.order_next[next_slot] = blk;
     ZRK_WAVE_PROBE(wave, 3, wall_clock64());
 }
 
@@ -1096,69 +1110,6 @@ constexpr int kSpinLimit = 1 << 22;
 
 // One workgroup: order[] = row blocks with cost > 0 (ascending), then the rest (ascending); cost[] cleared.
 // (Sorting by cost instead of two classes measured the same.)
-__device__ void build_order(int *s_wave, const OrderArgs &O)
-{
-    // Each thread takes kPer CONSECUTIVE row blocks (one pair of 16-byte loads), so that a single scan over the threads
-    // ranks the expensive blocks, and the cheap ones behind them, in block order.  Tables of more than kPer x blockDim
-    // row blocks take further rounds, and a counting pass first (the cheap blocks start behind ALL expensive ones).
-    constexpr int kPer = 8;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    const int per_round = kPer * (int)blockDim.x;
-    const int rounds = (O.nb + per_round - 1) / per_round;
-    int heavy_total = 0;
-    if (rounds > 1) {
-        int mine = 0;
-        for (int b = tid; b < O.nb; b += blockDim.x) mine += O.cost[b] > 0;
-        for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d);
-        if (lane == 0) s_wave[wave] = mine;
-        __syncthreads();
-        for (int w = 0; w < nw; ++w) heavy_total += s_wave[w];
-        __syncthreads();
-    }
-    int carry_h = 0, carry_l = 0;
-    for (int r = 0; r < rounds; ++r) {
-        const int b0 = r * per_round + tid * kPer;
-        int c[kPer];
-        if (b0 + kPer <= O.nb) {
-            const int4 lo = *(const int4 *)(O.cost + b0), hi = *(const int4 *)(O.cost + b0 + 4);
-            c[0] = lo.x; c[1] = lo.y; c[2] = lo.z; c[3] = lo.w; c[4] = hi.x; c[5] = hi.y; c[6] = hi.z; c[7] = hi.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < kPer; ++k) c[k] = (b0 + k < O.nb) ? O.cost[b0 + k] : 0;
-        }
-        int h = 0, l = 0;
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const bool in = b0 + k < O.nb;
-            h += in && c[k] > 0;
-            l += in && !(c[k] > 0);
-        }
-        const int v = h | (l << 16);                           // (at most kPer x 1024 of either: 14 bits)
-        int incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        int before = 0, total = 0;
-        for (int w = 0; w < nw; ++w) { if (w < wave) before += s_wave[w]; total += s_wave[w]; }
-        if (rounds == 1) heavy_total = total & 0xFFFF;
-        const int excl = before + incl - v;
-        int oh = carry_h + (excl & 0xFFFF), ol = heavy_total + carry_l + (excl >> 16);
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            if (b0 + k < O.nb) {
-                if (c[k] > 0) O.order[oh++] = b0 + k; else O.order[ol++] = b0 + k;
-                O.cost[b0 + k] = 0;
-            }
-        }
-        carry_h += total & 0xFFFF; carry_l += total >> 16;
-        __syncthreads();                                       // s_wave free again
-    }
-}
-
 __device__ __forceinline__ unsigned long long agg_load(const unsigned long long *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1426,14 +1377,13 @@ __device__ void put_radar_block(const PutArgs &U)
 __global__ __launch_bounds__(256) void k_put_radar_block(const PutArgs U) { put_radar_block(U); }
 
 __global__ __launch_bounds__(kCompBlock) void k_compact_fused(const CompactArgs C, int by_ticket, const MissileArgs M,
-                                                              const OrderArgs O, const EnsembleArgs E, const PutArgs U)
+                                                              const EnsembleArgs E, const PutArgs U)
 {
     __shared__ int s_wave[kCompBlock / 64];
     __shared__ CompactShared<kCompBlock> S;
-    if ((int)blockIdx.x >= C.nb) {                 // extra workgroups: missile events + tombstones, sweep order, radars
+    if ((int)blockIdx.x >= C.nb) {                 // extra workgroups: missile events + tombstones, radars
         int extra = (int)blockIdx.x - C.nb;
         if (M.m > 0 && extra-- == 0) { missile_finish_entry(s_wave, M); return; }
-        if (O.nb > 0 && extra-- == 0) { build_order(s_wave, O); return; }
         if (E.S > 0) { ensemble_derive(E, extra); return; }
         if (U.dst) put_radar_block(U);              // one scenario: the next tick's records, derived by the host
         return;
@@ -1441,15 +1391,12 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_fused(const CompactArgs 
     compact_block<kCompBlock>(S, C, by_ticket);
 }
 
-// Overlap mode of zrk_run_ticks: what the NEXT sweep needs of a tick's second launch -- the tombstones, the dispatch
-// order, the radar records -- as a launch of its own (a dozen workgroups) on the compute stream, while the lists and
-// the ordered events are compacted on a side stream beside the next sweep.
-__global__ __launch_bounds__(kCompBlock) void k_tick_small(const MissileArgs M, const OrderArgs O, const EnsembleArgs E,
-                                                           const PutArgs U)
+// Overlap mode of zrk_run_ticks: what the NEXT sweep needs of a tick's second launch -- the tombstones and the radar
+// records -- as a launch of its own (a dozen workgroups) on the compute stream, while the lists and the ordered events
+// are compacted on a side stream beside the next sweep.
+__global__ __launch_bounds__(kCompBlock) void k_tick_small(const MissileArgs M, const EnsembleArgs E, const PutArgs U)
 {
-    __shared__ int s_wave[kCompBlock / 64];
     int extra = (int)blockIdx.x;
-    if (O.nb > 0 && extra-- == 0) { build_order(s_wave, O); return; }
     const int kparts = (int)((M.m + kCompBlock - 1) / kCompBlock);
     if (extra < kparts) { missile_kills(M, extra); return; }
     extra -= kparts;
@@ -2046,6 +1993,7 @@ struct zrk_ctx {
     const void *order_ws = nullptr;    // workspace holding a sweep order built by the last tick of zrk_run_ticks ...
     int order_nb = 0;                  // ... for this many row blocks
     bool order_ready = false;
+    int order_phase = 0;               // which of the workspace's two order lists the next sweep reads
     bool order_enabled = true;
     int env_items = 0;                 // ZRK_COMPACT_ITEMS (0: automatic), read once: getenv per launch costs microseconds
     int env_order = -1;                // ZRK_COMPACT_ORDER: 0 "block", 1 anything else, -1 automatic
@@ -2095,7 +2043,8 @@ inline int nblocks(int64_t n, int per) { return (int)((n + per - 1) / per); }
 struct Workspace {
     int32_t *ctl;                  // single-launch compaction: ticket, done, error
     unsigned long long *agg;       // ... and its per-workgroup records
-    int32_t *cost, *order;         // per sweep row block: cost of this tick, dispatch order of the next
+    int32_t *order[2];             // per sweep row block: dispatch order, this tick's and the one being built
+    uint32_t *order_ctr;           // two sets of counters (kOrderCtrSet words each), alternating
     WaveBox *boxes;                // per sweep wave: box record
     int32_t *counts, *offs, *totals;
 };
@@ -2120,9 +2069,10 @@ Workspace carve(void *ws, int nb, int64_t n_max)
     w.totals = (int32_t *)((char *)ws + kFusedBytes);   // [ZRK_MAX_RADARS + 1] (+ pad to 64 ints)
     w.counts = w.totals + 64;
     w.offs = w.counts + (int64_t)(ZRK_MAX_RADARS + 1) * nb;
-    w.cost = w.counts + ((2 * (int64_t)(ZRK_MAX_RADARS + 1) * comp_blocks(n_max) + 63) & ~(int64_t)63);
-    w.order = w.cost + order_ints(n_max);
-    w.boxes = (WaveBox *)((char *)(w.order + order_ints(n_max)) + 2 * sizeof(RadarBlock));   // (two RadarBlocks in front)
+    w.order[0] = w.counts + ((2 * (int64_t)(ZRK_MAX_RADARS + 1) * comp_blocks(n_max) + 63) & ~(int64_t)63);
+    w.order[1] = w.order[0] + order_ints(n_max);
+    w.order_ctr = (uint32_t *)(w.order[1] + order_ints(n_max));
+    w.boxes = (WaveBox *)((char *)(w.order_ctr + 2 * kOrderCtrSet) + 2 * sizeof(RadarBlock));   // (two RadarBlocks in front)
     return w;
 }
 
@@ -2192,7 +2142,7 @@ ZRK_API int64_t zrk_workspace_bytes(int64_t n_max)
 {
     if (n_max < 0) return ZRK_E_INVALID;
     return kFusedBytes + 2 * (int64_t)sizeof(RadarBlock) +
-           (2 * order_ints(n_max) + box_ints(n_max) + 64 + 64 + 2 * (int64_t)(ZRK_MAX_RADARS + 1) * comp_blocks(n_max)) *
+           (2 * order_ints(n_max) + 2 * kOrderCtrSet + box_ints(n_max) + 64 + 64 + 2 * (int64_t)(ZRK_MAX_RADARS + 1) * comp_blocks(n_max)) *
                (int64_t)sizeof(int32_t);
 }
 
@@ -2249,9 +2199,10 @@ struct EnsLaunch {
 
 int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_t time_ms, const zrk_radar *radars,
                  int R, uint32_t flags, uint64_t seed, uint64_t tick, int64_t gid0, void *workspace, void *stream,
-                 const MissileArgs &M, uint32_t *vis = nullptr, int32_t *cost = nullptr, const int32_t *order = nullptr,
+                 const MissileArgs &M, uint32_t *vis = nullptr, int32_t *order_next = nullptr, const int32_t *order = nullptr,
                  WaveBox *boxes = nullptr, const EnsLaunch *ens = nullptr, const RadarBlock *rb_device = nullptr,
-                 uint32_t *flag = nullptr, uint32_t flag_value = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
+                 uint32_t *flag = nullptr, uint32_t flag_value = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                 uint32_t *order_ctr = nullptr, uint32_t *order_ctr_next = nullptr)
 {
     if (!ctx || !e || !workspace || (R > 0 && !radars && !ens && !rb_device)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
     if (R < 0 || R > ZRK_MAX_RADARS)
@@ -2261,7 +2212,7 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
     SweepParams P;
     P.sp = e->start_pos; P.vel = e->velocity; P.t0 = e->start_time; P.alive = e->alive; P.lidx = e->list_index;
     P.pos = e->pos[cur]; P.vis = vis ? vis : e->vis_mask;
-    P.cost = cost; P.order = order;
+    P.order = order; P.order_next = order_next; P.order_ctr = order_ctr; P.order_ctr_next = order_ctr_next;
     P.n = n; P.cap = e->capacity;
     P.t = (double)time_ms / 1000.0;                 // to_seconds, modules/AirObject.py:5-7
     P.seed = seed; P.tick = tick; P.gid0 = gid0;
@@ -2320,7 +2271,7 @@ bool compacts_in_one_launch(const zrk_ctx *ctx, int64_t n)
 
 int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int32_t base_index, void *workspace,
                    int32_t *det_idx, int64_t det_stride, int32_t *det_cnt, int64_t *packed, int64_t packed_capacity,
-                   int64_t gid0, void *stream, const MissileArgs &M, uint32_t *zero_next, const OrderArgs &O,
+                   int64_t gid0, void *stream, const MissileArgs &M, uint32_t *zero_next,
                    bool union_bits = false, const EnsLaunch *ens = nullptr, const PutArgs *put = nullptr,
                    SideItem *defer = nullptr)
 {
@@ -2377,13 +2328,16 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         std::memset(&E, 0, sizeof(E));
         if (ens) E = ens->next;
         if (defer) {                                 // overlap mode: the side stream's thread launches it (lists only)
-            defer->C = C; defer->by_ticket = by_ticket;
+            // Beside other kernels its workgroups are placed as room appears, in dispatch order only within each XCD:
+            // waiting in blockIdx order could then wait for a workgroup that has no compute unit yet while holding one
+            // that another waiting kernel needs.  Tickets (a workgroup's place is taken when it starts to run) cannot.
+            defer->C = C; defer->by_ticket = ctx->env_order >= 0 ? ctx->env_order : 1;
             return 0;
         }
         const int eparts = ens ? nblocks((int64_t)E.S * E.R, kCompBlock) : ((put && put->dst) ? 1 : 0);
         static PutArgs no_put;                       // (zero-initialised: dst == NULL)
-        hipLaunchKernelGGL(k_compact_fused, dim3((int)nbf + (M.m > 0 ? 1 : 0) + (O.nb > 0 ? 1 : 0) + eparts), dim3(kCompBlock), 0, s,
-                           C, by_ticket, M, O, E, (put && !ens) ? *put : no_put);
+        hipLaunchKernelGGL(k_compact_fused, dim3((int)nbf + (M.m > 0 ? 1 : 0) + eparts), dim3(kCompBlock), 0, s,
+                           C, by_ticket, M, E, (put && !ens) ? *put : no_put);
         return check_launch(ctx, "k_compact_fused");
     }
     if (defer) return fail(ctx, ZRK_E_INVALID, "zrk_compact: overlap mode needs the single-launch compaction");
@@ -2404,7 +2358,7 @@ ZRK_API int zrk_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R
                         int64_t packed_capacity, int64_t gid0, void *stream)
 {
     return launch_compact(ctx, vis_mask, n, R, base_index, workspace, det_idx, det_stride, det_cnt, packed, packed_capacity,
-                          gid0, stream, no_missiles(), nullptr, OrderArgs{nullptr, nullptr, 0, 0});
+                          gid0, stream, no_missiles(), nullptr);
 }
 
 ZRK_API int zrk_compact_bits(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int32_t base_index,
@@ -2412,7 +2366,7 @@ ZRK_API int zrk_compact_bits(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, 
                              int64_t union_words, void *stream)
 {
     return launch_compact(ctx, vis_mask, n, R, base_index, workspace, det_idx, det_stride, det_cnt, union_bits, union_words,
-                          0, stream, no_missiles(), nullptr, OrderArgs{nullptr, nullptr, 0, 0}, true);
+                          0, stream, no_missiles(), nullptr, true);
 }
 
 ZRK_API int64_t zrk_union_bits_words(int64_t n, int R, int64_t entries)
@@ -2893,9 +2847,12 @@ int side_issue(Side *sd, const SideItem &it)
     static PutArgs no_put;                               // (zero-initialised: dst == NULL)
     EnsembleArgs no_ens;
     std::memset(&no_ens, 0, sizeof(no_ens));
+    // (one lane waits in a launch of its own: letting the compaction's workgroups wait themselves -- resident ahead of
+    // their input -- saves the side stream 6 us a tick and deadlocks the device as soon as anything else on it needs
+    // whole compute units in dispatch order, e.g. another engine's single-launch compaction)
     hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, it.stream, sd->flag, it.flag_value, sd->flag + 2);
     hipLaunchKernelGGL(k_compact_fused, dim3(it.C.nb + (it.M.m > 0 ? 1 : 0)), dim3(kCompBlock), 0, it.stream, it.C, it.by_ticket, it.M,
-                       OrderArgs{nullptr, nullptr, 0, 0}, no_ens, no_put);
+                       no_ens, no_put);
     if (hipGetLastError() != hipSuccess) { sd->err = "side stream: compaction launch failed"; return ZRK_E_HIP; }
     if (it.x) {
         const int rc = it.x->api.AllGather(it.send, it.recv, (size_t)it.words, kNcclInt64, it.x->comm, it.stream);
@@ -2928,8 +2885,11 @@ void side_main(Side *sd, int device)
         if (std::chrono::steady_clock::now() - idle_since < std::chrono::milliseconds(50)) { __builtin_ia32_pause(); continue; }
         std::unique_lock<std::mutex> lk(sd->mu);
         sd->asleep.store(true);
-        if (sd->head.load(std::memory_order_acquire) == sd->tail.load() && !sd->stop.load()) sd->cv.wait_for(lk, std::chrono::milliseconds(1));
+        bool woken = false;
+        if (sd->head.load(std::memory_order_acquire) == sd->tail.load() && !sd->stop.load())
+            woken = sd->cv.wait_for(lk, std::chrono::milliseconds(1)) == std::cv_status::no_timeout;
         sd->asleep.store(false);
+        if (woken) idle_since = std::chrono::steady_clock::now();      // somebody is about to hand over work: stay up
     }
 }
 
@@ -3103,6 +3063,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         sd = side_of(ctx);
         if (!sd) return fail(ctx, ZRK_E_HIP, "zrk_run_ticks: the side stream could not be created");
         if (xio && exchange_drain(xio->x, xio->x->head.load()) != 0) return fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
+        // (its thread sleeps after 50 ms without work: wake it now, not at the first item two launches from here)
+        if (sd->asleep.load()) { std::lock_guard<std::mutex> lk(sd->mu); sd->cv.notify_one(); }
         if (sd->mask_rows < e->capacity || sd->masks_dirty) {
             if (int rc0 = side_drain(ctx, sd, sd->head.load())) return rc0;
             if (hipStreamSynchronize(sd->stream) != hipSuccess || (xio && hipStreamSynchronize(xio->x->cstream) != hipSuccess))
@@ -3190,11 +3152,10 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         }
         if (sd && (rc = side_wait(ctx, sd, side_slot)) != 0) break;
         if (sd && side_slot < Side::kMasks && M.m > 0) M.ev_code = sd->codes[side_slot];
-        // next tick's dispatch order: built by this tick's compaction from the costs this tick's sweep records
+        // next tick's dispatch order: this tick's sweep builds it as it goes
         const int nbs = nblocks(st->n, ZRK_BLOCK);
         // (a grid that is resident all at once has no "last": eight workgroups of four waves fit a compute unit)
-        const bool ordering = ctx->order_enabled && (det_idx || list) && R > 0 && nbs > 8 * ctx->cus &&
-                              (ens || compacts_in_one_launch(ctx, st->n));
+        const bool ordering = ctx->order_enabled && R > 0 && nbs > 8 * ctx->cus;
         if (ens) {
             EL.rb_table = (const char *)ens_tables[st->tick & 1u];
             EL.next.table_out = ens_tables[(st->tick + 1) & 1u];
@@ -3209,17 +3170,20 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             if (hipMemsetAsync(w.boxes + w0, 0, sizeof(WaveBox) * (size_t)(w1 - w0), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset boxes"); break; }
             ctx->box_n = st->n;
         }
-        if (ordering && (ctx->order_ws != workspace || ctx->order_nb != nbs)) {
-            if (hipMemsetAsync(w.cost, 0, sizeof(int32_t) * (size_t)nbs, s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset cost"); break; }
-            ctx->order_ws = workspace; ctx->order_nb = nbs; ctx->order_ready = false;
+        if (ordering && (ctx->order_ws != workspace || ctx->order_nb != nbs || !ctx->order_ready)) {
+            if (hipMemsetAsync(w.order_ctr, 0, 2 * kOrderCtrSet * sizeof(uint32_t), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset order counters"); break; }
+            ctx->order_ws = workspace; ctx->order_nb = nbs; ctx->order_ready = false; ctx->order_phase = 0;
         }
         if (!ordering) ctx->order_ready = false;
+        const int oph = ctx->order_phase;                                    // reads list oph, builds list oph ^ 1
         rc = launch_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse, st->seed,
-                          st->tick, st->gid0, workspace, stream, M, vis_now, ordering ? w.cost : nullptr,
-                          (ordering && ctx->order_ready) ? w.order : nullptr, w.boxes, ens ? &EL : nullptr,
+                          st->tick, st->gid0, workspace, stream, M, vis_now, ordering ? w.order[oph ^ 1] : nullptr,
+                          (ordering && ctx->order_ready) ? w.order[oph] : nullptr, w.boxes, ens ? &EL : nullptr,
                           rb_through_memory ? rb_dev[st->tick & 1u] : nullptr,
                           pend.on ? fx->flag : ((sd && k > 0) ? sd->flag : nullptr), pend.on ? pend.value : (sd ? sd->seq : 0u),
-                          on_dispatch ? ev[2 * (k / stride)] : nullptr, on_dispatch ? ev[2 * (k / stride) + 1] : nullptr);
+                          on_dispatch ? ev[2 * (k / stride)] : nullptr, on_dispatch ? ev[2 * (k / stride) + 1] : nullptr,
+                          w.order_ctr + kOrderCtrSet * (oph ^ 1), w.order_ctr + kOrderCtrSet * oph);
+        if (rc == 0 && ordering) { ctx->order_ready = true; ctx->order_phase = oph ^ 1; }
         if (pend.on) {                                                       // the previous tick's collective, behind this sweep's start
             if (rc == 0 && !(st->n > 0 || M.m > 0)) {                        // (no sweep was launched: raise the flag by itself)
                 hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, s, fx->flag, pend.value);
@@ -3244,21 +3208,19 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             EnsembleArgs E0;
             std::memset(&E0, 0, sizeof(E0));
             static PutArgs no_put;
-            const OrderArgs O = ordering ? OrderArgs{w.cost, w.order, nbs, 0} : OrderArgs{nullptr, nullptr, 0, 0};
             const int eparts = ens ? nblocks((int64_t)EL.next.S * EL.next.R, kCompBlock) : (rb_through_memory ? 1 : 0);
-            const int small_grid = std::max(1, nblocks(M.m, kCompBlock) + (O.nb > 0 ? 1 : 0) + eparts);
+            const int small_grid = std::max(1, nblocks(M.m, kCompBlock) + eparts);
             SideItem it;
             std::memset((void *)&it, 0, sizeof(it));
             // (the single-launch workspace's first-use clearing, if any, goes to the compute stream, ahead of the flag)
             rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, list, list_words,
-                                st->gid0, stream, no_missiles(), (side_slot < Side::kMasks) ? vis_now : nullptr, OrderArgs{nullptr, nullptr, 0, 0},
+                                st->gid0, stream, no_missiles(), (side_slot < Side::kMasks) ? vis_now : nullptr,
                                 (st->flags & ZRK_F_UNION_BITS) != 0, ens ? &EL : nullptr, nullptr, &it);
             if (rc != 0) break;
             const uint32_t v = ++sd->seq;
-            hipLaunchKernelGGL(k_tick_small, dim3(small_grid), dim3(kCompBlock), 0, s, M, O, ens ? EL.next : E0,
+            hipLaunchKernelGGL(k_tick_small, dim3(small_grid), dim3(kCompBlock), 0, s, M, ens ? EL.next : E0,
                                (rb_through_memory && !ens) ? put : no_put);
             if ((rc = check_launch(ctx, "k_tick_small")) != 0) break;
-            if (ordering) ctx->order_ready = true;
             if (ev_words && !fused && hipMemsetAsync(list + list_words, 0, sizeof(int64_t), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset events"); break; }
             it.stream = side_stream; it.flag_value = v; it.done_slot = side_slot;
             it.M = M; it.M.apply = 0;
@@ -3276,9 +3238,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (rc == 0 && (det_idx || list))
             rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, list,
                                 list_words, st->gid0, stream, M, vis_next,
-                                ordering ? OrderArgs{w.cost, w.order, nbs, 0} : OrderArgs{nullptr, nullptr, 0, 0},
                                 (st->flags & ZRK_F_UNION_BITS) != 0, ens ? &EL : nullptr, rb_through_memory ? &put : nullptr);
-        if (rc == 0 && ordering) ctx->order_ready = true;
         if (rc == 0 && m > 0 && !fused) rc = zrk_missile_step(ctx, e, st->cur, mis, m, st->time_ms, st->dt_ms, 1, stream);
         if (rc == 0 && ev_words && !fused) {
             if (m > 0) {
