@@ -26,12 +26,18 @@ than ranks (the exchange then goes through torch.distributed from Python, tick b
 `--gpus N` without a torch.distributed environment starts the N ranks itself (children of this process, spawned
 before anything here touches the GPU) and relays rank 0's line; under torch.distributed.run it must equal WORLD_SIZE.
 
+The timed steps go through ONE zrk_run_ticks call, which (for calls of four ticks or more, ZRK_OVERLAP=0 turns it off)
+compacts tick t's lists on a side stream beside tick t+1's sweep (`config.loop`); the kernels and their results are
+the two-launch loop's (tests/test_gpu_overlap.py).
+
 Prints ONE JSON line (rank 0).  `roofline` is the fused advance+sweep kernel: algorithmic bytes per launch (85 B per
-live entity, 1 B per tombstone) over its average duration, measured with HIP events on the launch stream inside the
-timed region (the pair also brackets the dispatch gap in front of the kernel, ~3 us more than rocprofv3 reports for
-the kernel alone; the rocprofv3 figure of the same command is kept under profiles/ and echoed as
-`profiled_kernel_us_recorded`).  `traffic_recorded` is the PMC figure of the committed counter passes -- counters
-cannot be read from inside this process.  `cpu_baseline` is the oracle (C restatement of the reference, oracle/) timed
+live entity, 1 B per tombstone) over its average duration, measured with HIP events inside the timed region on the
+stream the kernel is launched on (the pair rides on the dispatch -- hipExtLaunchKernel -- and reads the kernel's own
+begin and end stamps; every 4th sweep of a short run is timed, every 8th of a long one, because a timed launch costs
+the stream ~4 us).  In the overlapped loop the sweep shares the device with the previous tick's compaction and is
+~2 us slower than alone; the rocprofv3 figures of the same command are kept under profiles/ and echoed as
+`profiled_kernel_us_recorded` (this loop) and `profiled_kernel_us_alone_recorded` (ZRK_OVERLAP=0).  `traffic_recorded`
+is the PMC figure of the committed counter passes -- counters cannot be read from inside this process.  `cpu_baseline` is the oracle (C restatement of the reference, oracle/) timed
 on this host on a bounded number of ticks of the same scene.  Before the warm-up steps the device runs ~100 ms of an
 unrelated self-test kernel so that a 20-step run is not measured while the clocks are still ramping
 (`setup.clock_spinup_ms`; none of it counts as a step).
@@ -491,6 +497,10 @@ def main():
                                               else "through torch.distributed (rehearsal backend)"))
         else:
             what += "per-radar compaction"
+        one_call = (not exchanging) or state["c_side"]
+        overlapped = one_call and os.environ.get("ZRK_OVERLAP", "1") != "0" and args.steps >= int(os.environ.get("ZRK_OVERLAP_MIN", "4"))
+        loop_mode = ("overlapped: tick t's compaction on a side stream beside tick t+1's sweep" if overlapped
+                     else "two launches per tick on one stream")
         out = {
             "metric": "entity-timesteps/sec (targets+missiles)", "value": total_units / elapsed,
             "unit": "entity-timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -498,13 +508,15 @@ def main():
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": what, "entities_per_gpu": n_slots, "live_per_gpu": int(live1),
-                       "parallelism": f"shard{world}" if not ensemble else f"replicas{world}"},
+                       "parallelism": f"shard{world}" if not ensemble else f"replicas{world}",
+                       "loop": loop_mode},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "traffic_recorded": recorded(f"traffic_bytes_{args.workload}") if world == 1 else None,
                          "kernel": "k_tick_sweep", "avg_kernel_us": sweep_avg_ms * 1e3, "samples": int(len(good)),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "profiled_kernel_us_recorded": recorded(f"sweep_us_{args.workload}") if world == 1 else None,
+                         "profiled_kernel_us_alone_recorded": recorded(f"sweep_us_{args.workload}_plain_loop") if world == 1 else None,
                          "recorded_from": f"profiles/{PROFILE_TAG}_recorded.json (rocprofv3 passes of this command, committed)"},
             "setup": {"clock_spinup_ms": SPINUP_MS},
         }

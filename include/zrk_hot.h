@@ -289,8 +289,22 @@ typedef struct {
  * stores are scattered when the table is spatially sorted, so the zeros are not worth writing) into the
  * buffer the previous tick's compaction cleared; st->vis_cur says which buffer is current afterwards.
  * From the second tick on the two buffers belong to this loop, also between calls: do not write them.  If sweep_ms != NULL the sweep kernel of every
- * prof_stride-th tick is bracketed by HIP events on `stream`, the stream is synchronised at the
- * end and sweep_ms[k / prof_stride] receives the kernel's duration in milliseconds.
+ * prof_stride-th tick is timed with a pair of HIP events riding on its dispatch, the stream is synchronised at the
+ * end and sweep_ms[k / prof_stride] receives the kernel's duration in milliseconds (prof_stride < 0: the events are
+ * only recorded, zrk_read_sweep_ms reads them later).
+ *
+ * Calls of four ticks or more with compaction, a second mask buffer and a missile table the single-workgroup
+ * finisher covers run OVERLAPPED: the lists and the ordered event list of tick t are compacted on a side stream of the
+ * context beside the sweep of tick t + 1 (issued by a thread of the context's own, so that the caller's thread is left
+ * with two launches per tick); what the next sweep needs -- tombstones, radar records -- stays on `stream` as a small
+ * launch.  Same kernels, same results; `stream` takes the side stream in before the call returns, so the outputs
+ * are the caller's as before.  Differences a caller can see: the masks of all ticks but the LAST of such a call live
+ * in buffers of the context (ents->vis_mask / vis_mask_alt hold the last tick's, as st->vis_cur says), likewise
+ * mis->ev_code; the dispatch order of a sweep's workgroups is never the same twice (it does not enter any result).
+ * Environment (read at zrk_ctx_create / zrk_ctx_reload_env): ZRK_OVERLAP=0 never overlap; ZRK_OVERLAP_MIN=k from k
+ * ticks per call; ZRK_SWEEP_ORDER=0 sweep in table order; ZRK_COMPACT_ORDER=block|ticket; ZRK_TIME_BY_RECORDS=1 time
+ * between two recorded events.  A wait on the side stream that runs out (the compute stream stalled for seconds) is
+ * reported by zrk_compact_status.
  */
 int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *ents, const zrk_missiles *mis, int64_t m, zrk_loop *st,
                   zrk_radar *radars /* HOST, in/out */, const zrk_scan *scan /* HOST */, int R, void *workspace,
@@ -320,7 +334,14 @@ const char *zrk_exchange_last_error(zrk_exchange *x);
  * behind everything `stream` holds so far; two slots (0 / 1) may be in flight. */
 int zrk_exchange_all_gather(zrk_exchange *x, int slot, const int64_t *send /* DEVICE */, int64_t *recv /* DEVICE */,
                             int64_t words, void *stream);
-/* Make `stream` wait for the last all-gather posted on `slot` (nothing if none was). */
+/* The last all-gather posted on `slot` is over before anything launched on `stream` after this call runs (nothing if
+ * none was posted).  By default the HOST waits for it (the collective is two ticks old, and a wait in the stream costs
+ * the stream ~5 us of idle device per tick); ZRK_EXCHANGE_WAIT_IN_STREAM=1 at zrk_exchange_create makes it a stream
+ * wait.  Inside zrk_run_ticks_x the hand-over to the exchange's stream needs no event either: the next tick's sweep
+ * raises a word of device memory as it starts, a one-lane kernel on the exchange's stream waits for it, and the
+ * collective is issued by a thread of the exchange's own (ZRK_EXCHANGE_EVENTS=1: events instead;
+ * ZRK_EXCHANGE_THREAD=0: issued by the calling thread).  In the overlapped loop (see zrk_run_ticks) compaction and
+ * collective share the exchange's stream. */
 int zrk_exchange_wait(zrk_exchange *x, int slot, void *stream);
 /* Block the host until the exchange's stream is idle. */
 int zrk_exchange_sync(zrk_exchange *x);

@@ -10,12 +10,15 @@ B="python3 $R/bench.py"
 echo "== plain bench lines"
 $B --steps 1000 --warmup 50 > $out/bench_c3.json 2> $out/bench_c3.err
 $B --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_c3_20steps.json 2>> $out/bench_c3.err
+ZRK_OVERLAP=0 $B --steps 1000 --warmup 50 --no-cpu-baseline > $out/bench_c3_plain_loop.json 2>> $out/bench_c3.err
+ZRK_BENCH_FORCE_EXCHANGE=1 $B --steps 1000 --warmup 50 --no-cpu-baseline > $out/bench_c3_exchange_one_rank.json 2>> $out/bench_c3.err
 $B --workload C2 --steps 2000 --warmup 100 --no-cpu-baseline > $out/bench_c2.json 2>> $out/bench_c3.err
 $B --workload C5 --steps 500 --warmup 50 --cpu-budget 5 > $out/bench_c5.json 2>> $out/bench_c3.err
 $B --workload C3x4 --steps 200 --warmup 30 --no-cpu-baseline > $out/bench_c3x4.json 2>> $out/bench_c3.err
 $B --workload C4 --steps 100 --warmup 30 --no-cpu-baseline > $out/bench_c4_1gpu.json 2>> $out/bench_c3.err
 echo "== kernel stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c3 -- $B --steps 300 --warmup 50 --no-cpu-baseline > $out/stats_c3.json 2> $out/stats_c3.err
+( export ZRK_OVERLAP=0; rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c3_plain -- $B --steps 300 --warmup 50 --no-cpu-baseline > $out/stats_c3_plain.json 2> $out/stats_c3_plain.err )
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c3x4 -- $B --workload C3x4 --steps 100 --warmup 30 --no-cpu-baseline > $out/stats_c3x4.json 2> $out/stats_c3x4.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c5 -- $B --workload C5 --steps 200 --warmup 30 --no-cpu-baseline > $out/stats_c5.json 2> $out/stats_c5.err
 echo "== traffic counters"

@@ -36,7 +36,7 @@ def line(name):
     return json.loads(txt[-1]) if txt else None
 
 
-for wl, stats in (("C3", "stats_c3"), ("C3x4", "stats_c3x4"), ("C5", "stats_c5")):
+for wl, stats in (("C3", "stats_c3"), ("C3_plain_loop", "stats_c3_plain"), ("C3x4", "stats_c3x4"), ("C5", "stats_c5")):
     us = kernel_stats(stats, f"{tag}_{wl.lower()}_kernel_stats.csv")
     if us:
         recorded[f"sweep_us_{wl}"] = us
@@ -73,7 +73,7 @@ for wl in ("C3", "C3x4"):
            "FETCH_SIZE x 1024 x 1.998 (gfx950 reports half the bytes of a coalesced stream; calibrated on a pure-streaming "
            "launch with this kernel's 8-byte-per-lane loads), WRITE_SIZE x 1024 x 1.000"), indent=1) + "\n")
 
-for name in ("bench_c3", "bench_c3_20steps", "bench_c2", "bench_c5", "bench_c3x4", "bench_c4_1gpu"):
+for name in ("bench_c3", "bench_c3_20steps", "bench_c3_plain_loop", "bench_c3_exchange_one_rank", "bench_c2", "bench_c5", "bench_c3x4", "bench_c4_1gpu"):
     rec = line(name)
     if rec:
         (dst / f"{tag}_{name}.json").write_text(json.dumps(rec, indent=1) + "\n")
