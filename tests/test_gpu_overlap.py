@@ -37,6 +37,7 @@ def _same(a, b, what):
                          ids=["mid", "mid-no-noise", "small-no-missiles", "multi-round-grid"])
 def test_overlapped_loop_leaves_what_the_tick_by_tick_loop_leaves(n, R, m, noise, monkeypatch):
     from tests.test_gpu_engine import _engine
+    monkeypatch.setenv("ZRK_OVERLAP_MIN_ROWS", "0")           # (by default only tables of 4e5 rows or more overlap)
     monkeypatch.setenv("ZRK_OVERLAP", "0")
     ref, _, launched = _engine(n, R, m, seed=21, noise=noise)
     monkeypatch.setenv("ZRK_OVERLAP", "1")
@@ -55,12 +56,13 @@ def test_overlapped_loop_leaves_what_the_tick_by_tick_loop_leaves(n, R, m, noise
 
 
 def test_overlap_with_the_exchange_on_one_rank(monkeypatch):
-    """The same with the list going through the C-side all-gather (one rank): compaction, events tail and the collective
-    share the side stream; the merged list and the events of the second last and the last tick of a call are the plain
-    loop's."""
+    """The same with the list going through the C-side all-gather (one rank): the compaction (with the events tail) on the
+    side stream, the collective on the exchange's own, released by the side stream's next launch; the merged list and
+    the events of the second last and the last tick of a call are the plain loop's."""
     from tests.test_gpu_engine import _engine
     from zrk_modulation_amd.exchange import RcclExchange, union_bits_words
     n, R, m = 30_000, 6, 400
+    monkeypatch.setenv("ZRK_OVERLAP_MIN_ROWS", "0")
     monkeypatch.setenv("ZRK_OVERLAP", "0")
     ref, _, _ = _engine(n, R, m, seed=11, noise="philox")
     monkeypatch.setenv("ZRK_OVERLAP", "1")

@@ -27,6 +27,10 @@ for w in C3 C3x4; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/traffic_${w}_$c -- $B --workload $w --steps 40 --warmup 20 --no-cpu-baseline > $out/traffic_${w}_$c.log 2>&1
   done
 done
+# what the missile phase (riding in the sweep's grid: ten thousand rows of scattered gathers) adds to the sweep's traffic
+for c in FETCH_SIZE WRITE_SIZE; do
+  ( export PROF_M=0 PROF_TICKS=60; rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/traffic_nomis_$c -- python3 $R/tools/prof_run.py > $out/traffic_nomis_$c.log 2>&1 )
+done
 echo "== SQ counters"
 bash $R/tools/pmc_sq.sh $tag/sq > $out/sq_summary.txt 2>&1
 echo "== host time of the exchange paths, per-wave timeline"

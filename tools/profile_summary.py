@@ -67,6 +67,19 @@ for wl in ("C3", "C3x4"):
                            write_size_kb=vals["WRITE_SIZE"][0], read_bytes=rd, write_bytes=wr, traffic_bytes=rd + wr,
                            algorithmic_bytes=alg, traffic_over_algorithmic=(rd + wr) / alg if alg else None)
         recorded[f"traffic_bytes_{wl}"] = rd + wr
+# the same scene without missiles (tools/prof_run.py, PROF_M=0): what the missile phase's gathers add
+vals = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(str(src / f"traffic_nomis_{c}" / "*" / "*counter_collection.csv"))
+    if f:
+        rows = [r for r in csv.DictReader(open(f[0])) if "k_tick_sweep" in r["Kernel_Name"] and r["Counter_Name"] == c][25:]
+        vals[c] = sum(float(r["Counter_Value"]) for r in rows) / max(len(rows), 1)
+if len(vals) == 2:
+    rd, wr = vals["FETCH_SIZE"] * 1024 * cal["read_factor"], vals["WRITE_SIZE"] * 1024 * cal["write_factor"]
+    alg = 85.0 * 1_000_000
+    traffic["C3_without_missiles"] = dict(read_bytes=rd, write_bytes=wr, traffic_bytes=rd + wr, algorithmic_bytes=alg,
+                                          traffic_over_algorithmic=(rd + wr) / alg,
+                                          note="tools/prof_run.py with PROF_M=0: 1e6 rows, 16 radars, no missile rows and no missile phase")
 (dst / f"{tag}_pmc_traffic.json").write_text(json.dumps(dict(
     kernel="k_tick_sweep<true, true, true>", calibration=cal, workloads=traffic,
     method="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of bench.py (MI355X_MICROARCH.md HBM section): "

@@ -1946,11 +1946,11 @@ struct SideItem {
     CompactArgs C;
     int by_ticket;
     MissileArgs M;                  // apply == 0: the ordered event list only (and the events in the list's tail)
-    zrk_exchange *x;                // non-NULL: all-gather the list behind the compaction ...
-    int xslot;
-    const int64_t *send;
-    int64_t *recv;
-    int64_t words;
+    // an exchange's collective runs on the exchange's own stream and waits for *raise >= raise_value, which the NEXT
+    // launch on the side stream writes as it starts (this compaction and everything before it is over then)
+    uint32_t *raise;
+    uint32_t raise_value;
+    int flush;                      // 1: no tick, only the pending raise (behind the last tick of a call)
     int done_slot;                  // done[done_slot] is recorded last
 };
 
@@ -1973,6 +1973,8 @@ struct Side {
     hipEvent_t done[kMasks + 1] = {nullptr, nullptr, nullptr, nullptr};
     bool posted[kMasks + 1] = {false, false, false, false};
     uint64_t item_no[kMasks + 1] = {0, 0, 0, 0};
+    uint32_t *pend_raise = nullptr; // (the thread's own: what the next launch on the side stream has to raise)
+    uint32_t pend_raise_value = 0;
     static constexpr uint64_t kRing = 8;
     SideItem ring[kRing];
     std::atomic<uint64_t> head{0}, tail{0};
@@ -2021,6 +2023,7 @@ struct zrk_ctx {
     Side *side = nullptr;              // overlap mode, created on first use
     int overlap = 1;                   // ZRK_OVERLAP: 0 never, 1 (default) for calls of at least overlap_min ticks
     int overlap_min = 4;
+    int64_t overlap_min_rows = 400000; // ZRK_OVERLAP_MIN_ROWS: below, the compaction is too short for the third launch to pay
 };
 
 namespace {
@@ -2101,6 +2104,7 @@ ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
     { const char *v = std::getenv("ZRK_TIME_BY_RECORDS"); c->time_on_dispatch = !(v && v[0] == '1'); }
     { const char *v = std::getenv("ZRK_OVERLAP"); c->overlap = v ? std::atoi(v) : 1; }
     { const char *v = std::getenv("ZRK_OVERLAP_MIN"); c->overlap_min = v ? std::max(2, std::atoi(v)) : 4; }
+    { const char *v = std::getenv("ZRK_OVERLAP_MIN_ROWS"); c->overlap_min_rows = v ? std::atoll(v) : 400000; }
     if (const char *v = std::getenv("ZRK_COMPACT_ITEMS")) c->env_items = std::max(1, std::atoi(v));
     if (const char *v = std::getenv("ZRK_COMPACT_ORDER")) c->env_order = std::strcmp(v, "block") != 0;
     c->fused_max_blocks = kFusedMaxBlocks;
@@ -2775,8 +2779,11 @@ __global__ void k_raise_flag(uint32_t *flag, uint32_t value)
 
 // One lane waits for the word to reach `value` (sleeping between looks); gives up after a few seconds and says so
 // (zrk_exchange_sync reports it) rather than hold the device for ever.
-__global__ void k_wait_flag(const uint32_t *flag, uint32_t value, uint32_t *gave_up)
+__global__ void k_wait_flag(const uint32_t *flag, uint32_t value, uint32_t *gave_up, uint32_t *raise = nullptr,
+                            uint32_t raise_value = 0)
 {
+    // (running at all means everything before it on its stream is over: say so first, if somebody waits for that)
+    if (raise) __hip_atomic_store(raise, raise_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int spins = 0; spins < (1 << 20); ++spins) {
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= value) return;
         __builtin_amdgcn_s_sleep(32);
@@ -2790,7 +2797,7 @@ int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, in
 {
     // (a wait kernel of our own on a word of device memory: hipStreamWaitValue32 on signal memory does the same
     // job but cost the compute stream 3.5 us a tick in the measurement, this costs it nothing measurable)
-    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, x->cstream, x->flag, value, x->flag + 1);
+    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, x->cstream, x->flag, value, x->flag + 1, (uint32_t *)nullptr, 0u);
     if (hipGetLastError() != hipSuccess) { x->err = "k_wait_flag launch failed"; return ZRK_E_HIP; }
     const int rc = x->api.AllGather(send, recv, (size_t)words, kNcclInt64, x->comm, x->cstream);
     if (rc != 0) { x->err = std::string("ncclAllGather: ") + (x->api.GetErrorString ? x->api.GetErrorString(rc) : "error"); return ZRK_E_HIP; }
@@ -2847,22 +2854,21 @@ int side_issue(Side *sd, const SideItem &it)
     static PutArgs no_put;                               // (zero-initialised: dst == NULL)
     EnsembleArgs no_ens;
     std::memset(&no_ens, 0, sizeof(no_ens));
+    if (it.flush) {
+        if (sd->pend_raise) hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, it.stream, sd->pend_raise, sd->pend_raise_value);
+        sd->pend_raise = nullptr;
+        if (hipGetLastError() != hipSuccess) { sd->err = "side stream: launch failed"; return ZRK_E_HIP; }
+        return 0;
+    }
     // (one lane waits in a launch of its own: letting the compaction's workgroups wait themselves -- resident ahead of
     // their input -- saves the side stream 6 us a tick and deadlocks the device as soon as anything else on it needs
     // whole compute units in dispatch order, e.g. another engine's single-launch compaction)
-    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, it.stream, sd->flag, it.flag_value, sd->flag + 2);
+    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, it.stream, sd->flag, it.flag_value, sd->flag + 2, sd->pend_raise,
+                       sd->pend_raise_value);
+    sd->pend_raise = it.raise; sd->pend_raise_value = it.raise_value;
     hipLaunchKernelGGL(k_compact_fused, dim3(it.C.nb + (it.M.m > 0 ? 1 : 0)), dim3(kCompBlock), 0, it.stream, it.C, it.by_ticket, it.M,
                        no_ens, no_put);
     if (hipGetLastError() != hipSuccess) { sd->err = "side stream: compaction launch failed"; return ZRK_E_HIP; }
-    if (it.x) {
-        const int rc = it.x->api.AllGather(it.send, it.recv, (size_t)it.words, kNcclInt64, it.x->comm, it.stream);
-        if (rc != 0) {
-            sd->err = std::string("ncclAllGather: ") + (it.x->api.GetErrorString ? it.x->api.GetErrorString(rc) : "error");
-            return ZRK_E_HIP;
-        }
-        if (hipEventRecord(it.x->done[it.xslot], it.stream) != hipSuccess) { sd->err = "side stream: hipEventRecord failed"; return ZRK_E_HIP; }
-        it.x->posted[it.xslot] = true;
-    }
     if (hipEventRecord(sd->done[it.done_slot], it.stream) != hipSuccess) { sd->err = "side stream: hipEventRecord failed"; return ZRK_E_HIP; }
     sd->posted[it.done_slot] = true;
     return 0;
@@ -2919,7 +2925,7 @@ void side_enqueue(Side *sd, const SideItem &it)
     while (h - sd->tail.load(std::memory_order_acquire) >= Side::kRing) __builtin_ia32_pause();
     sd->ring[h % Side::kRing] = it;
     sd->head.store(h + 1, std::memory_order_release);
-    sd->item_no[it.done_slot] = h + 1;
+    if (!it.flush) sd->item_no[it.done_slot] = h + 1;
     if (sd->asleep.load()) { std::lock_guard<std::mutex> lk(sd->mu); sd->cv.notify_one(); }
 }
 
@@ -3058,8 +3064,9 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     // needs of the tick's second launch (tombstones, events, dispatch order, radar records) stays on the compute stream
     // as k_tick_small.  For calls of a few ticks at least: the last tick's compaction has nothing to run beside.
     Side *sd = nullptr;
-    if (ctx->overlap > 0 && K >= ctx->overlap_min && (det_idx || packed || xio) && st->n > 0 && R > 0 && e->vis_mask_alt &&
-        (ens || rb_through_memory) && (m == 0 || m <= 1024 * (int64_t)kMissileItems)) {
+    if (ctx->overlap > 0 && K >= ctx->overlap_min && st->n >= ctx->overlap_min_rows && (det_idx || packed || xio) && st->n > 0 &&
+        R > 0 && e->vis_mask_alt && (ens || rb_through_memory) && (m == 0 || m <= 1024 * (int64_t)kMissileItems) &&
+        (!xio || xio->x->flag)) {
         sd = side_of(ctx);
         if (!sd) return fail(ctx, ZRK_E_HIP, "zrk_run_ticks: the side stream could not be created");
         if (xio && exchange_drain(xio->x, xio->x->head.load()) != 0) return fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
@@ -3067,8 +3074,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (sd->asleep.load()) { std::lock_guard<std::mutex> lk(sd->mu); sd->cv.notify_one(); }
         if (sd->mask_rows < e->capacity || sd->masks_dirty) {
             if (int rc0 = side_drain(ctx, sd, sd->head.load())) return rc0;
-            if (hipStreamSynchronize(sd->stream) != hipSuccess || (xio && hipStreamSynchronize(xio->x->cstream) != hipSuccess))
-                return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
+            if (hipStreamSynchronize(sd->stream) != hipSuccess) return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
             for (int k = 0; k < Side::kMasks; ++k) {
                 if (sd->mask_rows < e->capacity) {
                     if (sd->masks[k]) (void)hipFree(sd->masks[k]);
@@ -3084,8 +3090,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         }
         if (m > sd->code_rows) {
             if (int rc0 = side_drain(ctx, sd, sd->head.load())) return rc0;
-            if (hipStreamSynchronize(sd->stream) != hipSuccess || (xio && hipStreamSynchronize(xio->x->cstream) != hipSuccess))
-                return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
+            if (hipStreamSynchronize(sd->stream) != hipSuccess) return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
             const int64_t rows = std::max<int64_t>(2 * m, 4096);
             for (int k = 0; k < Side::kMasks; ++k) {
                 if (sd->codes[k]) (void)hipFree(sd->codes[k]);
@@ -3097,16 +3102,15 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         }
         if (sd->seq > 0x7FFF0000u) {                     // far from wrapping: the comparison is on 32 bits
             if (int rc0 = side_drain(ctx, sd, sd->head.load())) return rc0;
-            if (hipStreamSynchronize(xio ? xio->x->cstream : sd->stream) != hipSuccess || hipStreamSynchronize(sd->stream) != hipSuccess)
-                return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
+            if (hipStreamSynchronize(sd->stream) != hipSuccess) return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
             hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, s, sd->flag, 0u);
             if (hipStreamSynchronize(s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
             sd->seq = 0;
         }
     }
-    hipStream_t side_stream = sd ? (xio ? xio->x->cstream : sd->stream) : nullptr;
+    hipStream_t side_stream = sd ? sd->stream : nullptr;
     int side_last = -1;
-    zrk_exchange *fx = (!sd && xio && xio->x->flag) ? xio->x : nullptr;
+    zrk_exchange *fx = (xio && xio->x->flag) ? xio->x : nullptr;
     if (fx && fx->seq > 0x7FFF0000u) {                   // far from wrapping: the comparison is on 32 bits
         if (hipStreamSynchronize(fx->cstream) != hipSuccess) return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
         hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, s, fx->flag, 0u);
@@ -3224,8 +3228,19 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             if (ev_words && !fused && hipMemsetAsync(list + list_words, 0, sizeof(int64_t), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset events"); break; }
             it.stream = side_stream; it.flag_value = v; it.done_slot = side_slot;
             it.M = M; it.M.apply = 0;
-            if (xio) { it.x = xio->x; it.xslot = slot; it.send = list; it.recv = xio->recv[slot]; it.words = xio->words; }
+            if (xio) {
+                // the collective of this tick: on the exchange's own stream, released by whatever the side stream launches
+                // next; the list it sends was last sent two ticks ago, and that collective must be through
+                if (zrk_exchange_wait(xio->x, slot, stream) != 0) { rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x)); break; }
+                it.raise = fx->flag; it.raise_value = ++fx->seq;
+            }
             side_enqueue(sd, it);
+            if (xio) {
+                if (fx->poster.joinable()) exchange_enqueue(fx, zrk_exchange::PostItem{slot, list, xio->recv[slot], xio->words, it.raise_value});
+                else if (exchange_post_behind_flag(fx, slot, list, xio->recv[slot], xio->words, it.raise_value) != 0) {
+                    rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(fx)); break;
+                }
+            }
             side_last = side_slot;
             if (side_slot == Side::kMasks) ctx->ring_clean[st->vis_cur] = false;
             st->time_ms += st->dt_ms;
@@ -3262,6 +3277,12 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (rc == 0 && side_last >= 0) {
             hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, s, sd->flag, sd->seq);
             rc = check_launch(ctx, "k_raise_flag");
+        }
+        if (side_last >= 0 && xio) {                      // the last list's collective waits for a launch behind its compaction
+            SideItem fl;
+            std::memset((void *)&fl, 0, sizeof(fl));
+            fl.stream = side_stream; fl.flush = 1;
+            side_enqueue(sd, fl);
         }
         const int rc_side = side_drain(ctx, sd, sd->head.load());
         if (rc == 0) rc = rc_side;
