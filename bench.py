@@ -497,8 +497,7 @@ def main():
                                               else "through torch.distributed (rehearsal backend)"))
         else:
             what += "per-radar compaction"
-        one_call = (not exchanging) or state["c_side"]
-        overlapped = one_call and os.environ.get("ZRK_OVERLAP", "1") != "0" and args.steps >= int(os.environ.get("ZRK_OVERLAP_MIN", "4"))
+        overlapped = eng.store.lib.zrk_last_run_overlapped(eng.store.ctx.handle) == 1     # (of the timed call)
         loop_mode = ("overlapped: tick t's compaction on a side stream beside tick t+1's sweep" if overlapped
                      else "two launches per tick on one stream")
         out = {

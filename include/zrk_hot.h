@@ -306,6 +306,8 @@ typedef struct {
  * between two recorded events.  A wait on the side stream that runs out (the compute stream stalled for seconds) is
  * reported by zrk_compact_status.
  */
+/* 1 if the last zrk_run_ticks / _x / _ensemble call of this context ran overlapped, 0 if not (diagnostics). */
+int zrk_last_run_overlapped(zrk_ctx *ctx);
 int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *ents, const zrk_missiles *mis, int64_t m, zrk_loop *st,
                   zrk_radar *radars /* HOST, in/out */, const zrk_scan *scan /* HOST */, int R, void *workspace,
                   int32_t *det_idx, int64_t det_stride, int32_t *det_cnt, int64_t *packed,

@@ -187,6 +187,7 @@ _PROTOTYPES = {
     "zrk_exchange_all_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "zrk_exchange_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "zrk_exchange_sync": (C.c_int, [C.c_void_p]),
+    "zrk_last_run_overlapped": (C.c_int, [C.c_void_p]),
     "zrk_read_sweep_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "zrk_noise_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p,
                                   C.c_int64, C.c_void_p]),

@@ -2024,6 +2024,7 @@ struct zrk_ctx {
     int overlap = 1;                   // ZRK_OVERLAP: 0 never, 1 (default) for calls of at least overlap_min ticks
     int overlap_min = 4;
     int64_t overlap_min_rows = 400000; // ZRK_OVERLAP_MIN_ROWS: below, the compaction is too short for the third launch to pay
+    int last_overlapped = 0;           // whether the last zrk_run_ticks* call ran overlapped
 };
 
 namespace {
@@ -3108,6 +3109,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             sd->seq = 0;
         }
     }
+    ctx->last_overlapped = sd ? 1 : 0;
     hipStream_t side_stream = sd ? sd->stream : nullptr;
     int side_last = -1;
     zrk_exchange *fx = (xio && xio->x->flag) ? xio->x : nullptr;
@@ -3330,6 +3332,8 @@ ZRK_API int64_t zrk_ensemble_table_bytes(int scenarios)
 }
 
 ZRK_API double zrk_d2_threshold(double max_distance) { return d2_threshold(max_distance); }
+
+ZRK_API int zrk_last_run_overlapped(zrk_ctx *ctx) { return ctx ? ctx->last_overlapped : ZRK_E_INVALID; }
 
 ZRK_API int zrk_read_sweep_ms(zrk_ctx *ctx, float *sweep_ms, int n)
 {
