@@ -1961,7 +1961,7 @@ struct Side {
     // mask buffers of its own for all ticks of a call but the last (whose masks the caller may read): each is all zero
     // except between the sweep that writes it and the compaction that reads and clears it; slot kMasks stands for the
     // caller's buffer of the last tick
-    static constexpr int kMasks = 3;
+    static constexpr int kMasks = 5;
     uint32_t *masks[kMasks] = {nullptr, nullptr, nullptr};
     int64_t mask_rows = 0;
     // ... and, with the same lifetimes, the per-row event codes of the missile phase (written by a tick's sweep, read by
