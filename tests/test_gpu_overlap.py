@@ -48,6 +48,8 @@ def test_overlapped_loop_leaves_what_the_tick_by_tick_loop_leaves(n, R, m, noise
         for _ in range(K):
             ref.run(1)
         ovl.run(K)
+        assert ovl.store.lib.zrk_last_run_overlapped(ovl.store.ctx.handle) == (1 if K >= 4 else 0)
+        assert ref.store.lib.zrk_last_run_overlapped(ref.store.ctx.handle) == 0
         a, b = _state(ref), _state(ovl)
         _same(a, b, f"after call {calls} of {K} ticks")
         total_events += int(a["ne"][0])
