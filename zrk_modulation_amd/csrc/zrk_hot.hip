@@ -118,6 +118,15 @@ struct SweepParams {
     uint32_t *vis;              // indexed by LIST index
     const int32_t *order;       // row block of each workgroup, expensive ones first (NULL: identity)
     int32_t *order_next;        // the same for the next tick, built as this sweep goes (NULL: not built), see below
+    // overlapped loop: removals decided by this tick's missile phase are MARKS (pend[row] = this tick's mark value,
+    // written only where there is none yet, never cleared inside a call) that the row's own thread carries out in the next
+    // tick -- flag down, position frozen in both buffers -- instead of a launch between two sweeps (AirEnv.py:33-40:
+    // effective from the next tick either way).  A mark other than this tick's means "removed before this tick".
+    // NULL: no marks
+    uint8_t *pend;
+    uint32_t mark, _pad3;       // this tick's mark value: 1 + tick % 255
+    uint8_t *alive_w;           // (the alive column again, writable)
+    const double *pos_prev;     // the other position buffer
     uint32_t *order_ctr;        // kOrderRegions pairs (expensive / cheap row blocks recorded so far), kOrderCtrStride words apart
     uint32_t *order_ctr_next;   // the next tick's set, cleared here
     int64_t n, cap;
@@ -160,6 +169,8 @@ struct MissileArgs {
     int32_t apply, ev_wire_cap;
     int64_t *ev_wire;           // tail of the exchange list: [count, (missile index << 32 | target index or 0xFFFFFFFF) ...]
     int64_t gid0;               // global list index of list element 0 (indices on the wire are global)
+    uint8_t *pend;              // overlapped loop: removals as marks (see SweepParams::pend); NULL: tombstones by the finisher
+    uint32_t mark, _pad3;       // this tick's mark value
 };
 
 // Dispatch order of the next sweep.  The sweep's duration is set by the expensive waves (rows inside some
@@ -436,7 +447,8 @@ __device__ uint8_t missile_step_row(const double *__restrict__ sp, const double 
                                     const int32_t *__restrict__ lidx, const double *pos_prev, int64_t cap,
                                     const int32_t *__restrict__ m_slot, const int32_t *__restrict__ m_tgt,
                                     const double *__restrict__ m_radius, double *__restrict__ m_period,
-                                    uint8_t *__restrict__ m_status, int64_t row, double t, double dts);
+                                    uint8_t *__restrict__ m_status, int64_t row, double t, double dts,
+                                    uint8_t *pend = nullptr, uint32_t mark = 0);
 
 // Horizontal bounding box of the wave: two minima and two maxima over the 64 lanes, wave-uniform on return.
 // min / max are idempotent, so rotations inside each row of 16 (by 1, 2, 4, 8) and the two row broadcasts
@@ -728,7 +740,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
         const int64_t row = (int64_t)blockIdx.x * ZRK_BLOCK + threadIdx.x;
         if (row < M.m)
             M.ev_code[row] = missile_step_row(M.sp, M.vel, M.t0, M.alive, M.lidx, M.pos_prev, M.cap, M.m_slot, M.m_tgt,
-                                              M.m_radius, M.m_period, M.m_status, row, M.t, M.dts);
+                                              M.m_radius, M.m_period, M.m_status, row, M.t, M.dts, M.pend, M.mark);
         return;
     }
     const int tid = threadIdx.x;
@@ -762,6 +774,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     // every column load of the row is issued before anything waits for one: rows past the end read row 0
     const int64_t ic = (i < P.n) ? i : 0;
     const uint8_t al = P.alive[ic];
+    const uint32_t pk = P.pend ? (uint32_t)P.pend[ic] : 0u;
     const int32_t lix = LIDX ? P.lidx[ic] : 0;
     // (only the loads here: the arithmetic waits for them and comes after everything that does not)
     double t0 = 0.0, vx = 0.0, vy = 0.0, vz = 0.0, sx0, sy0, sz0;
@@ -772,7 +785,8 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     } else {
         sx0 = P.pos[ic]; sy0 = P.pos[cap + ic]; sz0 = P.pos[2 * cap + ic];
     }
-    const bool live = (i < P.n) & (al != 0);
+    const bool removed = (pk != 0u) & (pk != P.mark);        // marked in an earlier tick of this call
+    const bool live = (i < P.n) & (al != 0) & !removed;
     const int64_t li = (LIDX && i < P.n) ? (int64_t)lix : i;     // where this row sits in (its scenario's) AirEnv list
     // the wave's box record, if the caller keeps any (zrk_run_ticks does): twelve scalar words
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -905,6 +919,10 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     // sparse mode: the buffer is known to be all zero (the previous tick's compaction cleared it), so only
     // detections are written -- list-indexed stores are scattered when the table is spatially sorted
     if (i < P.n && (mask || !(P.flags & kSparseVis))) P.vis[(int64_t)scen * P.rows_ps + li] = mask;
+    if (removed && al != 0 && i < P.n) {                     // carry the removal out: once, by the row's own thread
+        P.alive_w[i] = 0;
+        P.pos[i] = P.pos_prev[i]; P.pos[cap + i] = P.pos_prev[cap + i]; P.pos[2 * cap + i] = P.pos_prev[2 * cap + i];
+    }
     if (P.order_next && tid == 0 && (unsigned)next_slot < (unsigned)P.nb) P.order_next[next_slot] = blk;
     ZRK_WAVE_PROBE(wave, 3, wall_clock64());
 }
@@ -1422,7 +1440,8 @@ __device__ uint8_t missile_step_row(const double *__restrict__ sp, const double 
                                     const int32_t *__restrict__ lidx, const double *pos_prev, int64_t cap,
                                     const int32_t *__restrict__ m_slot, const int32_t *__restrict__ m_tgt,
                                     const double *__restrict__ m_radius, double *__restrict__ m_period,
-                                    uint8_t *__restrict__ m_status, int64_t row, double t, double dts)
+                                    uint8_t *__restrict__ m_status, int64_t row, double t, double dts,
+                                    uint8_t *pend, uint32_t mark)
 {
     uint8_t code = 0;
     const int32_t s = m_slot[row];
@@ -1433,7 +1452,9 @@ __device__ uint8_t missile_step_row(const double *__restrict__ sp, const double 
         const int32_t j = m_tgt[row];
         double tx, ty, tz;
         const bool earlier = lidx ? (lidx[j] < lidx[s]) : (j < s);
-        if (alive[j] && earlier) {        // already stepped this tick (list order): fresh, noise-free
+        bool there = alive[j] != 0;
+        if (pend) { const uint32_t pj = pend[j]; there = there && !(pj != 0u && pj != mark); }   // (removed last tick: not yet carried out, perhaps)
+        if (there && earlier) {           // already stepped this tick (list order): fresh, noise-free
             const double dj = t - t0[j];
             tx = sp[j] + vel[j] * dj; ty = sp[cap + j] + vel[cap + j] * dj; tz = sp[2 * cap + j] + vel[2 * cap + j] * dj;
         } else {                          // not stepped yet, or removed: what it held after last tick
@@ -1447,6 +1468,10 @@ __device__ uint8_t missile_step_row(const double *__restrict__ sp, const double 
             const double p = m_period[row] - dts;
             m_period[row] = p;
             if (p <= 0.0) { code = 2; m_status[row] = 2; }
+        }
+        if (pend && code) {               // removals as marks: first one stands (a mark is never overwritten inside a call)
+            if (pend[s] == 0) pend[s] = (uint8_t)mark;
+            if (code == 1 && pend[j] == 0) pend[j] = (uint8_t)mark;
         }
     }
     return code;
@@ -1610,6 +1635,16 @@ __global__ void k_events_wire(const int32_t *__restrict__ ev_missile, const int3
         ev_wire[1 + j] = (int64_t)(((uint64_t)(gid0 + (lidx ? lidx[ms] : ms)) << 32) |
                                    (ts >= 0 ? (uint64_t)(uint32_t)(gid0 + (lidx ? lidx[ts] : ts)) : 0xFFFFFFFFull));
     }
+}
+
+// Overlapped loop, behind the last tick of a call: the removals that tick decided (marks nobody has carried out yet)
+// as the tombstones the caller expects (kill_one), and every mark of the call cleared.
+__global__ void k_apply_marks(uint8_t *__restrict__ pend, uint8_t *alive, const double *pos_cur, double *pos_prev, int64_t cap, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || pend[i] == 0) return;
+    if (alive[i]) kill_one(alive, pos_cur, pos_prev, cap, (int32_t)i);
+    pend[i] = 0;
 }
 
 __global__ void k_kill_slots(uint8_t *alive, const double *src, double *dst, int64_t cap,
@@ -1968,6 +2003,8 @@ struct Side {
     // its tombstones on the compute stream and by its event list on the side stream, beside the next sweep)
     uint8_t *codes[kMasks] = {nullptr, nullptr, nullptr};
     int64_t code_rows = 0;
+    uint8_t *pend = nullptr;        // removal marks of the running call (SweepParams::pend), all zero between calls
+    int64_t pend_rows = 0;
     bool masks_dirty = false;       // a call failed half-way: clear them before the next use
     uint64_t mask_pos = 0;
     hipEvent_t done[kMasks + 1] = {nullptr, nullptr, nullptr, nullptr};
@@ -2172,6 +2209,7 @@ MissileArgs missile_args(const zrk_entities *e, int cur, const zrk_missiles *mis
     M.m = m;
     M.t = (double)time_ms / 1000.0; M.dts = (double)dt_ms / 1000.0;
     M.apply = apply; M.ev_wire_cap = 0; M.ev_wire = nullptr; M.gid0 = 0;
+    M.pend = nullptr; M.mark = 0; M._pad3 = 0;
     return M;
 }
 
@@ -2207,7 +2245,7 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
                  const MissileArgs &M, uint32_t *vis = nullptr, int32_t *order_next = nullptr, const int32_t *order = nullptr,
                  WaveBox *boxes = nullptr, const EnsLaunch *ens = nullptr, const RadarBlock *rb_device = nullptr,
                  uint32_t *flag = nullptr, uint32_t flag_value = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
-                 uint32_t *order_ctr = nullptr, uint32_t *order_ctr_next = nullptr)
+                 uint32_t *order_ctr = nullptr, uint32_t *order_ctr_next = nullptr, uint8_t *pend = nullptr, uint32_t mark = 0)
 {
     if (!ctx || !e || !workspace || (R > 0 && !radars && !ens && !rb_device)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
     if (R < 0 || R > ZRK_MAX_RADARS)
@@ -2224,6 +2262,7 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
     P.R = R; P.nb = nblocks(n, ZRK_BLOCK); P.flags = flags;
     P.mb = nblocks(M.m, ZRK_BLOCK); P.flag = flag; P.flag_value = flag_value;
     P.boxes = boxes;
+    P.pend = pend; P.mark = mark; P._pad3 = 0; P.alive_w = e->alive; P.pos_prev = e->pos[cur ^ 1];
     P.rb_table = ens ? ens->rb_table : nullptr; P.seeds = ens ? ens->seeds : nullptr;
     P.rows_ps = ens ? ens->rows_ps : 0; P.bps = ens ? ens->bps : 0;
     P.bps_magic = ens ? (uint32_t)((0x100000000ull + (uint64_t)ens->bps - 1) / (uint64_t)ens->bps) : 0u;
@@ -2963,6 +3002,7 @@ void side_destroy(Side *sd)
     for (int k = 0; k <= Side::kMasks; ++k) if (sd->done[k]) (void)hipEventDestroy(sd->done[k]);
     for (int k = 0; k < Side::kMasks; ++k) if (sd->masks[k]) (void)hipFree(sd->masks[k]);
     for (int k = 0; k < Side::kMasks; ++k) if (sd->codes[k]) (void)hipFree(sd->codes[k]);
+    if (sd->pend) (void)hipFree(sd->pend);
     if (sd->flag) (void)hipFree(sd->flag);
     delete sd;
 }
@@ -3041,8 +3081,14 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     PutArgs put;
     put.dst = nullptr;
     RadarBlock *rb_dev[2] = {nullptr, nullptr};
-    const bool rb_through_memory = !ens && R > 0 && radars && (det_idx || packed || xio) && st->n > 0 &&
-                                   compacts_in_one_launch(ctx, st->n) && K > 0;
+    const bool rbm_possible = !ens && R > 0 && radars && (det_idx || packed || xio) && st->n > 0 &&
+                              compacts_in_one_launch(ctx, st->n) && K > 0;
+    // Overlap mode (below) has no second launch on the compute stream for the records to ride in: there the sweep reads
+    // them from its own argument segment (0.3 us slower than from memory, against 5.7 us for a launch of their own)
+    const bool want_overlap = ctx->overlap > 0 && K >= ctx->overlap_min && st->n >= ctx->overlap_min_rows &&
+                              (det_idx || packed || xio) && st->n > 0 && R > 0 && e->vis_mask_alt && (ens || rbm_possible) &&
+                              (m == 0 || m <= 1024 * (int64_t)kMissileItems) && (!xio || xio->x->flag);
+    const bool rb_through_memory = rbm_possible && !want_overlap;
     if (rb_through_memory) {
         Workspace w0 = carve(workspace, 0, e->capacity);
         rb_dev[0] = (RadarBlock *)((char *)w0.boxes - 2 * sizeof(RadarBlock));
@@ -3061,13 +3107,13 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     const int64_t ev_words = (xio && xio->ev_capacity > 0) ? 1 + (int64_t)xio->ev_capacity : 0;
     // hand-over of a tick's list to the exchange stream: by the flag the next tick's sweep raises (no packet of its own on
     // the compute stream), the last tick of the call -- which has no next sweep -- by an event
-    // Overlap mode: the lists of tick t are compacted on a side stream beside the sweep of tick t + 1; what that sweep
-    // needs of the tick's second launch (tombstones, events, dispatch order, radar records) stays on the compute stream
-    // as k_tick_small.  For calls of a few ticks at least: the last tick's compaction has nothing to run beside.
+    // Overlap mode: the lists of tick t are compacted on a side stream beside the sweep of tick t + 1, and the compute
+    // stream carries nothing but sweeps: removals travel as marks that the next sweep's threads carry out themselves
+    // (SweepParams::pend), radar records in the sweep's arguments, the dispatch order is built by the sweep before.
+    // (An ensemble keeps a small second launch, k_tick_small: its scenarios' scan steps and records, and its removals.)
+    // For calls of a few ticks at least: the last tick's compaction has nothing to run beside.
     Side *sd = nullptr;
-    if (ctx->overlap > 0 && K >= ctx->overlap_min && st->n >= ctx->overlap_min_rows && (det_idx || packed || xio) && st->n > 0 &&
-        R > 0 && e->vis_mask_alt && (ens || rb_through_memory) && (m == 0 || m <= 1024 * (int64_t)kMissileItems) &&
-        (!xio || xio->x->flag)) {
+    if (want_overlap) {
         sd = side_of(ctx);
         if (!sd) return fail(ctx, ZRK_E_HIP, "zrk_run_ticks: the side stream could not be created");
         if (xio && exchange_drain(xio->x, xio->x->head.load()) != 0) return fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
@@ -3088,6 +3134,14 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             }
             sd->mask_rows = e->capacity; sd->masks_dirty = false;
             for (int k = 0; k <= Side::kMasks; ++k) { sd->posted[k] = false; sd->item_no[k] = 0; }
+        }
+        if (sd->pend_rows < e->capacity) {
+            if (sd->pend) (void)hipFree(sd->pend);
+            sd->pend = nullptr; sd->pend_rows = 0;
+            if (hipMalloc((void **)&sd->pend, (size_t)e->capacity) != hipSuccess ||
+                hipMemsetAsync(sd->pend, 0, (size_t)e->capacity, s) != hipSuccess)
+                return fail(ctx, ZRK_E_HIP, "zrk_run_ticks: the removal marks could not be allocated");
+            sd->pend_rows = e->capacity;
         }
         if (m > sd->code_rows) {
             if (int rc0 = side_drain(ctx, sd, sd->head.load())) return rc0;
@@ -3158,6 +3212,10 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         }
         if (sd && (rc = side_wait(ctx, sd, side_slot)) != 0) break;
         if (sd && side_slot < Side::kMasks && M.m > 0) M.ev_code = sd->codes[side_slot];
+        // removals as marks (one scenario): carried out by the next sweep's own threads, or behind the call's last tick
+        const bool marks = sd && !ens && M.m > 0;
+        const uint32_t mark = marks ? 1u + (uint32_t)(st->tick % 255u) : 0u;
+        if (marks) { M.pend = sd->pend; M.mark = mark; M.apply = 0; }
         // next tick's dispatch order: this tick's sweep builds it as it goes
         const int nbs = nblocks(st->n, ZRK_BLOCK);
         // (a grid that is resident all at once has no "last": eight workgroups of four waves fit a compute unit)
@@ -3188,7 +3246,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                           rb_through_memory ? rb_dev[st->tick & 1u] : nullptr,
                           pend.on ? fx->flag : ((sd && k > 0) ? sd->flag : nullptr), pend.on ? pend.value : (sd ? sd->seq : 0u),
                           on_dispatch ? ev[2 * (k / stride)] : nullptr, on_dispatch ? ev[2 * (k / stride) + 1] : nullptr,
-                          w.order_ctr + kOrderCtrSet * (oph ^ 1), w.order_ctr + kOrderCtrSet * oph);
+                          w.order_ctr + kOrderCtrSet * (oph ^ 1), w.order_ctr + kOrderCtrSet * oph, marks ? sd->pend : nullptr, mark);
         if (rc == 0 && ordering) { ctx->order_ready = true; ctx->order_phase = oph ^ 1; }
         if (pend.on) {                                                       // the previous tick's collective, behind this sweep's start
             if (rc == 0 && !(st->n > 0 || M.m > 0)) {                        // (no sweep was launched: raise the flag by itself)
@@ -3211,10 +3269,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             if (rc != 0) break;
             // compute stream: what the next sweep needs (the next sweep's first thread, or the launch behind the loop,
             // releases the side stream: beside this small launch the compaction would only be in its way)
-            EnsembleArgs E0;
-            std::memset(&E0, 0, sizeof(E0));
             static PutArgs no_put;
-            const int eparts = ens ? nblocks((int64_t)EL.next.S * EL.next.R, kCompBlock) : (rb_through_memory ? 1 : 0);
+            const int eparts = ens ? nblocks((int64_t)EL.next.S * EL.next.R, kCompBlock) : 0;
             const int small_grid = std::max(1, nblocks(M.m, kCompBlock) + eparts);
             SideItem it;
             std::memset((void *)&it, 0, sizeof(it));
@@ -3224,9 +3280,10 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                                 (st->flags & ZRK_F_UNION_BITS) != 0, ens ? &EL : nullptr, nullptr, &it);
             if (rc != 0) break;
             const uint32_t v = ++sd->seq;
-            hipLaunchKernelGGL(k_tick_small, dim3(small_grid), dim3(kCompBlock), 0, s, M, ens ? EL.next : E0,
-                               (rb_through_memory && !ens) ? put : no_put);
-            if ((rc = check_launch(ctx, "k_tick_small")) != 0) break;
+            if (ens) {
+                hipLaunchKernelGGL(k_tick_small, dim3(small_grid), dim3(kCompBlock), 0, s, M, EL.next, no_put);
+                if ((rc = check_launch(ctx, "k_tick_small")) != 0) break;
+            }
             if (ev_words && !fused && hipMemsetAsync(list + list_words, 0, sizeof(int64_t), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset events"); break; }
             it.stream = side_stream; it.flag_value = v; it.done_slot = side_slot;
             it.M = M; it.M.apply = 0;
@@ -3276,6 +3333,13 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     if (sd) {
         // the events in the last list's tail are complete once something behind its k_tick_small has started; then the
         // side stream's work is issued to the last item, and the compute stream takes it in: the lists are the caller's
+        if (rc == 0 && side_last >= 0 && !ens && m > 0) {
+            // the last tick's removals are still marks: tombstones now (and the call's marks cleared); this launch also
+            // stands behind the last sweep for the side stream's flag
+            hipLaunchKernelGGL(k_apply_marks, dim3(nblocks(st->n, 256)), dim3(256), 0, s, sd->pend, e->alive, e->pos[st->cur],
+                               e->pos[st->cur ^ 1], e->capacity, st->n);
+            rc = check_launch(ctx, "k_apply_marks");
+        }
         if (rc == 0 && side_last >= 0) {
             hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, s, sd->flag, sd->seq);
             rc = check_launch(ctx, "k_raise_flag");
@@ -3288,7 +3352,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         }
         const int rc_side = side_drain(ctx, sd, sd->head.load());
         if (rc == 0) rc = rc_side;
-        if (rc != 0) sd->masks_dirty = true;
+        if (rc != 0) { sd->masks_dirty = true; sd->pend_rows = 0; }  // (marks: allocated and cleared anew)
         if (rc == 0 && side_last >= 0 && sd->posted[side_last] && hipStreamWaitEvent(s, sd->done[side_last], 0) != hipSuccess)
             rc = fail(ctx, ZRK_E_HIP, "hipStreamWaitEvent");
     }
