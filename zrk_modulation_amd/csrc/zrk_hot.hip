@@ -734,7 +734,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     // the previous tick's compaction is over and visible once this grid starts: tell the exchange stream, which waits
     // for this word instead of an event (an event record costs the compute stream a barrier packet per tick)
     if (P.flag && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(P.flag, P.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P.flag, P.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((int)blockIdx.x < P.mb) {              // leading workgroups: Missile.step for every in-flight row (a long
         // dependent chain -- dispatched first, it is over long before the sweep's last wave is)
         const int64_t row = (int64_t)blockIdx.x * ZRK_BLOCK + threadIdx.x;
@@ -1981,17 +1981,21 @@ struct SideItem {
     CompactArgs C;
     int by_ticket;
     MissileArgs M;                  // apply == 0: the ordered event list only (and the events in the list's tail)
-    // an exchange's collective runs on the exchange's own stream and waits for *raise >= raise_value, which the NEXT
-    // launch on the side stream writes as it starts (this compaction and everything before it is over then)
+    // an exchange's collective runs on the exchange's own stream and waits for *raise >= raise_value, which a launch of
+    // its own behind the compaction writes
     uint32_t *raise;
     uint32_t raise_value;
-    int flush;                      // 1: no tick, only the pending raise (behind the last tick of a call)
     int done_slot;                  // done[done_slot] is recorded last
 };
 
 struct Side {
     hipStream_t stream = nullptr;   // (an exchange's own stream is used instead of this one when there is one)
-    uint32_t *flag = nullptr;       // device words: [0] see SideItem; [2] a wait gave up
+    uint32_t *flag = nullptr;       // device words: [2] a wait gave up
+    // the word the compute stream raises (SideItem::flag_value) lives in pinned HOST memory: the side stream's thread
+    // polls it there and launches the compaction when it is up -- a one-lane wait kernel in front of every compaction
+    // cost the side stream 5 us a tick (a lone wave is slow to find a slot on a device full of sweep waves)
+    volatile uint32_t *hflag = nullptr;
+    uint32_t *hflag_dev = nullptr;  // the same word as the device addresses it
     uint32_t seq = 0;
     // mask buffers of its own for all ticks of a call but the last (whose masks the caller may read): each is all zero
     // except between the sweep that writes it and the compaction that reads and clears it; slot kMasks stands for the
@@ -2010,8 +2014,6 @@ struct Side {
     hipEvent_t done[kMasks + 1] = {nullptr, nullptr, nullptr, nullptr};
     bool posted[kMasks + 1] = {false, false, false, false};
     uint64_t item_no[kMasks + 1] = {0, 0, 0, 0};
-    uint32_t *pend_raise = nullptr; // (the thread's own: what the next launch on the side stream has to raise)
-    uint32_t pend_raise_value = 0;
     static constexpr uint64_t kRing = 8;
     SideItem ring[kRing];
     std::atomic<uint64_t> head{0}, tail{0};
@@ -2812,6 +2814,11 @@ ZRK_API int zrk_exchange_all_gather(zrk_exchange *x, int slot, const int64_t *se
 
 namespace {
 
+__global__ void k_raise_flag_system(uint32_t *flag, uint32_t value)
+{
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ void k_raise_flag(uint32_t *flag, uint32_t value)
 {
     __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2819,11 +2826,8 @@ __global__ void k_raise_flag(uint32_t *flag, uint32_t value)
 
 // One lane waits for the word to reach `value` (sleeping between looks); gives up after a few seconds and says so
 // (zrk_exchange_sync reports it) rather than hold the device for ever.
-__global__ void k_wait_flag(const uint32_t *flag, uint32_t value, uint32_t *gave_up, uint32_t *raise = nullptr,
-                            uint32_t raise_value = 0)
+__global__ void k_wait_flag(const uint32_t *flag, uint32_t value, uint32_t *gave_up)
 {
-    // (running at all means everything before it on its stream is over: say so first, if somebody waits for that)
-    if (raise) __hip_atomic_store(raise, raise_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int spins = 0; spins < (1 << 20); ++spins) {
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= value) return;
         __builtin_amdgcn_s_sleep(32);
@@ -2837,7 +2841,7 @@ int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, in
 {
     // (a wait kernel of our own on a word of device memory: hipStreamWaitValue32 on signal memory does the same
     // job but cost the compute stream 3.5 us a tick in the measurement, this costs it nothing measurable)
-    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, x->cstream, x->flag, value, x->flag + 1, (uint32_t *)nullptr, 0u);
+    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, x->cstream, x->flag, value, x->flag + 1);
     if (hipGetLastError() != hipSuccess) { x->err = "k_wait_flag launch failed"; return ZRK_E_HIP; }
     const int rc = x->api.AllGather(send, recv, (size_t)words, kNcclInt64, x->comm, x->cstream);
     if (rc != 0) { x->err = std::string("ncclAllGather: ") + (x->api.GetErrorString ? x->api.GetErrorString(rc) : "error"); return ZRK_E_HIP; }
@@ -2894,20 +2898,25 @@ int side_issue(Side *sd, const SideItem &it)
     static PutArgs no_put;                               // (zero-initialised: dst == NULL)
     EnsembleArgs no_ens;
     std::memset(&no_ens, 0, sizeof(no_ens));
-    if (it.flush) {
-        if (sd->pend_raise) hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, it.stream, sd->pend_raise, sd->pend_raise_value);
-        sd->pend_raise = nullptr;
-        if (hipGetLastError() != hipSuccess) { sd->err = "side stream: launch failed"; return ZRK_E_HIP; }
-        return 0;
+    // The compaction is launched when its input is there, not before: letting its workgroups wait on the device -- resident
+    // ahead of their input -- deadlocks the device as soon as anything else on it needs whole compute units in dispatch
+    // order (e.g. another engine's single-launch compaction), and a one-lane wait kernel in front of it costs the side
+    // stream 5 us a tick.  This thread has nothing else to do.
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while ((int32_t)(*sd->hflag - it.flag_value) < 0) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                sd->err = "side stream: the compute stream did not reach the next sweep within 5 s"; return ZRK_E_STATE;
+            }
+            if (sd->stop.load()) { sd->err = "side stream: stopped"; return ZRK_E_STATE; }
+        }
     }
-    // (one lane waits in a launch of its own: letting the compaction's workgroups wait themselves -- resident ahead of
-    // their input -- saves the side stream 6 us a tick and deadlocks the device as soon as anything else on it needs
-    // whole compute units in dispatch order, e.g. another engine's single-launch compaction)
-    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, it.stream, sd->flag, it.flag_value, sd->flag + 2, sd->pend_raise,
-                       sd->pend_raise_value);
-    sd->pend_raise = it.raise; sd->pend_raise_value = it.raise_value;
     hipLaunchKernelGGL(k_compact_fused, dim3(it.C.nb + (it.M.m > 0 ? 1 : 0)), dim3(kCompBlock), 0, it.stream, it.C, it.by_ticket, it.M,
                        no_ens, no_put);
+    // an exchange's collective (on the exchange's own stream) waits for this word: the list and its events are complete
+    if (it.raise) hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, it.stream, it.raise, it.raise_value);
     if (hipGetLastError() != hipSuccess) { sd->err = "side stream: compaction launch failed"; return ZRK_E_HIP; }
     if (hipEventRecord(sd->done[it.done_slot], it.stream) != hipSuccess) { sd->err = "side stream: hipEventRecord failed"; return ZRK_E_HIP; }
     sd->posted[it.done_slot] = true;
@@ -2944,12 +2953,16 @@ Side *side_of(zrk_ctx *ctx)
     if (ctx->side) return ctx->side;
     Side *sd = new Side;
     bool ok = hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipMalloc((void **)&sd->flag, 16) == hipSuccess && hipMemset(sd->flag, 0, 16) == hipSuccess;
+              hipMalloc((void **)&sd->flag, 16) == hipSuccess && hipMemset(sd->flag, 0, 16) == hipSuccess &&
+              hipHostMalloc((void **)&sd->hflag, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+              hipHostGetDevicePointer((void **)&sd->hflag_dev, (void *)sd->hflag, 0) == hipSuccess;
+    if (ok) *sd->hflag = 0u;
     for (int k = 0; k <= Side::kMasks && ok; ++k) ok = hipEventCreateWithFlags(&sd->done[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         for (int k = 0; k <= Side::kMasks; ++k) if (sd->done[k]) (void)hipEventDestroy(sd->done[k]);
         if (sd->flag) (void)hipFree(sd->flag);
+        if (sd->hflag) (void)hipHostFree((void *)sd->hflag);
         if (sd->stream) (void)hipStreamDestroy(sd->stream);
         delete sd;
         return nullptr;
@@ -2965,7 +2978,7 @@ void side_enqueue(Side *sd, const SideItem &it)
     while (h - sd->tail.load(std::memory_order_acquire) >= Side::kRing) __builtin_ia32_pause();
     sd->ring[h % Side::kRing] = it;
     sd->head.store(h + 1, std::memory_order_release);
-    if (!it.flush) sd->item_no[it.done_slot] = h + 1;
+    sd->item_no[it.done_slot] = h + 1;
     if (sd->asleep.load()) { std::lock_guard<std::mutex> lk(sd->mu); sd->cv.notify_one(); }
 }
 
@@ -3004,6 +3017,7 @@ void side_destroy(Side *sd)
     for (int k = 0; k < Side::kMasks; ++k) if (sd->codes[k]) (void)hipFree(sd->codes[k]);
     if (sd->pend) (void)hipFree(sd->pend);
     if (sd->flag) (void)hipFree(sd->flag);
+    if (sd->hflag) (void)hipHostFree((void *)sd->hflag);
     delete sd;
 }
 
@@ -3158,8 +3172,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (sd->seq > 0x7FFF0000u) {                     // far from wrapping: the comparison is on 32 bits
             if (int rc0 = side_drain(ctx, sd, sd->head.load())) return rc0;
             if (hipStreamSynchronize(sd->stream) != hipSuccess) return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
-            hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, s, sd->flag, 0u);
             if (hipStreamSynchronize(s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
+            *sd->hflag = 0u;
             sd->seq = 0;
         }
     }
@@ -3244,7 +3258,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                           st->tick, st->gid0, workspace, stream, M, vis_now, ordering ? w.order[oph ^ 1] : nullptr,
                           (ordering && ctx->order_ready) ? w.order[oph] : nullptr, w.boxes, ens ? &EL : nullptr,
                           rb_through_memory ? rb_dev[st->tick & 1u] : nullptr,
-                          pend.on ? fx->flag : ((sd && k > 0) ? sd->flag : nullptr), pend.on ? pend.value : (sd ? sd->seq : 0u),
+                          pend.on ? fx->flag : ((sd && k > 0) ? sd->hflag_dev : nullptr), pend.on ? pend.value : (sd ? sd->seq : 0u),
                           on_dispatch ? ev[2 * (k / stride)] : nullptr, on_dispatch ? ev[2 * (k / stride) + 1] : nullptr,
                           w.order_ctr + kOrderCtrSet * (oph ^ 1), w.order_ctr + kOrderCtrSet * oph, marks ? sd->pend : nullptr, mark);
         if (rc == 0 && ordering) { ctx->order_ready = true; ctx->order_phase = oph ^ 1; }
@@ -3341,14 +3355,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             rc = check_launch(ctx, "k_apply_marks");
         }
         if (rc == 0 && side_last >= 0) {
-            hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, s, sd->flag, sd->seq);
+            hipLaunchKernelGGL(k_raise_flag_system, dim3(1), dim3(1), 0, s, sd->hflag_dev, sd->seq);
             rc = check_launch(ctx, "k_raise_flag");
-        }
-        if (side_last >= 0 && xio) {                      // the last list's collective waits for a launch behind its compaction
-            SideItem fl;
-            std::memset((void *)&fl, 0, sizeof(fl));
-            fl.stream = side_stream; fl.flush = 1;
-            side_enqueue(sd, fl);
         }
         const int rc_side = side_drain(ctx, sd, sd->head.load());
         if (rc == 0) rc = rc_side;
