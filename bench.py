@@ -516,7 +516,10 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "profiled_kernel_us_recorded": recorded(f"sweep_us_{args.workload}") if world == 1 else None,
                          "profiled_kernel_us_alone_recorded": recorded(f"sweep_us_{args.workload}_plain_loop") if world == 1 else None,
-                         "recorded_from": f"profiles/{PROFILE_TAG}_recorded.json (rocprofv3 passes of this command, committed)"},
+                         "recorded_from": f"profiles/{PROFILE_TAG}_recorded.json (rocprofv3 passes of this command, committed)",
+                         # the same algorithmic bytes over the whole tick (this rank's): what the loop around the kernel leaves of it
+                         "whole_tick": {"achieved": alg_bytes / (elapsed / args.steps) / 1e9,
+                                        "frac": alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}},
             "setup": {"clock_spinup_ms": SPINUP_MS},
         }
         if exchanging:

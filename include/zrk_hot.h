@@ -293,16 +293,18 @@ typedef struct {
  * end and sweep_ms[k / prof_stride] receives the kernel's duration in milliseconds (prof_stride < 0: the events are
  * only recorded, zrk_read_sweep_ms reads them later).
  *
- * Calls of four ticks or more with compaction, a second mask buffer and a missile table the single-workgroup
- * finisher covers run OVERLAPPED: the lists and the ordered event list of tick t are compacted on a side stream of the
- * context beside the sweep of tick t + 1 (issued by a thread of the context's own, so that the caller's thread is left
- * with two launches per tick); what the next sweep needs -- tombstones, radar records -- stays on `stream` as a small
- * launch.  Same kernels, same results; `stream` takes the side stream in before the call returns, so the outputs
- * are the caller's as before.  Differences a caller can see: the masks of all ticks but the LAST of such a call live
- * in buffers of the context (ents->vis_mask / vis_mask_alt hold the last tick's, as st->vis_cur says), likewise
- * mis->ev_code; the dispatch order of a sweep's workgroups is never the same twice (it does not enter any result).
+ * Calls of four ticks or more on a table of 4e5 rows or more, with compaction, a second mask buffer and a missile table
+ * the single-workgroup finisher covers, run OVERLAPPED: the lists and the ordered event list of tick t are compacted on
+ * a side stream of the context beside the sweep of tick t + 1 (launched by a thread of the context's own when the
+ * compute stream says, through a word of pinned host memory, that sweep t + 1 has started), and `stream` carries one
+ * launch per tick: removals decided by a tick's missile phase are marks that the rows' own threads carry out in the
+ * next sweep (tombstones again when the call returns), radar records travel in the sweep's arguments.  Same results;
+ * `stream` takes the side stream in before the call returns, so the outputs are the caller's as before.  Differences
+ * a caller can see: the masks of all ticks but the LAST of such a call live in buffers of the context
+ * (ents->vis_mask / vis_mask_alt hold the last tick's, as st->vis_cur says), likewise mis->ev_code; the dispatch order
+ * of a sweep's workgroups is never the same twice (it does not enter any result).
  * Environment (read at zrk_ctx_create / zrk_ctx_reload_env): ZRK_OVERLAP=0 never overlap; ZRK_OVERLAP_MIN=k from k
- * ticks per call; ZRK_SWEEP_ORDER=0 sweep in table order; ZRK_COMPACT_ORDER=block|ticket; ZRK_TIME_BY_RECORDS=1 time
+ * ticks per call; ZRK_OVERLAP_MIN_ROWS=n from n rows; ZRK_SWEEP_ORDER=0 sweep in table order; ZRK_COMPACT_ORDER=block|ticket; ZRK_TIME_BY_RECORDS=1 time
  * between two recorded events.  A wait on the side stream that runs out (the compute stream stalled for seconds) is
  * reported by zrk_compact_status.
  */

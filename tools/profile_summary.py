@@ -18,8 +18,14 @@ cal = json.load(open(dst / "r01_pmc_traffic.json"))["calibration"]
 recorded = {}
 
 
+def newest(pattern):
+    """gpurun_out/ accumulates the files of every collection run (one set per profiled process id): take the latest."""
+    import os
+    return sorted(glob.glob(pattern), key=os.path.getmtime, reverse=True)
+
+
 def kernel_stats(name, out):
-    f = glob.glob(str(src / name / "*" / "*kernel_stats.csv"))
+    f = newest(str(src / name / "*" / "*kernel_stats.csv"))
     if not f:
         return None
     shutil.copy(f[0], dst / out)
@@ -48,7 +54,7 @@ traffic = {}
 for wl in ("C3", "C3x4"):
     vals = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        f = glob.glob(str(src / f"traffic_{wl}_{c}" / "*" / "*counter_collection.csv"))
+        f = newest(str(src / f"traffic_{wl}_{c}" / "*" / "*counter_collection.csv"))
         if not f:
             continue
         rows = [r for r in csv.DictReader(open(f[0])) if "k_tick_sweep" in r["Kernel_Name"] and r["Counter_Name"] == c]
@@ -70,7 +76,7 @@ for wl in ("C3", "C3x4"):
 # the same scene without missiles (tools/prof_run.py, PROF_M=0): what the missile phase's gathers add
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(str(src / f"traffic_nomis_{c}" / "*" / "*counter_collection.csv"))
+    f = newest(str(src / f"traffic_nomis_{c}" / "*" / "*counter_collection.csv"))
     if f:
         rows = [r for r in csv.DictReader(open(f[0])) if "k_tick_sweep" in r["Kernel_Name"] and r["Counter_Name"] == c][25:]
         vals[c] = sum(float(r["Counter_Value"]) for r in rows) / max(len(rows), 1)

@@ -1989,7 +1989,7 @@ struct SideItem {
 };
 
 struct Side {
-    hipStream_t stream = nullptr;   // (an exchange's own stream is used instead of this one when there is one)
+    hipStream_t stream = nullptr;
     uint32_t *flag = nullptr;       // device words: [2] a wait gave up
     // the word the compute stream raises (SideItem::flag_value) lives in pinned HOST memory: the side stream's thread
     // polls it there and launches the compaction when it is up -- a one-lane wait kernel in front of every compaction
