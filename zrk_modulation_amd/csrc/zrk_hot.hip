@@ -3188,6 +3188,19 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         fx->seq = 0;
     }
     struct { bool on; int slot; int64_t *list; uint32_t value; } pend = {false, 0, nullptr, 0u};
+    struct { bool on; SideItem it; int slot; int64_t *list; } held;
+    held.on = false;
+    auto issue_held = [&]() -> int {
+        held.on = false;
+        if (zrk_exchange_wait(xio->x, held.slot, stream) != 0) return fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
+        side_enqueue(sd, held.it);
+        zrk_exchange *x = xio->x;
+        if (x->poster.joinable())
+            exchange_enqueue(x, zrk_exchange::PostItem{held.slot, held.list, xio->recv[held.slot], xio->words, held.it.raise_value});
+        else if (exchange_post_behind_flag(x, held.slot, held.list, xio->recv[held.slot], xio->words, held.it.raise_value) != 0)
+            return fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(x));
+        return 0;
+    };
     int rc = 0;
     for (int k = 0; k < K && rc == 0; ++k) {
         st->cur ^= 1;
@@ -3262,6 +3275,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                           on_dispatch ? ev[2 * (k / stride)] : nullptr, on_dispatch ? ev[2 * (k / stride) + 1] : nullptr,
                           w.order_ctr + kOrderCtrSet * (oph ^ 1), w.order_ctr + kOrderCtrSet * oph, marks ? sd->pend : nullptr, mark);
         if (rc == 0 && ordering) { ctx->order_ready = true; ctx->order_phase = oph ^ 1; }
+        if (rc == 0 && held.on) rc = issue_held();                           // (the previous tick's item, see below)
         if (pend.on) {                                                       // the previous tick's collective, behind this sweep's start
             if (rc == 0 && !(st->n > 0 || M.m > 0)) {                        // (no sweep was launched: raise the flag by itself)
                 hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, s, fx->flag, pend.value);
@@ -3302,17 +3316,15 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             it.stream = side_stream; it.flag_value = v; it.done_slot = side_slot;
             it.M = M; it.M.apply = 0;
             if (xio) {
-                // the collective of this tick: on the exchange's own stream, released by whatever the side stream launches
-                // next; the list it sends was last sent two ticks ago, and that collective must be through
-                if (zrk_exchange_wait(xio->x, slot, stream) != 0) { rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x)); break; }
+                // The collective of this tick runs on the exchange's own stream, released by a launch behind the compaction.
+                // The list it sends was last sent two ticks ago, and that collective must be through before the compaction
+                // may write it -- checked as late as possible, i.e. when the NEXT sweep has been launched (the item is
+                // held until then: the side stream cannot start it before that sweep runs anyway), so that a late
+                // collective never delays a launch on the compute stream.
                 it.raise = fx->flag; it.raise_value = ++fx->seq;
-            }
-            side_enqueue(sd, it);
-            if (xio) {
-                if (fx->poster.joinable()) exchange_enqueue(fx, zrk_exchange::PostItem{slot, list, xio->recv[slot], xio->words, it.raise_value});
-                else if (exchange_post_behind_flag(fx, slot, list, xio->recv[slot], xio->words, it.raise_value) != 0) {
-                    rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(fx)); break;
-                }
+                held.on = true; held.it = it; held.slot = slot; held.list = list;
+            } else {
+                side_enqueue(sd, it);
             }
             side_last = side_slot;
             if (side_slot == Side::kMasks) ctx->ring_clean[st->vis_cur] = false;
@@ -3345,18 +3357,18 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         st->tick += 1;
     }
     if (sd) {
-        // the events in the last list's tail are complete once something behind its k_tick_small has started; then the
-        // side stream's work is issued to the last item, and the compute stream takes it in: the lists are the caller's
+        if (held.on && rc == 0) rc = issue_held();
+        // behind the last tick: its removals as tombstones, the word the side stream's thread waits for, then the side
+        // stream's work is issued to the last item and the compute stream takes it in: the lists are the caller's
+        if (rc == 0 && side_last >= 0) {                  // (first: the last compaction may start as soon as the last sweep is over)
+            hipLaunchKernelGGL(k_raise_flag_system, dim3(1), dim3(1), 0, s, sd->hflag_dev, sd->seq);
+            rc = check_launch(ctx, "k_raise_flag");
+        }
         if (rc == 0 && side_last >= 0 && !ens && m > 0) {
-            // the last tick's removals are still marks: tombstones now (and the call's marks cleared); this launch also
-            // stands behind the last sweep for the side stream's flag
+            // the last tick's removals are still marks: tombstones now, and the call's marks cleared
             hipLaunchKernelGGL(k_apply_marks, dim3(nblocks(st->n, 256)), dim3(256), 0, s, sd->pend, e->alive, e->pos[st->cur],
                                e->pos[st->cur ^ 1], e->capacity, st->n);
             rc = check_launch(ctx, "k_apply_marks");
-        }
-        if (rc == 0 && side_last >= 0) {
-            hipLaunchKernelGGL(k_raise_flag_system, dim3(1), dim3(1), 0, s, sd->hflag_dev, sd->seq);
-            rc = check_launch(ctx, "k_raise_flag");
         }
         const int rc_side = side_drain(ctx, sd, sd->head.load());
         if (rc == 0) rc = rc_side;
