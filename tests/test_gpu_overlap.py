@@ -95,3 +95,44 @@ def test_overlap_with_the_exchange_on_one_rank(monkeypatch):
     assert seen_events > 0
     _same(_state(ref), _state(ovl), "after the exchanged calls")
     x.close()
+
+
+def test_several_missiles_on_one_target(monkeypatch):
+    """Removals travel as marks in the overlapped loop (first mark stands, never cleared inside a call).  The case that
+    needs exactly that: several missiles on the same target with different fuse radii -- the later ones arrive when the
+    target is gone, detonate on its frozen position (or run out of time) and mark it again, in the very tick in which
+    its own thread carries the first removal out.  State after every call must be the two-launch loop's."""
+    from zrk_modulation_amd import scenario as S
+    from zrk_modulation_amd.engine import HotPathEngine
+    n, R, m = 60_000, 5, 1200
+    ids, sp, vel, t0 = S.synthetic_targets(n, 77)
+    sp *= 0.25                                                   # a compact swarm: short flights, hits within the test
+    vel *= 0.2
+    radars = S.synthetic_radars(R)
+    tgt = (np.arange(m) // 6 * 97 % n).astype(np.int32)          # six missiles per target
+    radius = np.tile(np.array([2500.0, 1500.0, 900.0, 500.0, 250.0, 120.0]), m // 6)
+    engines = []
+    for ov in ("0", "1"):
+        monkeypatch.setenv("ZRK_OVERLAP_MIN_ROWS", "0")
+        monkeypatch.setenv("ZRK_OVERLAP", ov)
+        eng = HotPathEngine(device="cuda:0", dt_ms=200, seed=5, noise="philox", gid0=0)
+        eng.load(ids, sp, vel, t0, radars, missile_capacity=m).enable_lists()
+        assert eng.launch_missiles(tgt, launcher_pos=(0.0, 0.0, 0.0), speed=2500.0, radius=radius, period=30.0) > 600
+        engines.append(eng)
+    ref, ovl = engines
+    removed_late = 0
+    prev_alive = None
+    for calls, K in enumerate([6, 9, 4, 12, 7, 5, 20, 8, 16]):
+        ref.run(K)
+        ovl.run(K)
+        assert ovl.store.lib.zrk_last_run_overlapped(ovl.store.ctx.handle) == 1
+        a, b = _state(ref), _state(ovl)
+        _same(a, b, f"after call {calls} of {K} ticks")
+        if prev_alive is not None:
+            removed_late += int(prev_alive.sum() - a["alive"].sum())
+        prev_alive = a["alive"]
+    st = ref.store
+    status = st.dm_status[:st.m].cpu().numpy()
+    done_per_target = np.bincount(np.asarray(st.hm_tgt[:st.m])[status == 2], minlength=1)
+    assert done_per_target.max() >= 3, "several missiles of one target should have detonated or timed out"
+    assert removed_late > 0
