@@ -1409,6 +1409,20 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_fused(const CompactArgs 
     compact_block<kCompBlock>(S, C, by_ticket);
 }
 
+// The same for the overlapped loop's side stream: lists and (M.apply == 0) the ordered event list only.  An entry of its
+// own because of its arguments: the 9 KB of radar records that the entry above carries (unused there) made every launch
+// cost the side stream's thread 6-8 us, which is what bounded the loop.
+__global__ __launch_bounds__(kCompBlock) void k_compact_side(const CompactArgs C, int by_ticket, const MissileArgs M)
+{
+    __shared__ int s_wave[kCompBlock / 64];
+    __shared__ CompactShared<kCompBlock> S;
+    if ((int)blockIdx.x >= C.nb) {
+        if (M.m > 0 && (int)blockIdx.x == C.nb) missile_finish_entry(s_wave, M);
+        return;
+    }
+    compact_block<kCompBlock>(S, C, by_ticket);
+}
+
 // Overlap mode of zrk_run_ticks: what the NEXT sweep needs of a tick's second launch -- the tombstones and the radar
 // records -- as a launch of its own (a dozen workgroups) on the compute stream, while the lists and the ordered events
 // are compacted on a side stream beside the next sweep.
@@ -2685,6 +2699,15 @@ namespace {
 
 int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, int64_t *recv, int64_t words, uint32_t value);
 
+// How long the library's helper threads (an exchange's, a context's side stream's) keep spinning after their last
+// item before they sleep: waking one costs 50-100 us, which the first ticks of the next call would pay.  Half a
+// second covers the pauses between the calls of a tick loop; ZRK_HELPER_IDLE_MS changes it (0: sleep at once).
+std::chrono::milliseconds helper_idle()
+{
+    static const int ms = [] { const char *v = std::getenv("ZRK_HELPER_IDLE_MS"); return v ? std::max(0, std::atoi(v)) : 500; }();
+    return std::chrono::milliseconds(ms);
+}
+
 void exchange_poster_main(zrk_exchange *x)
 {
     if (hipSetDevice(x->device) != hipSuccess) { x->post_err = "hipSetDevice failed in the exchange thread"; x->post_rc.store(ZRK_E_HIP); }
@@ -2702,7 +2725,7 @@ void exchange_poster_main(zrk_exchange *x)
             continue;
         }
         if (x->stop.load()) return;
-        if (std::chrono::steady_clock::now() - idle_since < std::chrono::milliseconds(50)) {
+        if (std::chrono::steady_clock::now() - idle_since < helper_idle()) {
             __builtin_ia32_pause();
             continue;
         }
@@ -2895,9 +2918,6 @@ namespace {
 
 int side_issue(Side *sd, const SideItem &it)
 {
-    static PutArgs no_put;                               // (zero-initialised: dst == NULL)
-    EnsembleArgs no_ens;
-    std::memset(&no_ens, 0, sizeof(no_ens));
     // The compaction is launched when its input is there, not before: letting its workgroups wait on the device -- resident
     // ahead of their input -- deadlocks the device as soon as anything else on it needs whole compute units in dispatch
     // order (e.g. another engine's single-launch compaction), and a one-lane wait kernel in front of it costs the side
@@ -2913,8 +2933,7 @@ int side_issue(Side *sd, const SideItem &it)
             if (sd->stop.load()) { sd->err = "side stream: stopped"; return ZRK_E_STATE; }
         }
     }
-    hipLaunchKernelGGL(k_compact_fused, dim3(it.C.nb + (it.M.m > 0 ? 1 : 0)), dim3(kCompBlock), 0, it.stream, it.C, it.by_ticket, it.M,
-                       no_ens, no_put);
+    hipLaunchKernelGGL(k_compact_side, dim3(it.C.nb + (it.M.m > 0 ? 1 : 0)), dim3(kCompBlock), 0, it.stream, it.C, it.by_ticket, it.M);
     // an exchange's collective (on the exchange's own stream) waits for this word: the list and its events are complete
     if (it.raise) hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, it.stream, it.raise, it.raise_value);
     if (hipGetLastError() != hipSuccess) { sd->err = "side stream: compaction launch failed"; return ZRK_E_HIP; }
@@ -2937,7 +2956,7 @@ void side_main(Side *sd, int device)
             continue;
         }
         if (sd->stop.load()) return;
-        if (std::chrono::steady_clock::now() - idle_since < std::chrono::milliseconds(50)) { __builtin_ia32_pause(); continue; }
+        if (std::chrono::steady_clock::now() - idle_since < helper_idle()) { __builtin_ia32_pause(); continue; }
         std::unique_lock<std::mutex> lk(sd->mu);
         sd->asleep.store(true);
         bool woken = false;
