@@ -63,7 +63,7 @@ def py_loop(k):
 
 py_loop(100)
 res["python_tick_by_tick_one_rank"] = dict(zip(("host_us_per_tick", "wall_us_per_tick"), timed(lambda: py_loop(K), K)))
-res["note"] = ("C3 shard (1e6 AirObjects, 16 radars, 7158 missiles), one MI355X; host = time the enqueueing call takes, "
+res["note"] = ("C3 shard (1e6 AirObjects, 16 radars, up to 10 000 missiles), one MI355X; host = time the enqueueing call takes, "
                "wall = until the device is idle; the exchange is a one-rank communicator (RCCL runs, nothing crosses xGMI)")
 print(json.dumps(res, indent=1))
 if "--record" in sys.argv:
