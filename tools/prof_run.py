@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """The bench's C3 tick loop (lists + missiles + Philox noise) for profiling:
     rocprofv3 --kernel-trace --stats --output-format csv -d out -- python3 tools/prof_run.py [ticks] [n] [R] [m]"""
+import os
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from zrk_modulation_amd import _lib
+if os.environ.get("ZRK_LIB"):               # a differently built library (A/B of a build-time switch)
+    _lib.LIB_PATH = _lib.CSRC / os.environ["ZRK_LIB"]
 from zrk_modulation_amd import scenario as S
 from zrk_modulation_amd.engine import HotPathEngine
 import torch
 
-import os
 ticks = int(sys.argv[1]) if len(sys.argv) > 1 else int(os.environ.get("PROF_TICKS", 300))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else int(os.environ.get("PROF_N", 1_000_000))
 R = int(sys.argv[3]) if len(sys.argv) > 3 else int(os.environ.get("PROF_R", 16))

@@ -728,7 +728,7 @@ __device__ __forceinline__ void sweep_rows(const SweepParams &P, const char *rbp
 // One pass over the table: 64 consecutive rows per wave.  ADVANCE / LIDX mirror ZRK_F_ADVANCE and
 // list_index != NULL as template parameters so that the row's column loads sit in one basic block and are all in
 // flight before anything waits for one.
-template <bool PHILOX, bool ADVANCE, bool LIDX>
+template <bool PHILOX, bool ADVANCE, bool LIDX, bool MARKS = false>
 __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, const MissileArgs M)
 {
     // the previous tick's compaction is over and visible once this grid starts: tell the exchange stream, which waits
@@ -774,7 +774,8 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     // every column load of the row is issued before anything waits for one: rows past the end read row 0
     const int64_t ic = (i < P.n) ? i : 0;
     const uint8_t al = P.alive[ic];
-    const uint32_t pk = P.pend ? (uint32_t)P.pend[ic] : 0u;
+    // (removal marks: a variant of its own -- carried along unused they cost the plain loop's sweep 0.5 us)
+    const uint32_t pk = MARKS ? (uint32_t)P.pend[ic] : 0u;
     const int32_t lix = LIDX ? P.lidx[ic] : 0;
     // (only the loads here: the arithmetic waits for them and comes after everything that does not)
     double t0 = 0.0, vx = 0.0, vy = 0.0, vz = 0.0, sx0, sy0, sz0;
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     } else {
         sx0 = P.pos[ic]; sy0 = P.pos[cap + ic]; sz0 = P.pos[2 * cap + ic];
     }
-    const bool removed = (pk != 0u) & (pk != P.mark);        // marked in an earlier tick of this call
+    const bool removed = MARKS && (pk != 0u) & (pk != P.mark);   // marked in an earlier tick of this call
     const bool live = (i < P.n) & (al != 0) & !removed;
     const int64_t li = (LIDX && i < P.n) ? (int64_t)lix : i;     // where this row sits in (its scenario's) AirEnv list
     // the wave's box record, if the caller keeps any (zrk_run_ticks does): twelve scalar words
@@ -919,7 +920,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     // sparse mode: the buffer is known to be all zero (the previous tick's compaction cleared it), so only
     // detections are written -- list-indexed stores are scattered when the table is spatially sorted
     if (i < P.n && (mask || !(P.flags & kSparseVis))) P.vis[(int64_t)scen * P.rows_ps + li] = mask;
-    if (removed && al != 0 && i < P.n) {                     // carry the removal out: once, by the row's own thread
+    if (MARKS && removed && al != 0 && i < P.n) {            // carry the removal out: once, by the row's own thread
         P.alive_w[i] = 0;
         P.pos[i] = P.pos_prev[i]; P.pos[cap + i] = P.pos_prev[cap + i]; P.pos[2 * cap + i] = P.pos_prev[2 * cap + i];
     }
@@ -2292,11 +2293,18 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
     else fill_radar_block(ctx, radars, R, flags, P.rb);
     const dim3 grid(P.nb + P.mb);                           // leading workgroups step the missiles
     using Kernel = void (*)(const SweepParams, const MissileArgs);
-    static const Kernel variants[8] = {
+    static const Kernel variants[12] = {
         k_tick_sweep<false, false, false>, k_tick_sweep<true, false, false>, k_tick_sweep<false, true, false>,
         k_tick_sweep<true, true, false>,   k_tick_sweep<false, false, true>, k_tick_sweep<true, false, true>,
-        k_tick_sweep<false, true, true>,   k_tick_sweep<true, true, true>};
-    const int which = ((flags & ZRK_F_PHILOX) ? 1 : 0) | ((flags & ZRK_F_ADVANCE) ? 2 : 0) | (P.lidx ? 4 : 0);
+        k_tick_sweep<false, true, true>,   k_tick_sweep<true, true, true>,
+        // with removal marks (the overlapped loop, always advancing)
+        k_tick_sweep<false, true, false, true>, k_tick_sweep<true, true, false, true>,
+        k_tick_sweep<false, true, true, true>,  k_tick_sweep<true, true, true, true>};
+    int which = ((flags & ZRK_F_PHILOX) ? 1 : 0) | ((flags & ZRK_F_ADVANCE) ? 2 : 0) | (P.lidx ? 4 : 0);
+    if (pend) {
+        if (!(flags & ZRK_F_ADVANCE)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: removal marks only in the advancing sweep");
+        which = 8 + ((flags & ZRK_F_PHILOX) ? 1 : 0) + (P.lidx ? 2 : 0);
+    }
     // timed: the events ride on the dispatch itself (they read the kernel's own begin and end stamps, and cost the stream
     // no packet of their own -- a pair of hipEventRecord calls around the launch costs ~3 us of idle device each)
     if (ev_start && ev_stop) hipExtLaunchKernelGGL(variants[which], grid, dim3(ZRK_BLOCK), 0, (hipStream_t)stream, ev_start, ev_stop, 0, P, M);
