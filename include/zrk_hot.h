@@ -305,8 +305,8 @@ typedef struct {
  * of a sweep's workgroups is never the same twice (it does not enter any result).
  * Environment (read at zrk_ctx_create / zrk_ctx_reload_env): ZRK_OVERLAP=0 never overlap; ZRK_OVERLAP_MIN=k from k
  * ticks per call; ZRK_OVERLAP_MIN_ROWS=n from n rows; ZRK_SWEEP_ORDER=0 sweep in table order; ZRK_COMPACT_ORDER=block|ticket; ZRK_TIME_BY_RECORDS=1 time
- * between two recorded events.  A wait on the side stream that runs out (the compute stream stalled for seconds) is
- * reported by zrk_compact_status.
+ * between two recorded events.  If the side stream's thread waits five seconds for the compute stream to reach the
+ * next sweep it gives up: the call (or the next one) fails, and zrk_compact_status reports it.
  */
 /* 1 if the last zrk_run_ticks / _x / _ensemble call of this context ran overlapped, 0 if not (diagnostics). */
 int zrk_last_run_overlapped(zrk_ctx *ctx);

@@ -2005,7 +2005,6 @@ struct SideItem {
 
 struct Side {
     hipStream_t stream = nullptr;
-    uint32_t *flag = nullptr;       // device words: [2] a wait gave up
     // the word the compute stream raises (SideItem::flag_value) lives in pinned HOST memory: the side stream's thread
     // polls it there and launches the compaction when it is up -- a one-lane wait kernel in front of every compaction
     // cost the side stream 5 us a tick (a lone wave is slow to find a slot on a device full of sweep waves)
@@ -2451,12 +2450,8 @@ ZRK_API int zrk_compact_status(zrk_ctx *ctx, void *workspace, void *stream)
     hipStream_t s = (hipStream_t)stream;
     if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(ctl, workspace, sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess)
         return fail(ctx, ZRK_E_HIP, "zrk_compact_status: copy failed");
-    if (ctx->side) {                               // overlap mode: did a wait on the side stream run out?
-        uint32_t gave_up = 0;
-        if (hipMemcpy(&gave_up, ctx->side->flag + 2, sizeof(gave_up), hipMemcpyDeviceToHost) != hipSuccess)
-            return fail(ctx, ZRK_E_HIP, "zrk_compact_status: copy failed");
-        if (gave_up) return fail(ctx, ZRK_E_STATE, "zrk_run_ticks: the side stream gave up waiting for a sweep to finish; its lists are not valid");
-    }
+    if (ctx->side && ctx->side->rc.load() != 0)    // overlap mode: the side stream's thread gave up (its lists are not valid)
+        return fail(ctx, ZRK_E_STATE, ctx->side->err);
     if (ctx->fused_ws != workspace) return 0;      // never used with this context
     if (ctl[2] == 0 && ctl[0] == 0 && ctl[1] == 0) return 0;
     ctx->fused_ws = nullptr;                       // cleared again on the next use
@@ -2980,7 +2975,6 @@ Side *side_of(zrk_ctx *ctx)
     if (ctx->side) return ctx->side;
     Side *sd = new Side;
     bool ok = hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipMalloc((void **)&sd->flag, 16) == hipSuccess && hipMemset(sd->flag, 0, 16) == hipSuccess &&
               hipHostMalloc((void **)&sd->hflag, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
               hipHostGetDevicePointer((void **)&sd->hflag_dev, (void *)sd->hflag, 0) == hipSuccess;
     if (ok) *sd->hflag = 0u;
@@ -2988,7 +2982,6 @@ Side *side_of(zrk_ctx *ctx)
     if (!ok) {
         (void)hipGetLastError();
         for (int k = 0; k <= Side::kMasks; ++k) if (sd->done[k]) (void)hipEventDestroy(sd->done[k]);
-        if (sd->flag) (void)hipFree(sd->flag);
         if (sd->hflag) (void)hipHostFree((void *)sd->hflag);
         if (sd->stream) (void)hipStreamDestroy(sd->stream);
         delete sd;
@@ -3043,7 +3036,6 @@ void side_destroy(Side *sd)
     for (int k = 0; k < Side::kMasks; ++k) if (sd->masks[k]) (void)hipFree(sd->masks[k]);
     for (int k = 0; k < Side::kMasks; ++k) if (sd->codes[k]) (void)hipFree(sd->codes[k]);
     if (sd->pend) (void)hipFree(sd->pend);
-    if (sd->flag) (void)hipFree(sd->flag);
     if (sd->hflag) (void)hipHostFree((void *)sd->hflag);
     delete sd;
 }
