@@ -1424,17 +1424,17 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_side(const CompactArgs C
     compact_block<kCompBlock>(S, C, by_ticket);
 }
 
-// Overlap mode of zrk_run_ticks: what the NEXT sweep needs of a tick's second launch -- the tombstones and the radar
-// records -- as a launch of its own (a dozen workgroups) on the compute stream, while the lists and the ordered events
-// are compacted on a side stream beside the next sweep.
-__global__ __launch_bounds__(kCompBlock) void k_tick_small(const MissileArgs M, const EnsembleArgs E, const PutArgs U)
+// Overlapped loop of an ENSEMBLE: what the next sweep needs of a tick's second launch -- the tombstones, every
+// scenario's scan step and radar records -- as a launch of its own (a dozen workgroups) on the compute stream, while
+// the lists and the ordered events are compacted on a side stream beside the next sweep.  (One scenario needs no such
+// launch: removal marks, records in the sweep's arguments.)
+__global__ __launch_bounds__(kCompBlock) void k_tick_small(const MissileArgs M, const EnsembleArgs E)
 {
     int extra = (int)blockIdx.x;
     const int kparts = (int)((M.m + kCompBlock - 1) / kCompBlock);
     if (extra < kparts) { missile_kills(M, extra); return; }
     extra -= kparts;
-    if (E.S > 0) { if ((int64_t)extra * kCompBlock < (int64_t)E.S * E.R) ensemble_derive(E, extra); return; }
-    if (U.dst && extra == 0) put_radar_block(U);
+    if (E.S > 0 && (int64_t)extra * kCompBlock < (int64_t)E.S * E.R) ensemble_derive(E, extra);
 }
 
 // SectorRadar.smooth_objects with supplied draws: pos[idx[j]] += noise[j].
@@ -3314,9 +3314,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (prof && !on_dispatch && rc == 0 && hipEventRecord(ev[2 * (k / stride) + 1], s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipEventRecord");
         if (sd) {
             if (rc != 0) break;
-            // compute stream: what the next sweep needs (the next sweep's first thread, or the launch behind the loop,
-            // releases the side stream: beside this small launch the compaction would only be in its way)
-            static PutArgs no_put;
+            // (the next sweep's first thread, or a launch behind the loop, tells the side stream's thread that this tick's
+            // launches on the compute stream are over)
             const int eparts = ens ? nblocks((int64_t)EL.next.S * EL.next.R, kCompBlock) : 0;
             const int small_grid = std::max(1, nblocks(M.m, kCompBlock) + eparts);
             SideItem it;
@@ -3328,7 +3327,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             if (rc != 0) break;
             const uint32_t v = ++sd->seq;
             if (ens) {
-                hipLaunchKernelGGL(k_tick_small, dim3(small_grid), dim3(kCompBlock), 0, s, M, EL.next, no_put);
+                hipLaunchKernelGGL(k_tick_small, dim3(small_grid), dim3(kCompBlock), 0, s, M, EL.next);
                 if ((rc = check_launch(ctx, "k_tick_small")) != 0) break;
             }
             if (ev_words && !fused && hipMemsetAsync(list + list_words, 0, sizeof(int64_t), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset events"); break; }
