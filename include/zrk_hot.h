@@ -304,7 +304,8 @@ typedef struct {
  * (ents->vis_mask / vis_mask_alt hold the last tick's, as st->vis_cur says), likewise mis->ev_code; the dispatch order
  * of a sweep's workgroups is never the same twice (it does not enter any result).
  * Environment (read at zrk_ctx_create / zrk_ctx_reload_env): ZRK_OVERLAP=0 never overlap; ZRK_OVERLAP_MIN=k from k
- * ticks per call; ZRK_OVERLAP_MIN_ROWS=n from n rows; ZRK_SWEEP_ORDER=0 sweep in table order; ZRK_COMPACT_ORDER=block|ticket; ZRK_TIME_BY_RECORDS=1 time
+ * ticks per call; ZRK_OVERLAP_MIN_ROWS=n from n rows; ZRK_GATHER_RECORDS=0 the missile phase reads its targets from the
+ * columns instead of the 64-byte records the loop keeps per row (64 B x capacity of device memory, the context's); ZRK_SWEEP_ORDER=0 sweep in table order; ZRK_COMPACT_ORDER=block|ticket; ZRK_TIME_BY_RECORDS=1 time
  * between two recorded events.  If the side stream's thread waits five seconds for the compute stream to reach the
  * next sweep it gives up: the call (or the next one) fails, and zrk_compact_status reports it.
  */

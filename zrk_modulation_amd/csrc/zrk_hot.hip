@@ -171,6 +171,10 @@ struct MissileArgs {
     int64_t gid0;               // global list index of list element 0 (indices on the wire are global)
     uint8_t *pend;              // overlapped loop: removals as marks (see SweepParams::pend); NULL: tombstones by the finisher
     uint32_t mark, _pad3;       // this tick's mark value
+    // per-row gather records, 64 bytes: start_pos, velocity, start_time, list index -- what a missile needs of its TARGET
+    // from one cache line instead of eight (ten thousand missiles' gathers were a tenth of the sweep's traffic); kept
+    // by zrk_run_ticks (ensure_gather_records), NULL: the columns
+    const double *grec;
 };
 
 // Dispatch order of the next sweep.  The sweep's duration is set by the expensive waves (rows inside some
@@ -448,7 +452,7 @@ __device__ uint8_t missile_step_row(const double *__restrict__ sp, const double 
                                     const int32_t *__restrict__ m_slot, const int32_t *__restrict__ m_tgt,
                                     const double *__restrict__ m_radius, double *__restrict__ m_period,
                                     uint8_t *__restrict__ m_status, int64_t row, double t, double dts,
-                                    uint8_t *pend = nullptr, uint32_t mark = 0);
+                                    uint8_t *pend = nullptr, uint32_t mark = 0, const double *grec = nullptr);
 
 // Horizontal bounding box of the wave: two minima and two maxima over the 64 lanes, wave-uniform on return.
 // min / max are idempotent, so rotations inside each row of 16 (by 1, 2, 4, 8) and the two row broadcasts
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
         const int64_t row = (int64_t)blockIdx.x * ZRK_BLOCK + threadIdx.x;
         if (row < M.m)
             M.ev_code[row] = missile_step_row(M.sp, M.vel, M.t0, M.alive, M.lidx, M.pos_prev, M.cap, M.m_slot, M.m_tgt,
-                                              M.m_radius, M.m_period, M.m_status, row, M.t, M.dts, M.pend, M.mark);
+                                              M.m_radius, M.m_period, M.m_status, row, M.t, M.dts, M.pend, M.mark, M.grec);
         return;
     }
     const int tid = threadIdx.x;
@@ -1456,7 +1460,7 @@ __device__ uint8_t missile_step_row(const double *__restrict__ sp, const double 
                                     const int32_t *__restrict__ m_slot, const int32_t *__restrict__ m_tgt,
                                     const double *__restrict__ m_radius, double *__restrict__ m_period,
                                     uint8_t *__restrict__ m_status, int64_t row, double t, double dts,
-                                    uint8_t *pend, uint32_t mark)
+                                    uint8_t *pend, uint32_t mark, const double *grec)
 {
     uint8_t code = 0;
     const int32_t s = m_slot[row];
@@ -1466,12 +1470,26 @@ __device__ uint8_t missile_step_row(const double *__restrict__ sp, const double 
                      pz = sp[2 * cap + s] + vel[2 * cap + s] * d;
         const int32_t j = m_tgt[row];
         double tx, ty, tz;
-        const bool earlier = lidx ? (lidx[j] < lidx[s]) : (j < s);
+        // the target's trajectory and list index: one 64-byte record, or seven columns and the index column
+        double g[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        int32_t lj = j;
+        if (grec) {
+            const double *r = grec + 8 * (int64_t)j;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) g[q] = r[q];
+            lj = (int32_t)(uint32_t)__builtin_bit_cast(uint64_t, g[7]);
+        } else if (lidx) lj = lidx[j];
+        const bool earlier = lidx ? (lj < lidx[s]) : (j < s);
         bool there = alive[j] != 0;
         if (pend) { const uint32_t pj = pend[j]; there = there && !(pj != 0u && pj != mark); }   // (removed last tick: not yet carried out, perhaps)
         if (there && earlier) {           // already stepped this tick (list order): fresh, noise-free
-            const double dj = t - t0[j];
-            tx = sp[j] + vel[j] * dj; ty = sp[cap + j] + vel[cap + j] * dj; tz = sp[2 * cap + j] + vel[2 * cap + j] * dj;
+            if (grec) {
+                const double dj = t - g[6];
+                tx = g[0] + g[3] * dj; ty = g[1] + g[4] * dj; tz = g[2] + g[5] * dj;
+            } else {
+                const double dj = t - t0[j];
+                tx = sp[j] + vel[j] * dj; ty = sp[cap + j] + vel[cap + j] * dj; tz = sp[2 * cap + j] + vel[2 * cap + j] * dj;
+            }
         } else {                          // not stepped yet, or removed: what it held after last tick
             tx = pos_prev[j]; ty = pos_prev[cap + j]; tz = pos_prev[2 * cap + j];
         }
@@ -1650,6 +1668,19 @@ __global__ void k_events_wire(const int32_t *__restrict__ ev_missile, const int3
         ev_wire[1 + j] = (int64_t)(((uint64_t)(gid0 + (lidx ? lidx[ms] : ms)) << 32) |
                                    (ts >= 0 ? (uint64_t)(uint32_t)(gid0 + (lidx ? lidx[ts] : ts)) : 0xFFFFFFFFull));
     }
+}
+
+// Gather records (MissileArgs::grec) of rows [lo, hi) from the columns.
+__global__ void k_build_gather_records(const double *__restrict__ sp, const double *__restrict__ vel, const double *__restrict__ t0,
+                                       const int32_t *__restrict__ lidx, int64_t cap, int64_t lo, int64_t hi, double *__restrict__ grec)
+{
+    const int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    double *r = grec + 8 * i;
+    r[0] = sp[i]; r[1] = sp[cap + i]; r[2] = sp[2 * cap + i];
+    r[3] = vel[i]; r[4] = vel[cap + i]; r[5] = vel[2 * cap + i];
+    r[6] = t0[i];
+    r[7] = __builtin_bit_cast(double, (uint64_t)(uint32_t)(lidx ? lidx[i] : (int32_t)i));
 }
 
 // Overlapped loop, behind the last tick of a call: the removals that tick decided (marks nobody has carried out yet)
@@ -2078,6 +2109,13 @@ struct zrk_ctx {
     int overlap_min = 4;
     int64_t overlap_min_rows = 400000; // ZRK_OVERLAP_MIN_ROWS: below, the compaction is too short for the third launch to pay
     int last_overlapped = 0;           // whether the last zrk_run_ticks* call ran overlapped
+    // gather records of the table's rows for the missile phase (MissileArgs::grec), kept like the box records: for
+    // this table (its start_pos column), up to this many rows; rebuilt when the key changes, when rows were rewritten
+    // under the loop (zrk_ctx_invalidate_boxes) and for rows appended since
+    double *grec = nullptr;
+    int64_t grec_rows = 0, grec_n = 0;
+    const void *grec_key = nullptr;
+    bool grec_enabled = true;          // ZRK_GATHER_RECORDS=0: the columns
 };
 
 namespace {
@@ -2146,7 +2184,7 @@ ZRK_API int zrk_abi_version(void) { return ZRK_ABI_VERSION; }
 
 ZRK_API void zrk_ctx_invalidate_boxes(zrk_ctx *ctx)
 {
-    if (ctx) { ctx->box_ws = nullptr; ctx->box_n = 0; }
+    if (ctx) { ctx->box_ws = nullptr; ctx->box_n = 0; ctx->grec_n = 0; }
 }
 
 ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
@@ -2159,6 +2197,7 @@ ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
     { const char *v = std::getenv("ZRK_OVERLAP"); c->overlap = v ? std::atoi(v) : 1; }
     { const char *v = std::getenv("ZRK_OVERLAP_MIN"); c->overlap_min = v ? std::max(2, std::atoi(v)) : 4; }
     { const char *v = std::getenv("ZRK_OVERLAP_MIN_ROWS"); c->overlap_min_rows = v ? std::atoll(v) : 400000; }
+    { const char *v = std::getenv("ZRK_GATHER_RECORDS"); c->grec_enabled = !(v && v[0] == '0'); }
     if (const char *v = std::getenv("ZRK_COMPACT_ITEMS")) c->env_items = std::max(1, std::atoi(v));
     if (const char *v = std::getenv("ZRK_COMPACT_ORDER")) c->env_order = std::strcmp(v, "block") != 0;
     c->fused_max_blocks = kFusedMaxBlocks;
@@ -2190,6 +2229,7 @@ ZRK_API void zrk_ctx_destroy(zrk_ctx *ctx)
 {
     if (!ctx) return;
     side_destroy(ctx->side);
+    if (ctx->grec) (void)hipFree(ctx->grec);
     for (hipEvent_t e : ctx->tev) (void)hipEventDestroy(e);
     delete ctx;
 }
@@ -2225,7 +2265,7 @@ MissileArgs missile_args(const zrk_entities *e, int cur, const zrk_missiles *mis
     M.m = m;
     M.t = (double)time_ms / 1000.0; M.dts = (double)dt_ms / 1000.0;
     M.apply = apply; M.ev_wire_cap = 0; M.ev_wire = nullptr; M.gid0 = 0;
-    M.pend = nullptr; M.mark = 0; M._pad3 = 0;
+    M.pend = nullptr; M.mark = 0; M._pad3 = 0; M.grec = nullptr;
     return M;
 }
 
@@ -3206,6 +3246,26 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (hipStreamSynchronize(s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
         fx->seq = 0;
     }
+    // the missile phase's gather records (MissileArgs::grec): for tables whose missile phase rides in the sweep
+    const double *grec = nullptr;
+    if (ctx->grec_enabled && m > 0 && m <= 1024 * (int64_t)kMissileItems && st->n > 0 && R > 0 && (det_idx || packed || xio)) {
+        if (ctx->grec_rows < e->capacity) {
+            if (ctx->grec) (void)hipFree(ctx->grec);
+            ctx->grec = nullptr; ctx->grec_rows = 0; ctx->grec_n = 0;
+            if (hipMalloc((void **)&ctx->grec, sizeof(double) * 8 * (size_t)e->capacity) != hipSuccess) (void)hipGetLastError();   // (then: the columns)
+            else ctx->grec_rows = e->capacity;
+        }
+        if (ctx->grec) {
+            if (ctx->grec_key != (const void *)e->start_pos || st->n < ctx->grec_n) { ctx->grec_key = e->start_pos; ctx->grec_n = 0; }
+            if (ctx->grec_n < st->n) {
+                hipLaunchKernelGGL(k_build_gather_records, dim3(nblocks(st->n - ctx->grec_n, 256)), dim3(256), 0, s, e->start_pos, e->velocity,
+                                   e->start_time, e->list_index, e->capacity, ctx->grec_n, st->n, ctx->grec);
+                if (int rc0 = check_launch(ctx, "k_build_gather_records")) return rc0;
+                ctx->grec_n = st->n;
+            }
+            grec = ctx->grec;
+        }
+    }
     struct { bool on; int slot; int64_t *list; uint32_t value; } pend = {false, 0, nullptr, 0u};
     struct { bool on; SideItem it; int slot; int64_t *list; } held;
     held.on = false;
@@ -3235,6 +3295,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         // finishing workgroup, or ticks without compaction, take the stand-alone launches instead.
         const bool fused = m > 0 && m <= 1024 * (int64_t)kMissileItems && (det_idx || list) && st->n > 0 && R > 0;
         MissileArgs M = fused ? missile_args(e, st->cur, mis, m, st->time_ms, st->dt_ms, 1) : no_missiles();
+        if (fused) M.grec = grec;
         if (fused && ev_words) { M.ev_wire = list + list_words; M.ev_wire_cap = xio->ev_capacity; M.gid0 = st->gid0; }
         // two mask buffers: tick t writes only its detections into one (cleared by the previous tick's
         // scatter) while its own scatter clears the other for tick t+1.  The first tick on a pair of buffers
