@@ -136,3 +136,32 @@ def test_several_missiles_on_one_target(monkeypatch):
     done_per_target = np.bincount(np.asarray(st.hm_tgt[:st.m])[status == 2], minlength=1)
     assert done_per_target.max() >= 3, "several missiles of one target should have detonated or timed out"
     assert removed_late > 0
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_gather_records_follow_the_table(overlap, monkeypatch):
+    """The missile phase reads its targets from 64-byte records that zrk_run_ticks keeps per row (built for the rows
+    appended since the last call).  A second and a third salvo between calls append rows: same state as an engine that
+    reads the columns (ZRK_GATHER_RECORDS=0), after every call."""
+    from tests.test_gpu_engine import _engine
+    from zrk_modulation_amd import scenario as S
+    n, R, m = 50_000, 6, 900
+    monkeypatch.setenv("ZRK_OVERLAP_MIN_ROWS", "0")
+    monkeypatch.setenv("ZRK_OVERLAP", overlap)
+    engines = []
+    for rec in ("1", "0"):
+        monkeypatch.setenv("ZRK_GATHER_RECORDS", rec)
+        eng, _, launched = _engine(n, R, 300, seed=9, noise="philox")
+        assert launched > 50
+        engines.append(eng)
+    a_eng, b_eng = engines
+    later = S.missile_targets(n, 300) + 57                       # other targets for the later salvos
+    for calls, K in enumerate([6, 5, 9, 4, 12, 7]):
+        for eng in engines:
+            eng.run(K)
+        _same(_state(a_eng), _state(b_eng), f"after call {calls} of {K} ticks")
+        if calls in (0, 2):
+            got = [eng.launch_missiles((later + 1000 * calls) % n, launcher_pos=(500.0, -300.0, 0.0), speed=2800.0, radius=900.0, period=20.0)
+                   for eng in engines]
+            assert got[0] == got[1] and got[0] > 50
+    assert a_eng.store.m > 450
