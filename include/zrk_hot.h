@@ -117,8 +117,10 @@ void zrk_ctx_destroy(zrk_ctx *ctx);
  * this reads them again. */
 void zrk_ctx_reload_env(zrk_ctx *ctx);
 /* zrk_run_ticks keeps, in the workspace, a bounding box per block of table rows between ticks (rows move along
- * straight lines, so an old box grown by the block's top speed still holds them).  It notices rows appended to the
- * table by itself; a caller that rewrites the trajectory or the alive flag of EXISTING rows says so here. */
+ * straight lines, so an old box grown by the block's top speed still holds them), and, in memory of the context, a
+ * 64-byte record of every row's trajectory and list index for the missile phase's gathers.  It notices rows appended
+ * to the table by itself; a caller that rewrites the trajectory, the list index or the alive flag of EXISTING rows
+ * says so here. */
 void zrk_ctx_invalidate_boxes(zrk_ctx *ctx);
 const char *zrk_last_error(zrk_ctx *ctx);
 

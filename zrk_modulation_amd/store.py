@@ -272,8 +272,8 @@ class EntityStore:
 
     def overwrite_rows(self, rows, start_pos, velocity, start_time, kind=0):
         """Give existing (padding) rows a trajectory and bring them to life, in place: what a batched ensemble does
-        when a missile enters the air in a scenario's block of rows (the rows keep their list index).  The caller
-        tells the loop that rows changed under it (zrk_ctx_invalidate_boxes)."""
+        when a missile enters the air in a scenario's block of rows (the rows keep their list index).  Tells the loop
+        that rows changed under it (zrk_ctx_invalidate_boxes)."""
         rows = np.asarray(rows, np.int64)
         k = len(rows)
         sp = np.asarray(start_pos, np.float64).reshape(k, 3); vel = np.asarray(velocity, np.float64).reshape(k, 3)
@@ -291,6 +291,9 @@ class EntityStore:
         self.d_pos[0][:, r] = dsp
         self.d_pos[1][:, r] = dsp
         self.d_alive[r] = 1
+        # rows changed under the loop: its box records and gather records of them are stale (the call is cheap, and a
+        # caller that forgets it would get wrong detections, not an error)
+        self.lib.zrk_ctx_invalidate_boxes(self.ctx.handle)
         self._bump()
 
     def add_missile_row(self, slot, target_slot, radius, period):
