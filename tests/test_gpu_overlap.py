@@ -165,3 +165,46 @@ def test_gather_records_follow_the_table(overlap, monkeypatch):
                    for eng in engines]
             assert got[0] == got[1] and got[0] > 50
     assert a_eng.store.m > 450
+
+
+def test_overlapped_calls_match_the_oracle_directly():
+    """The overlapped loop against the ORACLE, without the two-launch loop in between: a table large enough for the
+    default thresholds (no environment set), calls of 8 and 6 ticks; the oracle is ticked the same number of times on
+    the host (with the noise table the device will draw), then masks, position bits, detonation events and lists of
+    the call's last tick, the flags and the radars' scan state must be the oracle's."""
+    from tests.test_gpu_engine import OracleMirror, _compare_tick, _device_noise_table
+    from zrk_modulation_amd import scenario as S
+    from zrk_modulation_amd.engine import HotPathEngine
+    n, R, m = 640_000, 7, 2000
+    ids, sp, vel, t0 = S.synthetic_targets(n, 99)
+    radars = S.synthetic_radars(R)
+    g = np.random.Generator(np.random.PCG64(100))
+    for k, rd in enumerate(radars):
+        rd["max_distance"] = float(g.uniform(2e4, 6e4)); rd["azimuth_start"] = float(g.uniform(0, 360))
+        rd["azimuth_range"] = float(g.uniform(20, 200)); rd["elevation_range"] = float(g.uniform(10, 90))
+        rd["azimuth_speed"] = float(g.uniform(1, 30)); rd["elevation_speed"] = float(g.uniform(0, 5))
+        rd["position"] = [float(v) for v in g.normal(0, 8e3, 3) * [1, 1, 0.05]]
+        if k == 4:
+            rd["scan_mode"] = "vertical"
+    eng = HotPathEngine(device="cuda:0", dt_ms=250, seed=31337, noise="philox")
+    eng.load(ids, sp, vel, t0, radars, missile_capacity=m).enable_lists()
+    assert eng.launch_missiles(S.missile_targets(n, m), speed=2500.0, radius=500.0, period=45.0) > 100
+    mir = OracleMirror(eng, radars)
+    tick = 0
+    seen_events = 0
+    for K in (8, 6):
+        events = None
+        for _ in range(K):
+            table = _device_noise_table(eng, tick, R, mir.n)
+            events = mir.tick(tick * 250, 250, 2, table, threads=16)
+            seen_events += len(events)
+            tick += 1
+        eng.run(K)
+        assert eng.store.lib.zrk_last_run_overlapped(eng.store.ctx.handle) == 1
+        vis, alive = _compare_tick(eng, mir, events, f"after {tick} ticks")
+        lists = eng.detections()
+        for r, want in enumerate(mir.lists()):
+            assert np.array_equal(lists[r], want), f"after {tick} ticks: radar {r}"
+        assert eng.radar_state() == [(r["caz"], r["cel"]) for r in mir.rs]
+        assert np.count_nonzero(vis) > 1000
+    assert seen_events > 0
