@@ -391,7 +391,7 @@ def main():
 
     def max_count():
         if state["c_side"]:
-            return max(max(xchg["x"].counts(0)), max(xchg["x"].counts(1)))
+            return max(max(xchg["x"].counts(k)) for k in range(xchg["x"].slots))
         return max(max(e.counts()) for e in xchg["ex"])
 
     if exchanging:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ZRK_ABI_VERSION 4
+#define ZRK_ABI_VERSION 5
 #define ZRK_MAX_RADARS 32           /* one bit per radar in the visibility mask */
 #define ZRK_BLOCK 256               /* table rows per sweep workgroup */
 
@@ -329,6 +329,9 @@ int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *ents, const zrk_missiles *mi
  * beside the next tick's sweep.  Rank 0 makes the id and hands it to the others by any means (128 bytes).
  */
 typedef struct { char internal[128]; } zrk_rccl_id;          /* ncclUniqueId */
+/* Lists in flight: a tick's list is rewritten ZRK_EXCHANGE_SLOTS ticks later, and its collective must be through by
+ * then (two were enough for correctness; four keep a late collective from ever stalling the compute stream's host). */
+#define ZRK_EXCHANGE_SLOTS 4
 typedef struct zrk_exchange zrk_exchange;
 
 int zrk_exchange_unique_id(const char *rccl_path, zrk_rccl_id *id /* HOST out */);
@@ -338,7 +341,7 @@ int zrk_exchange_create(const char *rccl_path, const zrk_rccl_id *id, int world,
 void zrk_exchange_destroy(zrk_exchange *x);
 const char *zrk_exchange_last_error(zrk_exchange *x);
 /* One all-gather of `words` 64-bit words per rank: recv = [world][words].  Enqueued on the exchange's stream
- * behind everything `stream` holds so far; two slots (0 / 1) may be in flight. */
+ * behind everything `stream` holds so far; ZRK_EXCHANGE_SLOTS slots may be in flight. */
 int zrk_exchange_all_gather(zrk_exchange *x, int slot, const int64_t *send /* DEVICE */, int64_t *recv /* DEVICE */,
                             int64_t words, void *stream);
 /* The last all-gather posted on `slot` is over before anything launched on `stream` after this call runs (nothing if
@@ -360,8 +363,8 @@ int zrk_exchange_sync(zrk_exchange *x);
  * Tick t uses slot t & 1 of send / recv. */
 typedef struct {
     zrk_exchange *x;
-    int64_t *send[2];               /* DEVICE [words] */
-    int64_t *recv[2];               /* DEVICE [world][words] */
+    int64_t *send[ZRK_EXCHANGE_SLOTS];   /* DEVICE [words]; tick t goes through slot t % ZRK_EXCHANGE_SLOTS */
+    int64_t *recv[ZRK_EXCHANGE_SLOTS];   /* DEVICE [world][words] */
     int64_t words;                  /* zrk_union_bits_words(capacity, R, entries) + (ev_capacity ? 1 + ev_capacity : 0) */
     int32_t ev_capacity;
     int32_t _pad;

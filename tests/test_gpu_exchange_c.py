@@ -25,7 +25,7 @@ def test_c_side_exchange_carries_the_same_list_and_events_as_the_plain_loop():
     for k in range(40):
         eng_a.run(1)
         eng_b.run(1, exchange=x)
-        slot = k & 1
+        slot = k % x.slots
         idx, msk = x.merged(slot)
         st = eng_a.store
         vis = st.vis()[:st.n_uploaded].cpu().numpy().view(np.uint32)
@@ -61,12 +61,12 @@ def test_k_ticks_per_call_with_the_exchange(env, monkeypatch):
     x = RcclExchange(union_bits_words(eng_b.store.cap, R, eng_b.store.cap), eng_b.store.device, R, offsets=[0], ev_capacity=128)
     st = eng_a.store
     for calls in range(3):
-        eng_b.run(9, exchange=x)       # an odd count: the last tick of the call alternates between the slots
+        eng_b.run(9, exchange=x)       # (a count that walks the last tick of the call through the slots)
         x.sync()
-        last = (9 * (calls + 1) - 1) & 1
+        last = (9 * (calls + 1) - 1) % x.slots
         eng_a.run(8)
         vis = st.vis()[:st.n_uploaded].cpu().numpy().view(np.uint32)
-        idx, msk = x.merged(last ^ 1)  # the second last tick: handed over by the flag
+        idx, msk = x.merged((last - 1) % x.slots)  # the second last tick: handed over by the flag
         assert np.array_equal(idx.cpu().numpy(), np.nonzero(vis)[0]), f"call {calls}: list of the second last tick differs"
         assert np.array_equal(msk.cpu().numpy().astype(np.uint32), vis[np.nonzero(vis)[0]])
         eng_a.run(1)

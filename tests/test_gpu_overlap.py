@@ -81,7 +81,7 @@ def test_overlap_with_the_exchange_on_one_rank(monkeypatch):
         x.sync()
         for back in (1, 0):                                      # second last tick, then the last one
             ref.run(K - 1 if back else 1)
-            slot = (tick + (K - 2 if back else K - 1)) & 1
+            slot = (tick + (K - 2 if back else K - 1)) % x.slots
             vis = st.vis()[:st.n_uploaded].cpu().numpy().view(np.uint32)
             idx, msk = x.merged(slot)
             want = np.nonzero(vis)[0]

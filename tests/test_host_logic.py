@@ -29,7 +29,7 @@ def test_ctypes_structs_match_the_header_layout():
     assert C.sizeof(_lib.ZrkMissiles) == 8 * 10
     assert C.sizeof(_lib.ZrkLaunchReq) == 56 and C.sizeof(_lib.ZrkLaunchRes) == 40
     assert C.sizeof(_lib.ZrkScan) == 32 and C.sizeof(_lib.ZrkLoop) == 64
-    assert C.sizeof(_lib.ZrkRcclId) == 128 and C.sizeof(_lib.ZrkExchangeIo) == 56 and C.sizeof(_lib.ZrkEnsemble) == 56
+    assert C.sizeof(_lib.ZrkRcclId) == 128 and C.sizeof(_lib.ZrkExchangeIo) == 8 + 2 * 8 * _lib.EXCHANGE_SLOTS + 16 and C.sizeof(_lib.ZrkEnsemble) == 56
     _lib.launch_dtypes()                      # numpy views of the launch records agree with the structs
 
 

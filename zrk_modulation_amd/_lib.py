@@ -14,7 +14,8 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = CSRC / "libzrk_hot.so"
 
-ZRK_ABI_VERSION = 4
+ZRK_ABI_VERSION = 5
+EXCHANGE_SLOTS = 4          # ZRK_EXCHANGE_SLOTS
 ZRK_MAX_RADARS = 32
 ZRK_BLOCK = 256
 F_ADVANCE, F_PHILOX, F_EXACT_ONLY, F_UNION_BITS = 1, 2, 4, 8
@@ -127,8 +128,8 @@ class ZrkRcclId(C.Structure):
 class ZrkExchangeIo(C.Structure):
     _fields_ = [
         ("x", C.c_void_p),
-        ("send", C.c_void_p * 2),
-        ("recv", C.c_void_p * 2),
+        ("send", C.c_void_p * EXCHANGE_SLOTS),
+        ("recv", C.c_void_p * EXCHANGE_SLOTS),
         ("words", C.c_int64),
         ("ev_capacity", C.c_int32),
         ("_pad", C.c_int32),

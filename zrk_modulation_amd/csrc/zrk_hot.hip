@@ -2714,8 +2714,8 @@ struct zrk_exchange {
     void *comm = nullptr;
     int world = 1, rank = 0, device = 0;
     hipStream_t cstream = nullptr;
-    hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
-    bool posted[2] = {false, false};
+    hipEvent_t ready[ZRK_EXCHANGE_SLOTS] = {}, done[ZRK_EXCHANGE_SLOTS] = {};
+    bool posted[ZRK_EXCHANGE_SLOTS] = {};
     // hand-over by flag (zrk_run_ticks_x): a word of device memory that the NEXT tick's sweep raises to `seq` as it starts;
     // a one-lane kernel on the exchange stream waits for the value (flag[1]: it gave up).  NULL (ZRK_EXCHANGE_EVENTS=1):
     // an event per tick on the compute stream instead
@@ -2728,7 +2728,7 @@ struct zrk_exchange {
     static constexpr uint64_t kRing = 8;
     PostItem ring[kRing];
     std::atomic<uint64_t> head{0}, tail{0};             // items handed to the thread / items it has issued
-    uint64_t item_no[2] = {0, 0};                       // per slot: `head` after its last item went in
+    uint64_t item_no[ZRK_EXCHANGE_SLOTS] = {};          // per slot: `head` after its last item went in
     std::thread poster;
     std::mutex mu;
     std::condition_variable cv;
@@ -2827,7 +2827,7 @@ ZRK_API int zrk_exchange_create(const char *rccl_path, const zrk_rccl_id *id, in
         return ZRK_E_HIP;
     }
     bool ok = hipStreamCreateWithFlags(&x->cstream, hipStreamNonBlocking) == hipSuccess;
-    for (int k = 0; k < 2 && ok; ++k)
+    for (int k = 0; k < ZRK_EXCHANGE_SLOTS && ok; ++k)
         ok = hipEventCreateWithFlags(&x->ready[k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&x->done[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) { x->err = "stream / event creation failed"; return ZRK_E_HIP; }
@@ -2854,7 +2854,7 @@ ZRK_API void zrk_exchange_destroy(zrk_exchange *x)
     }
     if (x->cstream) (void)hipStreamSynchronize(x->cstream);
     if (x->comm) (void)x->api.CommDestroy(x->comm);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < ZRK_EXCHANGE_SLOTS; ++k) {
         if (x->ready[k]) (void)hipEventDestroy(x->ready[k]);
         if (x->done[k]) (void)hipEventDestroy(x->done[k]);
     }
@@ -2867,7 +2867,7 @@ ZRK_API const char *zrk_exchange_last_error(zrk_exchange *x) { return x ? x->err
 
 ZRK_API int zrk_exchange_all_gather(zrk_exchange *x, int slot, const int64_t *send, int64_t *recv, int64_t words, void *stream)
 {
-    if (!x || !x->comm || !send || !recv || words <= 0 || (slot != 0 && slot != 1)) return ZRK_E_INVALID;
+    if (!x || !x->comm || !send || !recv || words <= 0 || slot < 0 || slot >= ZRK_EXCHANGE_SLOTS) return ZRK_E_INVALID;
     if (exchange_drain(x, x->head.load()) != 0) return ZRK_E_HIP;      // behind whatever the exchange's thread still had to issue
     if (hipEventRecord(x->ready[slot], (hipStream_t)stream) != hipSuccess ||
         hipStreamWaitEvent(x->cstream, x->ready[slot], 0) != hipSuccess) { x->err = "event hand-over to the exchange stream failed"; return ZRK_E_HIP; }
@@ -2920,10 +2920,10 @@ int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, in
 
 ZRK_API int zrk_exchange_wait(zrk_exchange *x, int slot, void *stream)
 {
-    if (!x || (slot != 0 && slot != 1)) return ZRK_E_INVALID;
+    if (!x || slot < 0 || slot >= ZRK_EXCHANGE_SLOTS) return ZRK_E_INVALID;
     if (exchange_drain(x, x->item_no[slot]) != 0) return ZRK_E_HIP;    // its collective has been issued (by the exchange's thread)
     if (!x->posted[slot]) return 0;
-    // usually that collective is long over (it was posted two ticks ago): then the host knows, and the stream is spared a
+    // usually that collective is long over (it was posted ZRK_EXCHANGE_SLOTS ticks ago): then the host knows, and the stream is spared a
     // barrier packet, which costs it more than the wait it would do
     if (hipEventQuery(x->done[slot]) == hipSuccess) return 0;
     // not yet -- mostly because the host runs ticks ahead of the device.  Waiting HERE (the host is then at most two ticks
@@ -3105,7 +3105,9 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     if (K < 0 || (st->cur != 0 && st->cur != 1)) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: K/cur out of range");
     if (xio) {
         if (packed) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: `packed` and an exchange are alternatives");
-        if (!xio->x || !xio->send[0] || !xio->send[1] || !xio->recv[0] || !xio->recv[1] || xio->ev_capacity < 0 ||
+        bool buffers = true;
+        for (int k = 0; k < ZRK_EXCHANGE_SLOTS; ++k) buffers = buffers && xio->send[k] && xio->recv[k];
+        if (!xio->x || !buffers || xio->ev_capacity < 0 ||
             xio->words < 3 + xio->ev_capacity + (xio->ev_capacity > 0 ? 1 : 0))
             return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: incomplete exchange description");
         if (!(st->flags & ZRK_F_UNION_BITS)) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: the exchange carries the wire format (ZRK_F_UNION_BITS)");
@@ -3286,7 +3288,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         const bool prof = n_prof && (k % stride == 0);
         const bool on_dispatch = prof && ctx->time_on_dispatch && (st->n > 0 || (m > 0 && m <= 1024 * (int64_t)kMissileItems));
         if (prof && !on_dispatch && hipEventRecord(ev[2 * (k / stride)], s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "hipEventRecord"); break; }
-        const int slot = (int)(st->tick & 1u);
+        const int slot = (int)(st->tick % (uint64_t)ZRK_EXCHANGE_SLOTS);
         int64_t *list = xio ? xio->send[slot] : packed;
         const int64_t list_words = xio ? xio->words - ev_words : packed_capacity;
         // Missiles read last tick's positions (pos[cur^1]) and trajectories only, so their per-row step rides in
@@ -3396,7 +3398,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             it.M = M; it.M.apply = 0;
             if (xio) {
                 // The collective of this tick runs on the exchange's own stream, released by a launch behind the compaction.
-                // The list it sends was last sent two ticks ago, and that collective must be through before the compaction
+                // The list it sends was last sent ZRK_EXCHANGE_SLOTS ticks ago, and that collective must be through before the compaction
                 // may write it -- checked as late as possible, i.e. when the NEXT sweep has been launched (the item is
                 // held until then: the side stream cannot start it before that sweep runs anyway), so that a late
                 // collective never delays a launch on the compute stream.
@@ -3411,7 +3413,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             st->tick += 1;
             continue;
         }
-        // this slot's list was last sent two ticks ago: that collective must have read it before it is rewritten
+        // this slot's list was last sent ZRK_EXCHANGE_SLOTS ticks ago: that collective must have read it before it is rewritten
         if (rc == 0 && xio && zrk_exchange_wait(xio->x, slot, stream) != 0) rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
         if (rc == 0 && two_vis) { ctx->ring_clean[st->vis_cur] = false; ctx->ring_clean[st->vis_cur ^ 1] = true; }
         if (rc == 0 && (det_idx || list))

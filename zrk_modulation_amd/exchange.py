@@ -127,12 +127,13 @@ class RcclExchange:
         self._allocate()
 
     def _allocate(self):
-        self.send = [torch.zeros(self.words, dtype=torch.int64, device=self.device) for _ in range(2)]
-        self.recv = [torch.zeros(self.world, self.words, dtype=torch.int64, device=self.device) for _ in range(2)]
+        self.slots = self._lib_mod.EXCHANGE_SLOTS      # tick t goes through slot t % slots
+        self.send = [torch.zeros(self.words, dtype=torch.int64, device=self.device) for _ in range(self.slots)]
+        self.recv = [torch.zeros(self.world, self.words, dtype=torch.int64, device=self.device) for _ in range(self.slots)]
         io = self._lib_mod.ZrkExchangeIo()
         io.x = self.handle
-        io.send[0], io.send[1] = self.send[0].data_ptr(), self.send[1].data_ptr()
-        io.recv[0], io.recv[1] = self.recv[0].data_ptr(), self.recv[1].data_ptr()
+        for k in range(self.slots):
+            io.send[k], io.recv[k] = self.send[k].data_ptr(), self.recv[k].data_ptr()
         io.words, io.ev_capacity = self.words, self.ev_capacity
         self.io = io
 
@@ -153,7 +154,7 @@ class RcclExchange:
 
     def room(self):
         """Masks a rank's list has room for, given the largest shard seen so far."""
-        n = int(max(self.recv[0][:, 1].max().item(), self.recv[1][:, 1].max().item()))
+        n = int(max(r[:, 1].max().item() for r in self.recv))
         body = self.words - (1 + self.ev_capacity if self.ev_capacity else 0) - 2 - (n + 63) // 64
         return body * (4 if self.R <= 16 else 2)
 
@@ -161,7 +162,7 @@ class RcclExchange:
         self.sync()
         room = self.room()
         ev_over = self.ev_capacity and any(int(r[:, self.words - 1 - self.ev_capacity].max().item()) > self.ev_capacity for r in self.recv)
-        return any(c > room for s in (0, 1) for c in self.recv[s][:, 0].cpu().tolist()) or bool(ev_over)
+        return any(c > room for r in self.recv for c in r[:, 0].cpu().tolist()) or bool(ev_over)
 
     def merged(self, slot):
         self.sync()
