@@ -2059,6 +2059,8 @@ struct Side {
     hipEvent_t done[kMasks + 1] = {nullptr, nullptr, nullptr, nullptr};
     bool posted[kMasks + 1] = {false, false, false, false};
     uint64_t item_no[kMasks + 1] = {0, 0, 0, 0};
+    uint64_t joined_upto = 0;       // items up to this number belong to calls whose side work joined_stream has taken in
+    hipStream_t joined_stream = nullptr;
     static constexpr uint64_t kRing = 8;
     SideItem ring[kRing];
     std::atomic<uint64_t> head{0}, tail{0};
@@ -3051,8 +3053,11 @@ int side_drain(zrk_ctx *ctx, Side *sd, uint64_t upto)
 }
 
 // The compaction that last used mask buffer `slot` is over (the host waits: see zrk_exchange_wait for why not the stream).
-int side_wait(zrk_ctx *ctx, Side *sd, int slot)
+int side_wait(zrk_ctx *ctx, Side *sd, int slot, hipStream_t compute)
 {
+    // (work of earlier calls: the compute stream took the side stream in when that call returned, whatever is launched
+    // on it now is behind that -- nothing to ask the runtime, whose first answer after a pause takes 10 us)
+    if (sd->item_no[slot] <= sd->joined_upto && compute == sd->joined_stream) return 0;
     if (int rc = side_drain(ctx, sd, sd->item_no[slot])) return rc;
     if (!sd->posted[slot]) return 0;
     for (;;) {
@@ -3319,7 +3324,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             vis_now = sd->masks[side_slot];
             sparse = kSparseVis;
         }
-        if (sd && (rc = side_wait(ctx, sd, side_slot)) != 0) break;
+        if (sd && (rc = side_wait(ctx, sd, side_slot, s)) != 0) break;
         if (sd && side_slot < Side::kMasks && M.m > 0) M.ev_code = sd->codes[side_slot];
         // removals as marks (one scenario): carried out by the next sweep's own threads, or behind the call's last tick
         const bool marks = sd && !ens && M.m > 0;
@@ -3454,8 +3459,10 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         const int rc_side = side_drain(ctx, sd, sd->head.load());
         if (rc == 0) rc = rc_side;
         if (rc != 0) { sd->masks_dirty = true; sd->pend_rows = 0; }  // (marks: allocated and cleared anew)
-        if (rc == 0 && side_last >= 0 && sd->posted[side_last] && hipStreamWaitEvent(s, sd->done[side_last], 0) != hipSuccess)
-            rc = fail(ctx, ZRK_E_HIP, "hipStreamWaitEvent");
+        if (rc == 0 && side_last >= 0 && sd->posted[side_last]) {
+            if (hipStreamWaitEvent(s, sd->done[side_last], 0) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipStreamWaitEvent");
+            else { sd->joined_upto = sd->head.load(); sd->joined_stream = s; }
+        }
     }
     if (n_prof && !deferred) {
         if (hipStreamSynchronize(s) != hipSuccess && rc == 0) rc = fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
