@@ -2777,7 +2777,7 @@ void exchange_poster_main(zrk_exchange *x)
         std::unique_lock<std::mutex> lk(x->mu);         // nothing for a while: sleep (the bounded wait covers a lost wake-up)
         x->asleep.store(true);
         if (x->head.load(std::memory_order_acquire) == x->tail.load() && !x->stop.load())
-            x->cv.wait_for(lk, std::chrono::milliseconds(1));
+            x->cv.wait_for(lk, std::chrono::milliseconds(20));
         x->asleep.store(false);
     }
 }
@@ -3006,7 +3006,7 @@ void side_main(Side *sd, int device)
         sd->asleep.store(true);
         bool woken = false;
         if (sd->head.load(std::memory_order_acquire) == sd->tail.load() && !sd->stop.load())
-            woken = sd->cv.wait_for(lk, std::chrono::milliseconds(1)) == std::cv_status::no_timeout;
+            woken = sd->cv.wait_for(lk, std::chrono::milliseconds(20)) == std::cv_status::no_timeout;
         sd->asleep.store(false);
         if (woken) idle_since = std::chrono::steady_clock::now();      // somebody is about to hand over work: stay up
     }
