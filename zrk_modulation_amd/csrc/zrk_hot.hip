@@ -2745,11 +2745,12 @@ namespace {
 int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, int64_t *recv, int64_t words, uint32_t value);
 
 // How long the library's helper threads (an exchange's, a context's side stream's) keep spinning after their last
-// item before they sleep: waking one costs 50-100 us, which the first ticks of the next call would pay.  Half a
-// second covers the pauses between the calls of a tick loop; ZRK_HELPER_IDLE_MS changes it (0: sleep at once).
+// item before they sleep.  Waking one costs 50-100 us, but zrk_run_ticks wakes them at its entry, before its first
+// launches, and a 20-tick call measures the same with ZRK_HELPER_IDLE_MS=0 (sleep at once) as with 500: 50 ms is
+// kept for loops that call back to back.
 std::chrono::milliseconds helper_idle()
 {
-    static const int ms = [] { const char *v = std::getenv("ZRK_HELPER_IDLE_MS"); return v ? std::max(0, std::atoi(v)) : 500; }();
+    static const int ms = [] { const char *v = std::getenv("ZRK_HELPER_IDLE_MS"); return v ? std::max(0, std::atoi(v)) : 50; }();
     return std::chrono::milliseconds(ms);
 }
 
@@ -3199,6 +3200,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (xio && exchange_drain(xio->x, xio->x->head.load()) != 0) return fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
         // (its thread sleeps after 50 ms without work: wake it now, not at the first item two launches from here)
         if (sd->asleep.load()) { std::lock_guard<std::mutex> lk(sd->mu); sd->cv.notify_one(); }
+        if (xio && xio->x->asleep.load()) { std::lock_guard<std::mutex> lk(xio->x->mu); xio->x->cv.notify_one(); }
         if (sd->mask_rows < e->capacity || sd->masks_dirty) {
             if (int rc0 = side_drain(ctx, sd, sd->head.load())) return rc0;
             if (hipStreamSynchronize(sd->stream) != hipSuccess) return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
