@@ -290,8 +290,8 @@ typedef struct {
  * the ticks alternate between the two mask buffers: each tick stores only its detections (list-indexed
  * stores are scattered when the table is spatially sorted, so the zeros are not worth writing) into the
  * buffer the previous tick's compaction cleared; st->vis_cur says which buffer is current afterwards.
- * From the second tick on the two buffers belong to this loop, also between calls: do not write them.  If sweep_ms != NULL the sweep kernel of every
- * prof_stride-th tick is timed with a pair of HIP events riding on its dispatch, the stream is synchronised at the
+ * From the second tick on the two buffers belong to this loop, also between calls: do not write them.
+ * If sweep_ms != NULL the sweep kernel of every prof_stride-th tick is timed with a pair of HIP events riding on its dispatch, the stream is synchronised at the
  * end and sweep_ms[k / prof_stride] receives the kernel's duration in milliseconds (prof_stride < 0: the events are
  * only recorded, zrk_read_sweep_ms reads them later).
  *
@@ -307,8 +307,9 @@ typedef struct {
  * of a sweep's workgroups is never the same twice (it does not enter any result).
  * Environment (read at zrk_ctx_create / zrk_ctx_reload_env): ZRK_OVERLAP=0 never overlap; ZRK_OVERLAP_MIN=k from k
  * ticks per call; ZRK_OVERLAP_MIN_ROWS=n from n rows; ZRK_GATHER_RECORDS=0 the missile phase reads its targets from the
- * columns instead of the 64-byte records the loop keeps per row (64 B x capacity of device memory, the context's); ZRK_SWEEP_ORDER=0 sweep in table order; ZRK_COMPACT_ORDER=block|ticket; ZRK_TIME_BY_RECORDS=1 time
- * between two recorded events.  If the side stream's thread waits five seconds for the compute stream to reach the
+ * columns instead of the 64-byte records the loop keeps per row (64 B x capacity of device memory, the context's);
+ * ZRK_SWEEP_ORDER=0 sweep in table order; ZRK_COMPACT_ORDER=block|ticket; ZRK_TIME_BY_RECORDS=1 time between two
+ * recorded events; ZRK_HELPER_IDLE_MS how long the library's threads spin before they sleep.  If the side stream's thread waits five seconds for the compute stream to reach the
  * next sweep it gives up: the call (or the next one) fails, and zrk_compact_status reports it.
  */
 /* 1 if the last zrk_run_ticks / _x / _ensemble call of this context ran overlapped, 0 if not (diagnostics). */
@@ -345,13 +346,13 @@ const char *zrk_exchange_last_error(zrk_exchange *x);
 int zrk_exchange_all_gather(zrk_exchange *x, int slot, const int64_t *send /* DEVICE */, int64_t *recv /* DEVICE */,
                             int64_t words, void *stream);
 /* The last all-gather posted on `slot` is over before anything launched on `stream` after this call runs (nothing if
- * none was posted).  By default the HOST waits for it (the collective is two ticks old, and a wait in the stream costs
+ * none was posted).  By default the HOST waits for it (the collective is ZRK_EXCHANGE_SLOTS ticks old, and a wait in the stream costs
  * the stream ~5 us of idle device per tick); ZRK_EXCHANGE_WAIT_IN_STREAM=1 at zrk_exchange_create makes it a stream
  * wait.  Inside zrk_run_ticks_x the hand-over to the exchange's stream needs no event either: the next tick's sweep
  * raises a word of device memory as it starts, a one-lane kernel on the exchange's stream waits for it, and the
  * collective is issued by a thread of the exchange's own (ZRK_EXCHANGE_EVENTS=1: events instead;
- * ZRK_EXCHANGE_THREAD=0: issued by the calling thread).  In the overlapped loop (see zrk_run_ticks) compaction and
- * collective share the exchange's stream. */
+ * ZRK_EXCHANGE_THREAD=0: issued by the calling thread).  In the overlapped loop (see zrk_run_ticks) the word is raised
+ * by a one-thread launch behind the compaction on the context's side stream. */
 int zrk_exchange_wait(zrk_exchange *x, int slot, void *stream);
 /* Block the host until the exchange's stream is idle. */
 int zrk_exchange_sync(zrk_exchange *x);
@@ -360,7 +361,7 @@ int zrk_exchange_sync(zrk_exchange *x);
  * ev_capacity > 0 -- by the tick's detonations, so that MissileDetonateMessage (modules/Missile.py:138-146) reaches
  * every rank with the list: word `words - 1 - ev_capacity` = number of events, then one word per event,
  * (global list index of the missile << 32) | global list index of the target, 0xFFFFFFFF for a self-detonation.
- * Tick t uses slot t & 1 of send / recv. */
+ * Tick t uses slot t % ZRK_EXCHANGE_SLOTS of send / recv. */
 typedef struct {
     zrk_exchange *x;
     int64_t *send[ZRK_EXCHANGE_SLOTS];   /* DEVICE [words]; tick t goes through slot t % ZRK_EXCHANGE_SLOTS */
