@@ -404,8 +404,9 @@ def main():
         stride = 64                      # ticks driven one call at a time: reading the events drains the stream
     deferred = not (exchanging and not state["c_side"])
 
-    def run_ticks(k, sweep_ms=None):
-        ps = (-stride if deferred else stride) if sweep_ms is not None else 1
+    def run_ticks(k, sweep_ms=None, every=None):
+        every = every or stride
+        ps = (-every if deferred else every) if sweep_ms is not None else 1
         if not exchanging:
             eng.run(k, sweep_ms=None if deferred else sweep_ms, prof_stride=ps)
             return
@@ -442,7 +443,13 @@ def main():
                 st0.ctx.check(st0.lib.zrk_selftest_noise(st0.ctx.handle, 1, 1, 3, 0, buf.data_ptr(), 1 << 20, None), "spin-up")
             torch.cuda.synchronize(device)
 
-    run_ticks(args.warmup)
+    # the warm-up steps go through the same code as the timed ones, sweep timing included: the library creates its timing
+    # events on first use, and a first hipExtLaunchKernel is slow -- neither belongs into the timed region
+    # (every warm-up sweep is timed, so that the timed region's events exist already)
+    warm_ms = np.zeros(args.warmup, np.float32) if (args.warmup > 0 and deferred) else None
+    run_ticks(args.warmup, warm_ms, every=1)
+    if warm_ms is not None and deferred:
+        eng.read_sweep_ms(len(warm_ms))
     overflow = False
     if exchanging and args.warmup > 0:
         # size the fixed lists from what the warm-up saw (1.25x the largest per-rank count: the count follows the
