@@ -44,7 +44,7 @@ int main(int argc, char **argv)
         C.packed_capacity = n + 1; C.gid0 = 0;
         EnsembleArgs E; std::memset(&E, 0, sizeof(E));
         static PutArgs U;
-        C.seg_blocks = 0; C._pad1 = 0; C.seg_slots = 0;
+        C.seg_blocks = 0; C.zero_own = 0; C.seg_slots = 0;
         hipLaunchKernelGGL(k_compact_fused, dim3(nb), dim3(kCompBlock), 0, 0, C, by_ticket, M, E, U);
         if (rep == 29) hipEventRecord(e1, 0);
     }

@@ -1155,7 +1155,7 @@ struct CompactArgs {
     UnionBits bits;
     // batched ensemble: the lists restart every seg_blocks workgroups (= seg_slots list slots, one scenario); radar r
     // of scenario s writes to det_idx[(s * R + r) * det_stride ...], counts to det_cnt[s * (R + 1) + r]; 0: one list
-    int32_t seg_blocks, _pad1;
+    int32_t seg_blocks, zero_own;  // zero_own: zero_next is `vis` itself, all zero but for the detections
     int64_t seg_slots;
 };
 
@@ -1198,7 +1198,9 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
     for (int it = 0; it < kFusedMaxItems; ++it) {
         if (it < C.items) {
             const int64_t i = blk0 + (int64_t)it * THREADS + tid;
-            if (C.zero_next && i < C.n) C.zero_next[i] = 0u;   // next tick's (other) mask buffer, cleared in passing
+            // next tick's (other) mask buffer, cleared in passing; the overlapped loop clears the buffer it has just read,
+            // where only the detections are not zero already
+            if (C.zero_next && i < C.n && (!C.zero_own || mk[it] != 0u)) C.zero_next[i] = 0u;
             const unsigned long long bu = __ballot(mk[it] != 0u);
             if (lane == 0) {
                 S.wcnt[it * (THREADS / 64) + wave] = (int)__popcll(bu);
@@ -2431,7 +2433,8 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         C.epoch = ctx->epoch; C.base_index = base_index; C.ctl = w.ctl; C.agg = w.agg; C.det_idx = det_idx;
         C.det_stride = det_stride; C.det_cnt = det_cnt; C.packed = packed; C.packed_capacity = packed_capacity; C.gid0 = gid0;
         C.bits = U;
-        C.seg_blocks = ens ? (int32_t)(ens->rows_ps / ((int64_t)kCompBlock * items)) : 0; C._pad1 = 0;
+        C.seg_blocks = ens ? (int32_t)(ens->rows_ps / ((int64_t)kCompBlock * items)) : 0;
+        C.zero_own = (zero_next == vis_mask) ? 1 : 0;
         C.seg_slots = ens ? ens->rows_ps : 0;
         EnsembleArgs E;
         std::memset(&E, 0, sizeof(E));
