@@ -32,14 +32,15 @@
 extern "C" {
 #endif
 
-#define ZRK_ABI_VERSION 5
+#define ZRK_ABI_VERSION 6
 #define ZRK_MAX_RADARS 32           /* one bit per radar in the visibility mask */
 #define ZRK_BLOCK 256               /* table rows per sweep workgroup */
 
 #define ZRK_E_INVALID (-1)          /* bad argument (null pointer, size out of range) */
 #define ZRK_E_HIP (-2)              /* a HIP call failed; see zrk_last_error */
 #define ZRK_E_CAPACITY (-3)         /* an output buffer is too small */
-#define ZRK_E_STATE (-4)            /* the workspace was modified behind the library's back */
+#define ZRK_E_STATE (-4)            /* the workspace was modified behind the library's back; a bounded wait ran out
+                                       (helper thread, peer rank, device); a collective went out poisoned */
 
 /* flags of zrk_tick_sweep */
 #define ZRK_F_ADVANCE 1u            /* recompute pos from the trajectory before sweeping */
@@ -309,8 +310,11 @@ typedef struct {
  * ticks per call; ZRK_OVERLAP_MIN_ROWS=n from n rows; ZRK_GATHER_RECORDS=0 the missile phase reads its targets from the
  * columns instead of the 64-byte records the loop keeps per row (64 B x capacity of device memory, the context's);
  * ZRK_SWEEP_ORDER=0 sweep in table order; ZRK_COMPACT_ORDER=block|ticket; ZRK_TIME_BY_RECORDS=1 time between two
- * recorded events; ZRK_HELPER_IDLE_MS how long the library's threads spin before they sleep.  If the side stream's thread waits five seconds for the compute stream to reach the
- * next sweep it gives up: the call (or the next one) fails, and zrk_compact_status reports it.
+ * recorded events; ZRK_HELPER_IDLE_MS how long the library's threads spin after their last item before they sleep
+ * (default 1: they spin inside a call only).  Every host-side wait is bounded by ZRK_HOST_WAIT_MS (default 30000): if the
+ * side stream's thread waits that long for the compute stream to reach the next sweep (the caller had queued more work in
+ * front of the loop than that, or the device is gone) it gives up, THAT call returns ZRK_E_STATE (its lists are not
+ * valid; zrk_compact_status says so too), and the next call starts the side stream afresh -- the failure is not sticky.
  */
 /* 1 if the last zrk_run_ticks / _x / _ensemble call of this context ran overlapped, 0 if not (diagnostics). */
 int zrk_last_run_overlapped(zrk_ctx *ctx);
@@ -352,7 +356,16 @@ int zrk_exchange_all_gather(zrk_exchange *x, int slot, const int64_t *send /* DE
  * raises a word of device memory as it starts, a one-lane kernel on the exchange's stream waits for it, and the
  * collective is issued by a thread of the exchange's own (ZRK_EXCHANGE_EVENTS=1: events instead;
  * ZRK_EXCHANGE_THREAD=0: issued by the calling thread).  In the overlapped loop (see zrk_run_ticks) the word is raised
- * by a one-thread launch behind the compaction on the context's side stream. */
+ * by a one-thread launch behind the compaction on the context's side stream.
+ * Helper threads: the exchange's own thread exists only where the rank has three host cores or more to itself
+ * (usable cores / world >= 3, ZRK_HELPERS=1|2 forces either); otherwise the side stream's thread issues the collectives
+ * as well, and all helpers sleep between calls.
+ * Failure: the wait kernel does not wait for ever (~1-2 s, ZRK_WAIT_FLAG_SPINS looks).  When it gives up, the collective
+ * behind it still runs (the peers are in it), but the list goes out POISONED -- count -1, which exchange.decode_* reject
+ * -- as does every later list of this exchange; zrk_run_ticks_x / zrk_exchange_sync / zrk_exchange_all_gather return
+ * ZRK_E_STATE from then on.  A profiler that serialises kernels across streams (rocprofv3 --pmc) forces exactly that:
+ * do not collect counters on the exchange path.  A host-side wait for a collective that does not end (a dead peer) is
+ * bounded by ZRK_HOST_WAIT_MS and returns ZRK_E_STATE. */
 int zrk_exchange_wait(zrk_exchange *x, int slot, void *stream);
 /* Block the host until the exchange's stream is idle. */
 int zrk_exchange_sync(zrk_exchange *x);
@@ -421,6 +434,11 @@ int zrk_selftest_math(zrk_ctx *ctx, int op, const double *a, const double *b, do
  * in tick `tick` under ZRK_F_PHILOX. */
 int zrk_selftest_noise(zrk_ctx *ctx, uint64_t seed, uint64_t tick, uint32_t ordinal, int64_t entity0,
                        double *out /* DEVICE [n][3] */, int64_t n, void *stream);
+/* Every host-side wait of the library (for a helper thread, for a collective posted ZRK_EXCHANGE_SLOTS ticks ago, for a
+ * compaction on the side stream) is bounded by ZRK_HOST_WAIT_MS (default 30000) and ends in ZRK_E_STATE.  This runs the
+ * wait on a condition that never comes for limit_ms and returns what such a wait returns; no device needed.
+ * what: 0 the wait itself, 1 a full hand-over ring that nobody empties. */
+int zrk_selftest_host_wait(int what, int limit_ms);
 
 #ifdef __cplusplus
 }

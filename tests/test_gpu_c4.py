@@ -1,0 +1,152 @@
+"""BASELINE config 4 (ONE population sharded across GPUs, per-tick all-gather of the compacted detection list and the
+detonation events) against the ORACLE of the whole population -- not against a single-table device run:
+
+* what a sharded run puts on the wire, decoded with exchange.decode_union_bits / decode_events, equals tick by tick what
+  the CPU restatement of Manager.run_simulation's L1 loop (reference modules/Manager.py:123-131, Radar.py:44-73,
+  Missile.py:138-146) finds for the population as a whole;
+* one tick of all 10^7 rows x 16 radars on one GPU (the three-launch compaction) equals the oracle bit for bit.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def varied_radars(R, seed):
+    from zrk_modulation_amd import scenario as S
+    radars = S.synthetic_radars(R)
+    g = np.random.Generator(np.random.PCG64(seed))
+    for k, rd in enumerate(radars):
+        rd["max_distance"] = float(g.uniform(2e4, 6e4)); rd["azimuth_start"] = float(g.uniform(0, 360))
+        rd["azimuth_range"] = float(g.uniform(20, 200)); rd["elevation_range"] = float(g.uniform(10, 90))
+        rd["azimuth_speed"] = float(g.uniform(1, 30)); rd["elevation_speed"] = float(g.uniform(0, 5))
+        rd["position"] = [float(v) for v in g.normal(0, 8e3, 3) * [1, 1, 0.05]]
+        if k % 4 == 3:
+            rd["scan_mode"] = "vertical"
+    return radars
+
+
+def build_shards(n, R, m, shards, seed, dt_ms, radars, only=None):
+    """`shards` engines over contiguous index ranges of one population, each with the missiles aimed at its own rows
+    (a missile lives on the rank that owns its target), global index space as bench.py lays it out."""
+    from zrk_modulation_amd import scenario as S
+    from zrk_modulation_amd.engine import HotPathEngine
+    ids, sp, vel, t0 = S.synthetic_targets(n, seed)
+    sp[:, :2] *= 0.3                                   # a compact swarm: missiles arrive within the test
+    per, m_per = n // shards, m // shards
+    stride = per + m_per
+    engines, launched = [], 0
+    for g in (range(shards) if only is None else [only]):
+        lo, hi = g * per, (g + 1) * per
+        eng = HotPathEngine(device="cuda:0", dt_ms=dt_ms, seed=seed + 7, noise="philox", gid0=g * stride)
+        eng.load(ids[lo:hi], sp[lo:hi], vel[lo:hi], t0[lo:hi], radars, missile_capacity=m_per)
+        launched += eng.launch_missiles(S.missile_targets(per, m_per), launcher_pos=(300.0 * g, -200.0, 0.0), speed=3000.0,
+                                        radius=900.0, period=20.0)
+        engines.append(eng)
+    return engines, stride, launched
+
+
+class WholeOracle:
+    """The oracle of the whole population next to the shards' engines: ticks it with the noise the devices will draw
+    (dumped by the devices, keyed by GLOBAL index) and maps global wire indices to its dense list."""
+
+    def __init__(self, engines, radars, stride):
+        from tests.test_gpu_engine import OracleMirror
+        self.parts = [OracleMirror(e, radars) for e in engines]
+        self.whole = OracleMirror.from_parts(self.parts)
+        self.engines, self.stride, self.R = engines, stride, len(radars)
+
+    def noise_table(self, tick):
+        from tests.test_gpu_engine import _device_noise_table
+        tabs = [_device_noise_table(e, tick, self.R, p.n).reshape(self.R, p.n, 3) for e, p in zip(self.engines, self.parts)]
+        return np.ascontiguousarray(np.concatenate(tabs, axis=1)).reshape(-1)
+
+    def tick(self, tick, dt_ms):
+        events = self.whole.tick(tick * dt_ms, dt_ms, 2, self.noise_table(tick), threads=16)
+        return events, self.whole.vis.copy(), self.whole.lists()
+
+    def dense(self, global_index):
+        g = np.asarray(global_index, np.int64)
+        shard = g // self.stride
+        return self.whole.base[shard] + (g - shard * self.stride)
+
+    def check(self, idx, msk, events_wire, want, tag):
+        events, vis, lists = want
+        d = self.dense(idx.cpu().numpy())
+        got = np.zeros(self.whole.n, np.uint32)
+        got[d] = msk.cpu().numpy().astype(np.uint32)
+        assert np.all(np.diff(d) > 0), f"{tag}: the merged list is not in index order"
+        assert np.array_equal(got, vis), f"{tag}: decoded masks differ from the oracle's"
+        for r, lst in enumerate(lists):
+            assert np.array_equal(d[((got[d] >> r) & 1) == 1], lst), f"{tag}: radar {r}'s list differs"
+        ev = [(int(self.dense(a)), -1 if b < 0 else int(self.dense(b))) for a, b in events_wire]
+        assert ev == events, f"{tag}: detonation events on the wire differ: {ev} vs {events}"
+
+
+@pytest.mark.parametrize("loop", ["tick-by-tick", "overlapped-calls", "one-helper"])
+def test_sharded_wire_matches_oracle_of_the_whole_population(loop, monkeypatch):
+    """Two shards of one population (240 000 rows, 600 missiles, Philox noise, varied radars), each through the C-side
+    exchange with the wire format and the events tail; the two ranks' buffers side by side are what an all-gather over
+    two ranks delivers.  Every tick: decoded masks, per-radar lists and detonations == oracle of the WHOLE population."""
+    from zrk_modulation_amd.exchange import RcclExchange, decode_events, decode_union_bits, union_bits_words
+    n, R, m, shards, dt = 240_000, 6, 600, 2, 400
+    if loop != "tick-by-tick":
+        monkeypatch.setenv("ZRK_OVERLAP_MIN_ROWS", "0")
+    if loop == "one-helper":
+        monkeypatch.setenv("ZRK_HELPERS", "1")
+    radars = varied_radars(R, 5)
+    engines, stride, launched = build_shards(n, R, m, shards, 321, dt, radars)
+    assert launched > 300
+    ora = WholeOracle(engines, radars, stride)
+    ev_cap = 512
+    xs = [RcclExchange(union_bits_words(e.store.cap, R, e.store.cap), e.store.device, R, offsets=[g * stride], ev_capacity=ev_cap)
+          for g, e in enumerate(engines)]
+    offsets = [g * stride for g in range(shards)]
+    tick, seen_events, seen = 0, 0, 0
+    calls = [1] * 10 if loop == "tick-by-tick" else [4, 4, 4]
+    for K in calls:
+        want = [ora.tick(tick + j, dt) for j in range(K)]
+        for e, x in zip(engines, xs):
+            e.run(K, exchange=x)
+            assert e.store.lib.zrk_last_run_overlapped(e.store.ctx.handle) == (0 if loop == "tick-by-tick" else 1)
+        for x in xs:
+            x.sync()
+        for j in range(K):                               # ZRK_EXCHANGE_SLOTS = 4 ticks are still in their slots
+            slot = (tick + j) % xs[0].slots
+            gathered = torch.stack([x.recv[slot][0] for x in xs])
+            idx, msk = decode_union_bits(gathered, R, offsets, ev_cap)
+            ora.check(idx, msk, decode_events(gathered, ev_cap), want[j], f"{loop} tick {tick + j}")
+            seen_events += len(want[j][0]); seen += int(np.count_nonzero(want[j][1]))
+        tick += K
+    assert seen_events > 20 and seen > 10_000
+    for x in xs:
+        assert not x.overflowed()
+        x.close()
+
+
+def test_c4_full_size_tick_matches_the_oracle():
+    """configs[3] at its full size on ONE GPU: 10^7 AirObjects x 16 radars, 10^4 missiles, noise off (the oracle's OpenMP
+    radar phase decides every one of the 1.6e8 pairs with the reference's formula), the three-launch compaction.  Masks,
+    position bits, detonation rows and every radar's list for two ticks; lists sorted and duplicate-free."""
+    from tests.test_gpu_engine import OracleMirror, _compare_tick
+    from zrk_modulation_amd import scenario as S
+    from zrk_modulation_amd.engine import HotPathEngine
+    n, R, m = S.WORKLOADS["C4"]
+    ids, sp, vel, t0 = S.population_slice(S.SEEDS["C4"], 0, n)
+    radars = S.synthetic_radars(R)
+    eng = HotPathEngine(device="cuda:0", dt_ms=10, seed=1, noise="off")
+    eng.load(ids, sp, vel, t0, radars, missile_capacity=m).enable_lists()
+    assert eng.launch_missiles(S.missile_targets(n, m)) > m // 2
+    del ids, sp, vel, t0
+    mir = OracleMirror(eng, radars)
+    for k in range(2):
+        events = mir.tick(k * 10, 10, 0, None, threads=16)
+        eng.run(1)
+        vis, _ = _compare_tick(eng, mir, events, f"C4 tick {k}")
+        lists = eng.detections()
+        for r, want in enumerate(mir.lists()):
+            assert np.array_equal(lists[r], want), f"C4 tick {k}: radar {r}'s list differs"
+            assert np.all(np.diff(lists[r]) > 0)
+    eng.store.compact_status()
+    assert np.count_nonzero(vis) > 1_000_000

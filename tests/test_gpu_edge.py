@@ -165,3 +165,39 @@ def test_long_missile_table_takes_the_multi_launch_path():
         if ts >= 0:
             mir.alive[ts] = 0
     assert np.array_equal(alive, mir.alive)
+
+
+@pytest.mark.parametrize("path", ["records-in-device-memory", "records-in-the-kernel-arguments"])
+def test_every_pair_through_the_exact_tier_on_both_record_paths(path, monkeypatch):
+    """ZRK_F_EXACT_ONLY sends every in-range (radar, row) pair through visible_exact, which reads the radar's cold record
+    by ADDRESS: in the two-launch loop the records sit in device memory (put there by the previous tick's compaction
+    launch), in the overlapped loop and in a stand-alone sweep in the kernel-argument segment.  Round 2 lost a GPU to a
+    record address formed where the kernel-argument pointer is null; both paths against the oracle,
+    and the device fault word (zrk_compact_status) must stay clear."""
+    from tests.test_gpu_c4 import varied_radars
+    from tests.test_gpu_engine import OracleMirror, _compare_tick
+    from zrk_modulation_amd import scenario as S
+    from zrk_modulation_amd._lib import F_EXACT_ONLY
+    from zrk_modulation_amd.engine import HotPathEngine
+    n, R, m = 30_000, 7, 150
+    monkeypatch.setenv("ZRK_OVERLAP_MIN_ROWS", "0")
+    monkeypatch.setenv("ZRK_OVERLAP", "0" if path == "records-in-device-memory" else "1")
+    ids, sp, vel, t0 = S.synthetic_targets(n, 17)
+    radars = varied_radars(R, 9)
+    eng = HotPathEngine(device="cuda:0", dt_ms=300, seed=2, noise="off")
+    eng.load(ids, sp, vel, t0, radars, missile_capacity=m).enable_lists()
+    eng.launch_missiles(S.missile_targets(n, m), speed=2500.0, radius=600.0, period=30.0)
+    eng.loop.flags |= F_EXACT_ONLY
+    mir = OracleMirror(eng, radars)
+    tick = 0
+    for K in (4, 5):
+        events = None
+        for _ in range(K):
+            events = mir.tick(tick * 300, 300, 0, None)
+            tick += 1
+        eng.run(K)
+        assert eng.store.lib.zrk_last_run_overlapped(eng.store.ctx.handle) == (0 if path == "records-in-device-memory" else 1)
+        vis, _ = _compare_tick(eng, mir, events, f"{path} after {tick} ticks")
+        for r, (got, want) in enumerate(zip(eng.detections(), mir.lists())):       # (detections() checks the fault word)
+            assert np.array_equal(got, want), f"{path} after {tick} ticks: radar {r}"
+        assert np.count_nonzero(vis) > 500

@@ -78,6 +78,36 @@ class OracleMirror:
                                            r["elevation_speed"], r["elevation_start"], r["caz"], r["cel"])
         return events
 
+    @classmethod
+    def from_parts(cls, parts):
+        """ONE population out of the mirrors of its shards (BASELINE config 4): the lists of the shards one after the
+        other -- shard g's targets, then its missiles -- which is the order the rank-ordered concatenation of the shards'
+        wire lists must reproduce.  Dense index of shard g's list element i: base[g] + i."""
+        self = cls.__new__(cls)
+        self.O, self.L = parts[0].O, parts[0].L
+        self.base = np.cumsum([0] + [p.n for p in parts])
+        mbase = np.cumsum([0] + [p.m for p in parts])
+        n = self.n = int(self.base[-1])
+        m = self.m = int(mbase[-1])
+        planes = lambda name: np.concatenate([getattr(p, name).reshape(3, p.n) for p in parts], axis=1).reshape(-1).copy()   # noqa: E731
+        self.sp, self.vel, self.pos, self.prev = planes("sp"), planes("vel"), planes("pos"), planes("prev")
+        self.t0 = np.concatenate([p.t0 for p in parts])
+        self.pv = np.zeros(n, np.uint8); self.alive = np.ones(n, np.uint8)
+        self.kind = np.concatenate([p.kind for p in parts])
+        self.mrow = np.concatenate([np.where(p.mrow >= 0, p.mrow + mbase[g], -1) for g, p in enumerate(parts)]).astype(np.int32)
+        self.m_tgt = np.concatenate([p.m_tgt[:p.m] + self.base[g] for g, p in enumerate(parts)] + [np.zeros(0, np.int64)]).astype(np.int32)
+        self.m_radius = np.concatenate([p.m_radius[:p.m] for p in parts] + [np.zeros(0)]).copy()
+        self.m_period = np.concatenate([p.m_period[:p.m] for p in parts] + [np.zeros(0)]).copy()
+        if m == 0:
+            self.m_tgt, self.m_radius, self.m_period = np.zeros(1, np.int32), np.zeros(1), np.zeros(1)
+        self.m_status = np.ones(max(m, 1), np.uint8)
+        self.ev = (np.zeros(max(m, 1), np.int32), np.zeros(max(m, 1), np.int32), np.zeros(max(m, 1), np.uint8))
+        self.vis = np.zeros(n, np.uint32)
+        self.rs = [dict(r) for r in parts[0].rs]
+        self.pending = []
+        self.lidx = np.arange(n)
+        return self
+
     def lists(self):
         out = []
         buf = np.zeros(self.n, np.int32)

@@ -74,3 +74,35 @@ def test_k_ticks_per_call_with_the_exchange(env, monkeypatch):
         idx, msk = x.merged(last)      # the last tick: by the event
         assert np.array_equal(idx.cpu().numpy(), np.nonzero(vis)[0]), f"call {calls}: list of the last tick differs"
     x.close()
+
+
+def test_a_collective_whose_list_never_came_goes_out_poisoned_and_fails_the_call(monkeypatch):
+    """k_wait_flag gives up (here at once: ZRK_WAIT_FLAG_SPINS=0) instead of holding the device for ever.  The collective
+    behind it still runs -- the peers are in it -- but nobody may take what it carried for a tick's list: the count on the
+    wire is -1 from the tick after at the latest, every decoder rejects it, and zrk_run_ticks_x / zrk_exchange_sync fail."""
+    from zrk_modulation_amd._lib import ZrkError
+    from zrk_modulation_amd.exchange import PoisonedList, RcclExchange, decode_events, decode_union_bits, union_bits_words
+    monkeypatch.setenv("ZRK_WAIT_FLAG_SPINS", "0")
+    n, R, m = 20_000, 4, 100
+    eng, _, _ = _engines(n, R, m, 5)
+    x = RcclExchange(union_bits_words(eng.store.cap, R, eng.store.cap), eng.store.device, R, offsets=[0], ev_capacity=128)
+    with pytest.raises((ZrkError, RuntimeError)):
+        eng.run(9, exchange=x)                           # (the host may learn of it only when it synchronises)
+        x.sync()
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError):
+        x.sync()
+    with pytest.raises((ZrkError, RuntimeError)):        # and it stays failed: no later list of this exchange passes
+        eng.run(2, exchange=x)
+        x.sync()
+    torch.cuda.synchronize()
+    # from the tick after the give-up on every list is poisoned behind its compaction (the first one races with its own):
+    # after nine ticks each slot's last list carries the poison
+    counts = [int(x.recv[k][0, 0].item()) for k in range(x.slots)]
+    assert counts == [-1] * x.slots, counts
+    slot = 1
+    with pytest.raises(PoisonedList):
+        decode_union_bits(x.recv[slot], R, [0], 128)
+    with pytest.raises(PoisonedList):
+        decode_events(x.recv[slot], 128)
+    x.close()

@@ -208,3 +208,106 @@ def test_overlapped_calls_match_the_oracle_directly():
         assert eng.radar_state() == [(r["caz"], r["cel"]) for r in mir.rs]
         assert np.count_nonzero(vis) > 1000
     assert seen_events > 0
+
+
+def test_a_missile_whose_target_is_a_missile(monkeypatch):
+    """A missile row may name another missile's row as its target (the C ABI takes any row).  When B hits A in tick t, A is
+    out of the air from tick t + 1 on (AirEnv.py:33-40) -- in the overlapped loop that removal is a mark which A's own row
+    thread carries out somewhere inside sweep t + 1, the very grid whose leading workgroups step the missiles: A's missile
+    thread must read the mark, not the flag.  Half of the A's would time out in exactly that tick if they were allowed
+    to step once more: an extra event, an extra removal.  Against the two-launch loop after every call, and against the
+    oracle tick by tick."""
+    from tests.test_gpu_engine import OracleMirror, _compare_tick, _device_noise_table
+    from zrk_modulation_amd import scenario as S
+    from zrk_modulation_amd.engine import HotPathEngine
+    n, R, pairs, dt = 50_000, 4, 700, 200
+    ids, sp, vel, t0 = S.synthetic_targets(n, 31)
+    sp[:, :2] *= 0.3
+    radars = S.synthetic_radars(R)
+    tgt = (np.arange(pairs) * 61 % n).astype(np.int32)
+    engines = []
+    for ov in ("0", "1"):
+        monkeypatch.setenv("ZRK_OVERLAP_MIN_ROWS", "0")
+        monkeypatch.setenv("ZRK_OVERLAP", ov)
+        eng = HotPathEngine(device="cuda:0", dt_ms=dt, seed=8, noise="philox", gid0=0)
+        eng.load(ids, sp, vel, t0, radars, missile_capacity=2 * pairs).enable_lists()
+        # the A's: every other one would run out of time in its second tick in the air (1.5 ticks of fuse)
+        period_a = np.where(np.arange(pairs) % 2 == 0, 1.5 * dt / 1000, 40.0)
+        k = eng.launch_missiles(tgt, speed=2500.0, radius=300.0, period=period_a)
+        assert k > pairs // 2
+        # the B's fly the same lines (same launcher, same target, same speed: the same solves succeed) -- and are then
+        # aimed at their A
+        assert eng.launch_missiles(tgt, speed=2500.0, radius=50.0, period=40.0) == k
+        st = eng.store
+        rows_a = np.asarray(st.hm_slot[:k], np.int32)
+        st.dm_tgt[k:2 * k] = torch.as_tensor(rows_a, device=st.device)
+        st.hm_tgt = np.concatenate([st.hm_tgt[:k], rows_a])
+        engines.append(eng)
+    ref, ovl = engines
+    mir = OracleMirror(ref, radars)
+    tick = 0
+    seen = []
+    for calls, K in enumerate([6, 4, 9]):
+        events = None
+        for _ in range(K):
+            events = mir.tick(tick * dt, dt, 2, _device_noise_table(ref, tick, R, mir.n))
+            seen.append(len(events))
+            tick += 1
+        ref.run(K)
+        ovl.run(K)
+        assert ovl.store.lib.zrk_last_run_overlapped(ovl.store.ctx.handle) == 1
+        _same(_state(ref), _state(ovl), f"after call {calls} of {K} ticks")
+        _compare_tick(ovl, mir, events, f"overlapped loop after {tick} ticks")
+    # tick 0: every B hits its A (distance 0); tick 1: nothing -- the A's are gone, although half of them were due
+    assert seen[0] == k and seen[1] == 0, seen[:3]
+    alive = ovl.store.d_alive[:ovl.store.n_uploaded].cpu().numpy()
+    assert alive[np.asarray(ovl.store.hm_slot[:2 * k])].sum() == 0
+
+
+def test_a_failed_side_stream_is_not_sticky(monkeypatch):
+    """The side stream's thread gives up when the compute stream does not reach the next sweep within the host wait limit
+    (here: 40 ms, behind ~0.3 s of unrelated work queued on the stream).  THAT call fails with ZRK_E_STATE; the table
+    stands as after the ticks that were swept; the next call runs overlapped again and ends where an engine that never
+    failed ends."""
+    from tests.test_gpu_engine import _engine
+    from zrk_modulation_amd._lib import ZrkError
+    monkeypatch.setenv("ZRK_OVERLAP_MIN_ROWS", "0")
+    monkeypatch.setenv("ZRK_OVERLAP", "0")
+    ref, _, _ = _engine(40_000, 5, 300, seed=13, noise="philox")
+    monkeypatch.setenv("ZRK_OVERLAP", "1")
+    ovl, _, _ = _engine(40_000, 5, 300, seed=13, noise="philox")
+    st = ovl.store
+    ovl.run(6); ref.run(6)
+    _same(_state(ref), _state(ovl), "before the failure")
+    monkeypatch.setenv("ZRK_HOST_WAIT_MS", "40")
+    st.lib.zrk_ctx_reload_env(st.ctx.handle)
+    a = torch.ones(6144, 6144, dtype=torch.float64, device=st.device)
+    b = torch.empty_like(a)
+    torch.mm(a, a, out=b)
+    torch.cuda.synchronize()
+    for _ in range(40):                                  # a few hundred milliseconds of unrelated work in front of the loop
+        torch.mm(a, a, out=b)
+    tick0 = int(ovl.loop.tick)
+    with pytest.raises(ZrkError):
+        ovl.run(12)
+    torch.cuda.synchronize()
+    done = int(ovl.loop.tick) - tick0
+    assert 0 < done < 12, "the call should have stopped at the ring slot whose compaction never came"
+    monkeypatch.setenv("ZRK_HOST_WAIT_MS", "30000")
+    st.lib.zrk_ctx_reload_env(st.ctx.handle)
+    ref.run(done)
+    a, b = _state_table(ref), _state_table(ovl)
+    _same(a, b, f"table after the failed call ({done} ticks swept)")
+    ovl.run(7); ref.run(7)
+    assert st.lib.zrk_last_run_overlapped(st.ctx.handle) == 1
+    _same(_state(ref), _state(ovl), "after the call behind the failure")
+
+
+def _state_table(eng):
+    """What a failed call must still leave intact: the table and the missile rows (not the lists, not the events)."""
+    st = eng.store
+    n, m = st.n_uploaded, st.m
+    torch.cuda.synchronize()
+    return dict(pos_cur=st.host_pos("cur").view(np.uint64), pos_prev=st.host_pos("prev").view(np.uint64),
+                alive=st.d_alive[:n].cpu().numpy(), period=st.dm_period[:m].cpu().numpy().view(np.uint64),
+                status=st.dm_status[:m].cpu().numpy(), radar=np.array(eng.radar_state()))

@@ -248,3 +248,41 @@ def test_host_mirror_append_is_amortised():
             copies += 1
             last = base
     assert copies <= 5 and np.array_equal(st.h_ids, np.arange(5000))
+
+
+def test_host_waits_are_bounded_and_end_in_a_state_error():
+    """Every host-side wait of the library (helper threads, collectives posted ticks ago, side-stream compactions) goes
+    through one bounded spin: a condition that never comes -- a stalled flag, a ring nobody empties -- ends in
+    ZRK_E_STATE after the limit instead of a process that spins for ever (include/zrk_hot.h, ZRK_HOST_WAIT_MS)."""
+    import time
+    from zrk_modulation_amd import _lib
+    L = _lib.load()
+    for what in (0, 1):
+        t0 = time.perf_counter()
+        assert L.zrk_selftest_host_wait(what, 40) == _lib.ZRK_E_STATE
+        took = time.perf_counter() - t0
+        assert 0.03 < took < 2.0, f"a 40 ms limit took {took:.3f} s"
+
+
+def test_poisoned_lists_are_rejected_by_every_decoder():
+    """A rank whose list was never handed over sends count -1 (k_wait_flag's give-up): nothing downstream may read such
+    a buffer as a tick's detections."""
+    import torch
+    from zrk_modulation_amd import exchange as X
+    R, n, ev = 5, 300, 8
+    vis = np.zeros(n, np.uint32)
+    vis[[3, 64, 65, 200]] = [1, 3, 16, 31]
+    words = X.union_bits_words(n, R, 16)
+    good = np.concatenate([X.encode_union_bits(vis, R, words), np.zeros(1 + ev, np.int64)])
+    bad = good.copy()
+    bad[0] = -1
+    ok = torch.from_numpy(np.stack([good, good]))
+    idx, msk = X.decode_union_bits(ok, R, [0, 1000], ev)
+    assert idx.tolist() == [3, 64, 65, 200, 1003, 1064, 1065, 1200] and msk.tolist() == [1, 3, 16, 31] * 2
+    assert X.decode_events(ok, ev) == []
+    for rows in ([bad, good], [good, bad]):
+        g = torch.from_numpy(np.stack(rows))
+        with pytest.raises(X.PoisonedList):
+            X.decode_union_bits(g, R, [0, 1000], ev)
+        with pytest.raises(X.PoisonedList):
+            X.decode_events(g, ev)

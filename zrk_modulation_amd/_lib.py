@@ -14,11 +14,12 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = CSRC / "libzrk_hot.so"
 
-ZRK_ABI_VERSION = 5
+ZRK_ABI_VERSION = 6
 EXCHANGE_SLOTS = 4          # ZRK_EXCHANGE_SLOTS
 ZRK_MAX_RADARS = 32
 ZRK_BLOCK = 256
 F_ADVANCE, F_PHILOX, F_EXACT_ONLY, F_UNION_BITS = 1, 2, 4, 8
+ZRK_E_INVALID, ZRK_E_HIP, ZRK_E_CAPACITY, ZRK_E_STATE = -1, -2, -3, -4
 
 
 class HotPathUnavailable(RuntimeError):
@@ -210,6 +211,7 @@ _PROTOTYPES = {
                                     C.c_void_p]),
     "zrk_selftest_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64, C.c_void_p,
                                      C.c_int64, C.c_void_p]),
+    "zrk_selftest_host_wait": (C.c_int, [C.c_int, C.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <sched.h>
 
 #include "zrk_hot.h"
 
@@ -217,6 +218,13 @@ __device__ __forceinline__ double floormod_small(double a, double b)
 // the exact bounds (relative error ~1e-16), sqrt correctly rounded, everything else a handful of roundings --
 // whatever is farther than 1e-11 of the distance from every face is on the side it appears to be on, also for the
 // angles (their own rounding is ~1e-15 relative).  Only rows inside that band (nanometres) take the angle formula.
+// Device-side "this must not happen" word, read by zrk_compact_status.  Bit 0: visible_exact was handed a record
+// address without a high word.  THE ADDRESS OF A RADAR RECORD IS FORMED IN THE __global__ BODY ONLY (k_tick_sweep: `rbp`):
+// outside a kernel __builtin_amdgcn_kernarg_segment_ptr() is the constant 0 -- the backend lowers the intrinsic to
+// null in every function that is not an entry point, without a diagnostic -- and a record "at" 0 + offsetof(SweepParams,
+// rb.cold) + r * sizeof(RadarCold) is a load from page 0x1000: the memory access fault of round 2.
+__device__ uint32_t g_device_fault;
+
 __device__ __noinline__ bool visible_exact(uint64_t cold_record, double dx, double dy, double dz)
 {
     // radar r's cold record in the kernel-argument segment, by address (a by-value copy of the record would travel
@@ -224,6 +232,10 @@ __device__ __noinline__ bool visible_exact(uint64_t cold_record, double dx, doub
     typedef const double __attribute__((address_space(4))) *ConstDoubles;
     const uint64_t addr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(cold_record >> 32)) << 32) |
                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cold_record);
+    if ((uint32_t)(addr >> 32) == 0u) {            // (wave-uniform) never a device or kernarg address: do not touch it
+        atomicOr(&g_device_fault, 1u);
+        return false;
+    }
     const ConstDoubles q = (ConstDoubles)addr;
     static_assert(sizeof(RadarCold) == 14 * sizeof(double), "RadarCold is fourteen doubles");
     RadarCold c;
@@ -1466,7 +1478,11 @@ __device__ uint8_t missile_step_row(const double *__restrict__ sp, const double 
 {
     uint8_t code = 0;
     const int32_t s = m_slot[row];
-    if (m_status[row] == 1 && alive[s]) {
+    // (overlapped loop: a missile that is itself somebody's target and was hit LAST tick is removed from this tick on
+    // -- AirEnv.py:33-40 -- but only its own row thread, somewhere in this very grid, lowers the flag: the mark says it)
+    bool flying = m_status[row] == 1 && alive[s] != 0;
+    if (pend && flying) { const uint32_t ps = pend[s]; flying = !(ps != 0u && ps != mark); }
+    if (flying) {
         const double d = t - t0[s];
         const double px = sp[s] + vel[s] * d, py = sp[cap + s] + vel[cap + s] * d,
                      pz = sp[2 * cap + s] + vel[2 * cap + s] * d;
@@ -2018,6 +2034,52 @@ double d2_threshold(double m)
 
 }  // namespace
 
+// Every host-side wait of this library is bounded (a dead peer rank, a helper thread that failed, a device that does
+// not come back must end in ZRK_E_STATE, not in a process that spins for ever): ZRK_HOST_WAIT_MS, default 30 s.
+namespace {
+std::atomic<int> g_host_wait_ms{-1};              // read at first use and by zrk_ctx_reload_env
+void host_wait_reload()
+{
+    const char *v = std::getenv("ZRK_HOST_WAIT_MS");
+    g_host_wait_ms.store(v ? std::max(1, std::atoi(v)) : 30000);
+}
+std::chrono::milliseconds host_wait_limit()
+{
+    if (g_host_wait_ms.load(std::memory_order_relaxed) < 0) host_wait_reload();
+    return std::chrono::milliseconds(g_host_wait_ms.load(std::memory_order_relaxed));
+}
+
+// Host threads this process may really use: the affinity mask, capped by the cgroup's CPU quota (what sizes the number of
+// helper threads a rank starts: three busy threads per rank on an 8-rank node want 24 cores).
+int usable_host_cores()
+{
+    int cores = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) cores = CPU_COUNT(&set);
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long long period = 0;
+        if (std::fscanf(f, "%31s %lld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0)
+            cores = std::min<long long>(cores, std::max<long long>(1, std::atoll(quota) / period));
+        std::fclose(f);
+    }
+    return std::max(1, cores);
+}
+
+// Spins (pause) until ok() holds; false when the limit ran out first.  The clock is read every 4096 looks.
+template <class Pred>
+bool spin_until(Pred ok, std::chrono::milliseconds limit = host_wait_limit())
+{
+    if (ok()) return true;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1;; ++spins) {
+        __builtin_ia32_pause();
+        if (ok()) return true;
+        if ((spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > limit) return false;
+    }
+}
+}  // namespace
+
 // Overlap mode of zrk_run_ticks: the side stream on which a tick's lists are compacted beside the next tick's sweep,
 // and the thread that issues its work (waiting for a flag word, the compaction, in an exchange the collective behind it,
 // an event) so that the calling thread is left with the two launches of the compute stream.
@@ -2034,6 +2096,13 @@ struct SideItem {
     uint32_t *raise;
     uint32_t raise_value;
     int done_slot;                  // done[done_slot] is recorded last
+    // one helper thread per rank (few host cores per rank): this thread also issues the tick's collective, right behind
+    // the launch that raises the word it waits for (otherwise the exchange's own thread does)
+    zrk_exchange *post_x;
+    int post_slot;
+    const int64_t *post_send;
+    int64_t *post_recv;
+    int64_t post_words;
 };
 
 struct Side {
@@ -2071,7 +2140,7 @@ struct Side {
     std::condition_variable cv;
     std::atomic<bool> asleep{false}, stop{false};
     std::atomic<int> rc{0};
-    std::string err;
+    std::string err;                // written by the thread before rc, read after
 };
 
 struct zrk_ctx {
@@ -2194,6 +2263,7 @@ ZRK_API void zrk_ctx_invalidate_boxes(zrk_ctx *ctx)
 ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
 {
     if (!c) return;
+    host_wait_reload();
     c->order_enabled = true; c->diag = 0; c->env_items = 0; c->env_order = -1;
     if (const char *v = std::getenv("ZRK_SWEEP_ORDER")) c->order_enabled = std::atoi(v) != 0;
     if (const char *v = std::getenv("ZRK_DIAG")) c->diag = (uint32_t)std::strtoul(v, nullptr, 0);
@@ -2497,6 +2567,12 @@ ZRK_API int zrk_compact_status(zrk_ctx *ctx, void *workspace, void *stream)
         return fail(ctx, ZRK_E_HIP, "zrk_compact_status: copy failed");
     if (ctx->side && ctx->side->rc.load() != 0)    // overlap mode: the side stream's thread gave up (its lists are not valid)
         return fail(ctx, ZRK_E_STATE, ctx->side->err);
+    uint32_t dev_fault = 0;
+    if (hipMemcpyFromSymbol(&dev_fault, HIP_SYMBOL(g_device_fault), sizeof(dev_fault)) != hipSuccess)
+        return fail(ctx, ZRK_E_HIP, "zrk_compact_status: the device fault word could not be read");
+    if (dev_fault != 0)
+        return fail(ctx, ZRK_E_STATE, "a sweep was handed a radar record without an address (device fault word " + std::to_string(dev_fault) +
+                                      "): its visibility masks are not valid");
     if (ctx->fused_ws != workspace) return 0;      // never used with this context
     if (ctl[2] == 0 && ctl[0] == 0 && ctl[1] == 0) return 0;
     ctx->fused_ws = nullptr;                       // cleared again on the next use
@@ -2646,6 +2722,16 @@ ZRK_API int zrk_ccp_link(zrk_ctx *ctx, const double *det_pos, const double *det_
     return check_launch(ctx, "zrk_ccp_link");
 }
 
+// What every bounded host wait of the library does when its condition never comes: `what` 0 the spin helper itself, 1 a
+// ring the helper thread never empties.  No device needed (tests/test_host_logic.py).
+ZRK_API int zrk_selftest_host_wait(int what, int limit_ms)
+{
+    const auto limit = std::chrono::milliseconds(std::max(1, limit_ms));
+    if (what == 0) return spin_until([] { return false; }, limit) ? 0 : ZRK_E_STATE;
+    std::atomic<uint64_t> head{8}, tail{0};
+    return spin_until([&] { return head.load() - tail.load(std::memory_order_acquire) < 8; }, limit) ? 0 : ZRK_E_STATE;
+}
+
 ZRK_API int zrk_selftest_math(zrk_ctx *ctx, int op, const double *a, const double *b, double *y, int64_t n, void *stream)
 {
     if (!ctx || !a || !b || !y) return fail(ctx, ZRK_E_INVALID, "zrk_selftest_math: null argument");
@@ -2722,10 +2808,22 @@ struct zrk_exchange {
     hipEvent_t ready[ZRK_EXCHANGE_SLOTS] = {}, done[ZRK_EXCHANGE_SLOTS] = {};
     bool posted[ZRK_EXCHANGE_SLOTS] = {};
     // hand-over by flag (zrk_run_ticks_x): a word of device memory that the NEXT tick's sweep raises to `seq` as it starts;
-    // a one-lane kernel on the exchange stream waits for the value (flag[1]: it gave up).  NULL (ZRK_EXCHANGE_EVENTS=1):
-    // an event per tick on the compute stream instead
+    // a one-lane kernel on the exchange stream waits for the value.  NULL (ZRK_EXCHANGE_EVENTS=1): an event per tick on
+    // the compute stream instead
     uint32_t *flag = nullptr;
     uint32_t seq = 0;
+    // ... and what that kernel does when the value does not come (k_wait_flag): it raises this word of PINNED HOST memory,
+    // which the host reads without a synchronisation at the end of every zrk_run_ticks_x call and in zrk_exchange_sync, and
+    // poisons the list it was waiting for (count -1) -- as it does with every later list of this exchange, so that the peers
+    // learn it from the wire
+    volatile uint32_t *gave_up = nullptr;
+    uint32_t *gave_up_dev = nullptr;
+    int wait_spins = 1 << 20;                          // looks (s_sleep 32 between them) before it gives up: ~1-2 s
+    // one helper thread per rank: the side stream's thread issues the collectives (SideItem::post_x); set for the duration of
+    // a call, with the number of the side ring's item that carries each slot's collective
+    struct Side *via_side = nullptr;
+    uint64_t side_item_no[ZRK_EXCHANGE_SLOTS] = {};
+    bool one_helper = false;
     bool wait_in_stream = false;                        // ZRK_EXCHANGE_WAIT_IN_STREAM=1, see zrk_exchange_wait
     // ... and those collectives are issued by a thread of the exchange's own: waiting for the value, the RCCL call and the
     // event record take the calling thread longer than the two launches of a tick, and the device would wait for its host
@@ -2746,14 +2844,27 @@ struct zrk_exchange {
 namespace {
 
 int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, int64_t *recv, int64_t words, uint32_t value);
+__global__ void k_poison_if_gave_up(const uint32_t *gave_up, int64_t *send);
+
+// the wait kernel of some collective gave up (k_wait_flag): that list and every later one went out poisoned
+int exchange_gave_up(zrk_exchange *x)
+{
+    if (x->gave_up && *x->gave_up != 0u) {
+        x->err = "the exchange stream gave up waiting for a list to be handed over (k_wait_flag): the collective went out with a poisoned "
+                 "list (count -1), as does every later one of this exchange";
+        return ZRK_E_STATE;
+    }
+    return 0;
+}
 
 // How long the library's helper threads (an exchange's, a context's side stream's) keep spinning after their last
-// item before they sleep.  Waking one costs 50-100 us, but zrk_run_ticks wakes them at its entry, before its first
-// launches, and a 20-tick call measures the same with ZRK_HELPER_IDLE_MS=0 (sleep at once) as with 500: 50 ms is
-// kept for loops that call back to back.
+// item before they sleep on their condition variable.  Inside a call the next item is never more than a tick away, so
+// they spin only there; between calls they sleep (eight ranks with two spinning helpers each would otherwise hold
+// sixteen cores of a node for nothing).  Waking one costs 50-100 us, but zrk_run_ticks wakes them at its entry, before
+// its first launches, and a 20-tick call measures the same with ZRK_HELPER_IDLE_MS=0 (sleep at once) as with 500.
 std::chrono::milliseconds helper_idle()
 {
-    static const int ms = [] { const char *v = std::getenv("ZRK_HELPER_IDLE_MS"); return v ? std::max(0, std::atoi(v)) : 50; }();
+    static const int ms = [] { const char *v = std::getenv("ZRK_HELPER_IDLE_MS"); return v ? std::max(0, std::atoi(v)) : 1; }();
     return std::chrono::milliseconds(ms);
 }
 
@@ -2786,22 +2897,38 @@ void exchange_poster_main(zrk_exchange *x)
     }
 }
 
-void exchange_enqueue(zrk_exchange *x, const zrk_exchange::PostItem &it)
+int exchange_enqueue(zrk_exchange *x, const zrk_exchange::PostItem &it)
 {
     const uint64_t h = x->head.load(std::memory_order_relaxed);
-    while (h - x->tail.load(std::memory_order_acquire) >= zrk_exchange::kRing) __builtin_ia32_pause();
+    if (!spin_until([&] { return h - x->tail.load(std::memory_order_acquire) < zrk_exchange::kRing; })) {
+        x->err = "the exchange's thread did not take an item within the host wait limit (ZRK_HOST_WAIT_MS)";
+        return ZRK_E_STATE;
+    }
     x->ring[h % zrk_exchange::kRing] = it;
     x->head.store(h + 1, std::memory_order_release);
     x->item_no[it.slot] = h + 1;
     if (x->asleep.load()) { std::lock_guard<std::mutex> lk(x->mu); x->cv.notify_one(); }
+    return 0;
 }
+
+int side_issued_upto(Side *sd, uint64_t upto, std::string &err);
 
 // everything handed to the thread has been issued on the exchange stream (0), or the thread's failure
 int exchange_drain(zrk_exchange *x, uint64_t upto)
 {
-    while (x->tail.load(std::memory_order_acquire) < upto) __builtin_ia32_pause();
-    if (x->post_rc.load() != 0) { x->err = x->post_err; return ZRK_E_HIP; }
+    if (!spin_until([&] { return x->tail.load(std::memory_order_acquire) >= upto; })) {
+        x->err = "the exchange's thread did not issue its collectives within the host wait limit (ZRK_HOST_WAIT_MS)";
+        return ZRK_E_STATE;
+    }
+    if (x->post_rc.load() != 0) { x->err = x->post_err; return x->post_rc.load(); }
     return 0;
+}
+
+// the collective of `slot` has been issued, whoever issues them in this call
+int exchange_issued(zrk_exchange *x, int slot)
+{
+    if (x->via_side) return side_issued_upto(x->via_side, x->side_item_no[slot], x->err);
+    return exchange_drain(x, x->item_no[slot]);
 }
 
 }  // namespace
@@ -2841,12 +2968,22 @@ ZRK_API int zrk_exchange_create(const char *rccl_path, const zrk_rccl_id *id, in
     x->wait_in_stream = in_stream && in_stream[0] == '1';
     const char *force_events = std::getenv("ZRK_EXCHANGE_EVENTS");
     if (!(force_events && force_events[0] == '1')) {
-        if (hipMalloc((void **)&x->flag, 8) != hipSuccess || hipMemset(x->flag, 0, 8) != hipSuccess) {
+        if (hipMalloc((void **)&x->flag, 8) != hipSuccess || hipMemset(x->flag, 0, 8) != hipSuccess ||
+            hipHostMalloc((void **)&x->gave_up, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&x->gave_up_dev, (void *)x->gave_up, 0) != hipSuccess) {
             x->err = "the exchange's flag words could not be allocated"; return ZRK_E_HIP;
         }
+        *x->gave_up = 0u;
     }
+    if (const char *v = std::getenv("ZRK_WAIT_FLAG_SPINS")) x->wait_spins = std::max(0, std::atoi(v));   // (0: gives up at once -- tests)
+    // Helper threads.  By default the collectives are issued by a thread of the exchange's own (the side stream of the
+    // overlapped loop has another); where the rank has fewer than three host cores to itself the side stream's thread
+    // issues them too (ZRK_HELPERS=1 / 2 forces either), and a rank alone on less than two cores ... still works, slower.
+    int helpers = usable_host_cores() / std::max(1, world) < 3 ? 1 : 2;
+    if (const char *v = std::getenv("ZRK_HELPERS")) helpers = std::atoi(v) <= 1 ? 1 : 2;
+    x->one_helper = helpers == 1;
     const char *no_thread = std::getenv("ZRK_EXCHANGE_THREAD");
-    if (x->flag && !(no_thread && no_thread[0] == '0')) x->poster = std::thread(exchange_poster_main, x);
+    if (x->flag && !x->one_helper && !(no_thread && no_thread[0] == '0')) x->poster = std::thread(exchange_poster_main, x);
     return 0;
 }
 
@@ -2866,6 +3003,7 @@ ZRK_API void zrk_exchange_destroy(zrk_exchange *x)
     }
     if (x->cstream) (void)hipStreamDestroy(x->cstream);
     if (x->flag) (void)hipFree(x->flag);
+    if (x->gave_up) (void)hipHostFree((void *)x->gave_up);
     delete x;
 }
 
@@ -2874,9 +3012,14 @@ ZRK_API const char *zrk_exchange_last_error(zrk_exchange *x) { return x ? x->err
 ZRK_API int zrk_exchange_all_gather(zrk_exchange *x, int slot, const int64_t *send, int64_t *recv, int64_t words, void *stream)
 {
     if (!x || !x->comm || !send || !recv || words <= 0 || slot < 0 || slot >= ZRK_EXCHANGE_SLOTS) return ZRK_E_INVALID;
-    if (exchange_drain(x, x->head.load()) != 0) return ZRK_E_HIP;      // behind whatever the exchange's thread still had to issue
+    if (int rc = exchange_gave_up(x)) return rc;                       // (no further list of this exchange passes for a tick's)
+    if (int rc = exchange_drain(x, x->head.load())) return rc;         // behind whatever the exchange's thread still had to issue
     if (hipEventRecord(x->ready[slot], (hipStream_t)stream) != hipSuccess ||
         hipStreamWaitEvent(x->cstream, x->ready[slot], 0) != hipSuccess) { x->err = "event hand-over to the exchange stream failed"; return ZRK_E_HIP; }
+    if (x->gave_up_dev) {                                // (a give-up the host has not seen yet: this list goes out poisoned too)
+        hipLaunchKernelGGL(k_poison_if_gave_up, dim3(1), dim3(1), 0, x->cstream, x->gave_up_dev, (int64_t *)send);
+        if (hipGetLastError() != hipSuccess) { x->err = "k_poison_if_gave_up launch failed"; return ZRK_E_HIP; }
+    }
     const int rc = x->api.AllGather(send, recv, (size_t)words, kNcclInt64, x->comm, x->cstream);
     if (rc != 0) { x->err = std::string("ncclAllGather: ") + (x->api.GetErrorString ? x->api.GetErrorString(rc) : "error"); return ZRK_E_HIP; }
     if (hipEventRecord(x->done[slot], x->cstream) != hipSuccess) { x->err = "hipEventRecord failed"; return ZRK_E_HIP; }
@@ -2896,15 +3039,34 @@ __global__ void k_raise_flag(uint32_t *flag, uint32_t value)
     __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One lane waits for the word to reach `value` (sleeping between looks); gives up after a few seconds and says so
-// (zrk_exchange_sync reports it) rather than hold the device for ever.
-__global__ void k_wait_flag(const uint32_t *flag, uint32_t value, uint32_t *gave_up)
+// One lane waits for the word to reach `value` (sleeping between looks).  It does not hold the device for ever: after
+// `spins` looks (~1-2 s) it gives up -- and then the collective behind it must not pass for a tick's list: the word in
+// pinned host memory goes up (the host fails the call: zrk_run_ticks_x, zrk_exchange_sync) and the list's count is
+// overwritten with -1, which every decoder rejects (exchange.decode_union_bits / decode_events / overflowed).  The
+// late compaction may still write the real count over the poison of THIS list before the collective reads it, so every
+// later list of the exchange is poisoned as well (the word stays up), behind its compaction: the peers find out from
+// the wire at the latest one tick on.  (A profiler that serialises kernels across streams -- rocprofv3 --pmc -- makes the
+// producer on the other stream wait for this kernel: the give-up is then certain.  Do not collect counters on the
+// exchange path.)
+__global__ void k_wait_flag(const uint32_t *flag, uint32_t value, uint32_t *gave_up, int64_t *send, int spins)
 {
-    for (int spins = 0; spins < (1 << 20); ++spins) {
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= value) return;
-        __builtin_amdgcn_s_sleep(32);
+    bool up = false;
+    // (once it has given up, the later lists are poisoned BEHIND their compaction: those waits take the full default)
+    if (__hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) spins = 1 << 20;
+    for (int k = 0; k < spins && !up; ++k) {
+        up = (int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) >= 0;
+        if (!up) __builtin_amdgcn_s_sleep(32);
     }
-    __hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!up) __hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!up || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+        __hip_atomic_store(send, (int64_t)-1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The same for a list that is handed over by an event (the last tick of a call): poisoned if the exchange has given up before.
+__global__ void k_poison_if_gave_up(const uint32_t *gave_up, int64_t *send)
+{
+    if (__hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+        __hip_atomic_store(send, (int64_t)-1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // The collective of a list whose producer has no event behind it: the exchange stream waits until the flag word
@@ -2913,7 +3075,7 @@ int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, in
 {
     // (a wait kernel of our own on a word of device memory: hipStreamWaitValue32 on signal memory does the same
     // job but cost the compute stream 3.5 us a tick in the measurement, this costs it nothing measurable)
-    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, x->cstream, x->flag, value, x->flag + 1);
+    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, x->cstream, x->flag, value, x->gave_up_dev, (int64_t *)send, x->wait_spins);
     if (hipGetLastError() != hipSuccess) { x->err = "k_wait_flag launch failed"; return ZRK_E_HIP; }
     const int rc = x->api.AllGather(send, recv, (size_t)words, kNcclInt64, x->comm, x->cstream);
     if (rc != 0) { x->err = std::string("ncclAllGather: ") + (x->api.GetErrorString ? x->api.GetErrorString(rc) : "error"); return ZRK_E_HIP; }
@@ -2927,7 +3089,7 @@ int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, in
 ZRK_API int zrk_exchange_wait(zrk_exchange *x, int slot, void *stream)
 {
     if (!x || slot < 0 || slot >= ZRK_EXCHANGE_SLOTS) return ZRK_E_INVALID;
-    if (exchange_drain(x, x->item_no[slot]) != 0) return ZRK_E_HIP;    // its collective has been issued (by the exchange's thread)
+    if (int rc = exchange_issued(x, slot)) return rc;                  // its collective has been issued (by a helper thread)
     if (!x->posted[slot]) return 0;
     // usually that collective is long over (it was posted ZRK_EXCHANGE_SLOTS ticks ago): then the host knows, and the stream is spared a
     // barrier packet, which costs it more than the wait it would do
@@ -2939,25 +3101,21 @@ ZRK_API int zrk_exchange_wait(zrk_exchange *x, int slot, void *stream)
         if (hipStreamWaitEvent((hipStream_t)stream, x->done[slot], 0) != hipSuccess) { x->err = "hipStreamWaitEvent failed"; return ZRK_E_HIP; }
         return 0;
     }
-    while (true) {
-        const hipError_t q = hipEventQuery(x->done[slot]);
-        if (q == hipSuccess) return 0;
-        if (q != hipErrorNotReady) { x->err = "hipEventQuery failed"; return ZRK_E_HIP; }
-        __builtin_ia32_pause();
+    hipError_t q = hipErrorNotReady;
+    if (!spin_until([&] { q = hipEventQuery(x->done[slot]); return q != hipErrorNotReady; })) {
+        x->err = "a collective posted ZRK_EXCHANGE_SLOTS ticks ago is not through within the host wait limit (ZRK_HOST_WAIT_MS): a peer rank is gone or stuck";
+        return ZRK_E_STATE;
     }
+    if (q != hipSuccess) { x->err = "hipEventQuery failed"; return ZRK_E_HIP; }
+    return 0;
 }
 
 ZRK_API int zrk_exchange_sync(zrk_exchange *x)
 {
     if (!x) return ZRK_E_INVALID;
-    if (exchange_drain(x, x->head.load()) != 0) return ZRK_E_HIP;
+    if (int rc = exchange_drain(x, x->head.load())) return rc;
     if (hipStreamSynchronize(x->cstream) != hipSuccess) { x->err = "hipStreamSynchronize failed"; return ZRK_E_HIP; }
-    if (x->flag) {
-        uint32_t gave_up = 0;
-        if (hipMemcpy(&gave_up, x->flag + 1, sizeof(gave_up), hipMemcpyDeviceToHost) != hipSuccess) { x->err = "hipMemcpy failed"; return ZRK_E_HIP; }
-        if (gave_up) { x->err = "the exchange stream gave up waiting for a sweep to raise its flag: that collective sent an unfinished list"; return ZRK_E_HIP; }
-    }
-    return 0;
+    return exchange_gave_up(x);
 }
 
 
@@ -2971,23 +3129,22 @@ int side_issue(Side *sd, const SideItem &it)
     // ahead of their input -- deadlocks the device as soon as anything else on it needs whole compute units in dispatch
     // order (e.g. another engine's single-launch compaction), and a one-lane wait kernel in front of it costs the side
     // stream 5 us a tick.  This thread has nothing else to do.
-    {
-        const auto t0 = std::chrono::steady_clock::now();
-        unsigned spins = 0;
-        while ((int32_t)(*sd->hflag - it.flag_value) < 0) {
-            __builtin_ia32_pause();
-            if ((++spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
-                sd->err = "side stream: the compute stream did not reach the next sweep within 5 s"; return ZRK_E_STATE;
-            }
-            if (sd->stop.load()) { sd->err = "side stream: stopped"; return ZRK_E_STATE; }
-        }
+    if (!spin_until([&] { return (int32_t)(*sd->hflag - it.flag_value) >= 0 || sd->stop.load(); })) {
+        // (the caller queued more work in front of the loop than the limit allows for, or the device is gone)
+        sd->err = "side stream: the compute stream did not reach the next sweep within the host wait limit (ZRK_HOST_WAIT_MS)";
+        return ZRK_E_STATE;
     }
+    if ((int32_t)(*sd->hflag - it.flag_value) < 0) { sd->err = "side stream: stopped"; return ZRK_E_STATE; }
     hipLaunchKernelGGL(k_compact_side, dim3(it.C.nb + (it.M.m > 0 ? 1 : 0)), dim3(kCompBlock), 0, it.stream, it.C, it.by_ticket, it.M);
     // an exchange's collective (on the exchange's own stream) waits for this word: the list and its events are complete
     if (it.raise) hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, it.stream, it.raise, it.raise_value);
     if (hipGetLastError() != hipSuccess) { sd->err = "side stream: compaction launch failed"; return ZRK_E_HIP; }
     if (hipEventRecord(sd->done[it.done_slot], it.stream) != hipSuccess) { sd->err = "side stream: hipEventRecord failed"; return ZRK_E_HIP; }
     sd->posted[it.done_slot] = true;
+    if (it.post_x && exchange_post_behind_flag(it.post_x, it.post_slot, it.post_send, it.post_recv, it.post_words, it.raise_value) != 0) {
+        sd->err = std::string("side stream: ") + it.post_x->err;
+        return ZRK_E_HIP;
+    }
     return 0;
 }
 
@@ -3038,21 +3195,34 @@ Side *side_of(zrk_ctx *ctx)
     return sd;
 }
 
-void side_enqueue(Side *sd, const SideItem &it)
+int side_enqueue(zrk_ctx *ctx, Side *sd, const SideItem &it)
 {
     const uint64_t h = sd->head.load(std::memory_order_relaxed);
-    while (h - sd->tail.load(std::memory_order_acquire) >= Side::kRing) __builtin_ia32_pause();
+    if (!spin_until([&] { return h - sd->tail.load(std::memory_order_acquire) < Side::kRing; }))
+        return fail(ctx, ZRK_E_STATE, "side stream: its thread did not take an item within the host wait limit (ZRK_HOST_WAIT_MS)");
     sd->ring[h % Side::kRing] = it;
     sd->head.store(h + 1, std::memory_order_release);
     sd->item_no[it.done_slot] = h + 1;
     if (sd->asleep.load()) { std::lock_guard<std::mutex> lk(sd->mu); sd->cv.notify_one(); }
+    return 0;
 }
 
 // Everything up to item number `upto` has been issued (0), or the thread's failure.
+int side_issued_upto(Side *sd, uint64_t upto, std::string &err)
+{
+    // (twice the limit: the thread itself may be sitting out one limit in side_issue, and reports that)
+    if (!spin_until([&] { return sd->tail.load(std::memory_order_acquire) >= upto; }, 2 * host_wait_limit())) {
+        err = "side stream: its thread did not issue its work within the host wait limit (ZRK_HOST_WAIT_MS)";
+        return ZRK_E_STATE;
+    }
+    if (sd->rc.load() != 0) { err = sd->err; return sd->rc.load(); }
+    return 0;
+}
+
 int side_drain(zrk_ctx *ctx, Side *sd, uint64_t upto)
 {
-    while (sd->tail.load(std::memory_order_acquire) < upto) __builtin_ia32_pause();
-    if (sd->rc.load() != 0) return fail(ctx, sd->rc.load(), sd->err);
+    std::string err;
+    if (int rc = side_issued_upto(sd, upto, err)) return fail(ctx, rc, err);
     return 0;
 }
 
@@ -3064,12 +3234,10 @@ int side_wait(zrk_ctx *ctx, Side *sd, int slot, hipStream_t compute)
     if (sd->item_no[slot] <= sd->joined_upto && compute == sd->joined_stream) return 0;
     if (int rc = side_drain(ctx, sd, sd->item_no[slot])) return rc;
     if (!sd->posted[slot]) return 0;
-    for (;;) {
-        const hipError_t q = hipEventQuery(sd->done[slot]);
-        if (q == hipSuccess) return 0;
-        if (q != hipErrorNotReady) return fail(ctx, ZRK_E_HIP, "side stream: hipEventQuery failed");
-        __builtin_ia32_pause();
-    }
+    hipError_t q = hipErrorNotReady;
+    if (!spin_until([&] { q = hipEventQuery(sd->done[slot]); return q != hipErrorNotReady; }))
+        return fail(ctx, ZRK_E_STATE, "side stream: a compaction launched ticks ago is not through within the host wait limit (ZRK_HOST_WAIT_MS)");
+    return q == hipSuccess ? 0 : fail(ctx, ZRK_E_HIP, "side stream: hipEventQuery failed");
 }
 
 void side_destroy(Side *sd)
@@ -3200,8 +3368,21 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     if (want_overlap) {
         sd = side_of(ctx);
         if (!sd) return fail(ctx, ZRK_E_HIP, "zrk_run_ticks: the side stream could not be created");
-        if (xio && exchange_drain(xio->x, xio->x->head.load()) != 0) return fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
-        // (its thread sleeps after 50 ms without work: wake it now, not at the first item two launches from here)
+        if (xio) { if (int rcx = exchange_drain(xio->x, xio->x->head.load())) return fail(ctx, rcx, zrk_exchange_last_error(xio->x)); }
+        if (sd->rc.load() != 0) {
+            // Its thread failed in an earlier call (reported then: that call returned the error).  The failure is not
+            // sticky: the thread skips what it still holds, both streams are drained, the hand-over word, the ring slots and
+            // the buffers start afresh -- and this call runs overlapped again.
+            std::string ignored;
+            (void)side_issued_upto(sd, sd->head.load(), ignored);
+            if (hipStreamSynchronize(sd->stream) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+                return fail(ctx, ZRK_E_HIP, "zrk_run_ticks: the side stream did not drain after its thread's failure");
+            *sd->hflag = 0u; sd->seq = 0;
+            sd->masks_dirty = true; sd->pend_rows = 0; sd->joined_upto = 0; sd->joined_stream = nullptr;
+            sd->err.clear();
+            sd->rc.store(0);
+        }
+        // (its thread sleeps after a millisecond without work: wake it now, not at the first item two launches from here)
         if (sd->asleep.load()) { std::lock_guard<std::mutex> lk(sd->mu); sd->cv.notify_one(); }
         if (xio && xio->x->asleep.load()) { std::lock_guard<std::mutex> lk(xio->x->mu); xio->x->cv.notify_one(); }
         if (sd->mask_rows < e->capacity || sd->masks_dirty) {
@@ -3283,21 +3464,30 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     held.on = false;
     auto issue_held = [&]() -> int {
         held.on = false;
-        if (zrk_exchange_wait(xio->x, held.slot, stream) != 0) return fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
-        side_enqueue(sd, held.it);
         zrk_exchange *x = xio->x;
-        if (x->poster.joinable())
-            exchange_enqueue(x, zrk_exchange::PostItem{held.slot, held.list, xio->recv[held.slot], xio->words, held.it.raise_value});
-        else if (exchange_post_behind_flag(x, held.slot, held.list, xio->recv[held.slot], xio->words, held.it.raise_value) != 0)
+        if (int rcw = zrk_exchange_wait(x, held.slot, stream)) return fail(ctx, rcw, zrk_exchange_last_error(x));
+        if (x->one_helper) {                             // the side stream's thread issues the collective behind its launches
+            held.it.post_x = x; held.it.post_slot = held.slot; held.it.post_send = held.list;
+            held.it.post_recv = xio->recv[held.slot]; held.it.post_words = xio->words;
+        }
+        if (int rce = side_enqueue(ctx, sd, held.it)) return rce;
+        if (x->one_helper) { x->via_side = sd; x->side_item_no[held.slot] = sd->head.load(); return 0; }
+        if (x->poster.joinable()) {
+            if (int rce = exchange_enqueue(x, zrk_exchange::PostItem{held.slot, held.list, xio->recv[held.slot], xio->words, held.it.raise_value}))
+                return fail(ctx, rce, zrk_exchange_last_error(x));
+        } else if (exchange_post_behind_flag(x, held.slot, held.list, xio->recv[held.slot], xio->words, held.it.raise_value) != 0)
             return fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(x));
         return 0;
     };
     int rc = 0;
+    bool marks_used = false;                             // some sweep of this call ran with removal marks
     for (int k = 0; k < K && rc == 0; ++k) {
+        // (a tick that fails before its sweep is launched leaves the loop state as the last complete tick left it)
+        const int32_t cur_before = st->cur, vis_cur_before = st->vis_cur;
         st->cur ^= 1;
         const bool prof = n_prof && (k % stride == 0);
         const bool on_dispatch = prof && ctx->time_on_dispatch && (st->n > 0 || (m > 0 && m <= 1024 * (int64_t)kMissileItems));
-        if (prof && !on_dispatch && hipEventRecord(ev[2 * (k / stride)], s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "hipEventRecord"); break; }
+        if (prof && !on_dispatch && hipEventRecord(ev[2 * (k / stride)], s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "hipEventRecord"); st->cur = cur_before; break; }
         const int slot = (int)(st->tick % (uint64_t)ZRK_EXCHANGE_SLOTS);
         int64_t *list = xio ? xio->send[slot] : packed;
         const int64_t list_words = xio ? xio->words - ev_words : packed_capacity;
@@ -3329,7 +3519,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             vis_now = sd->masks[side_slot];
             sparse = kSparseVis;
         }
-        if (sd && (rc = side_wait(ctx, sd, side_slot, s)) != 0) break;
+        if (sd && (rc = side_wait(ctx, sd, side_slot, s)) != 0) { st->cur = cur_before; st->vis_cur = vis_cur_before; break; }
         if (sd && side_slot < Side::kMasks && M.m > 0) M.ev_code = sd->codes[side_slot];
         // removals as marks (one scenario): carried out by the next sweep's own threads, or behind the call's last tick
         const bool marks = sd && !ens && M.m > 0;
@@ -3359,13 +3549,16 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         }
         if (!ordering) ctx->order_ready = false;
         const int oph = ctx->order_phase;                                    // reads list oph, builds list oph ^ 1
-        rc = launch_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse, st->seed,
+        const int rc_sweep =
+             launch_sweep(ctx, e, st->n, st->cur, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse, st->seed,
                           st->tick, st->gid0, workspace, stream, M, vis_now, ordering ? w.order[oph ^ 1] : nullptr,
                           (ordering && ctx->order_ready) ? w.order[oph] : nullptr, w.boxes, ens ? &EL : nullptr,
                           rb_through_memory ? rb_dev[st->tick & 1u] : nullptr,
                           pend.on ? fx->flag : ((sd && k > 0) ? sd->hflag_dev : nullptr), pend.on ? pend.value : (sd ? sd->seq : 0u),
                           on_dispatch ? ev[2 * (k / stride)] : nullptr, on_dispatch ? ev[2 * (k / stride) + 1] : nullptr,
                           w.order_ctr + kOrderCtrSet * (oph ^ 1), w.order_ctr + kOrderCtrSet * oph, marks ? sd->pend : nullptr, mark);
+        rc = rc_sweep;
+        if (rc_sweep == 0 && marks) marks_used = true;
         if (rc == 0 && ordering) { ctx->order_ready = true; ctx->order_phase = oph ^ 1; }
         if (rc == 0 && held.on) rc = issue_held();                           // (the previous tick's item, see below)
         if (pend.on) {                                                       // the previous tick's collective, behind this sweep's start
@@ -3373,20 +3566,27 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                 hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, s, fx->flag, pend.value);
                 rc = check_launch(ctx, "k_raise_flag");
             }
-            if (rc == 0 && fx->poster.joinable())
-                exchange_enqueue(fx, zrk_exchange::PostItem{pend.slot, pend.list, xio->recv[pend.slot], xio->words, pend.value});
-            else if (rc == 0 && exchange_post_behind_flag(fx, pend.slot, pend.list, xio->recv[pend.slot], xio->words, pend.value) != 0)
+            if (rc == 0 && fx->poster.joinable()) {
+                if (int rce = exchange_enqueue(fx, zrk_exchange::PostItem{pend.slot, pend.list, xio->recv[pend.slot], xio->words, pend.value}))
+                    rc = fail(ctx, rce, zrk_exchange_last_error(fx));
+            } else if (rc == 0 && exchange_post_behind_flag(fx, pend.slot, pend.list, xio->recv[pend.slot], xio->words, pend.value) != 0)
                 rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(fx));
             pend.on = false;
         }
-        if (!ens) zrk_scan_advance(radars, scan, R);                          // Radar.py:205 (an ensemble's: on the device)
+        if (!ens && rc_sweep == 0) zrk_scan_advance(radars, scan, R);         // Radar.py:205 (an ensemble's: on the device)
         if (rb_through_memory) {                                             // the next tick's records ride with this compaction
             fill_radar_block(ctx, radars, R, st->flags, put.rb);
             put.dst = (uint32_t *)rb_dev[(st->tick + 1) & 1u];
         }
         if (prof && !on_dispatch && rc == 0 && hipEventRecord(ev[2 * (k / stride) + 1], s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipEventRecord");
         if (sd) {
-            if (rc != 0) break;
+            if (rc != 0) {
+                // no sweep: as after the last complete tick; swept but its side work cannot be handed over: the tick counts
+                // (its removals are marks, carried out below), its lists are lost with the call
+                if (rc_sweep != 0) { st->cur = cur_before; st->vis_cur = vis_cur_before; }
+                else { st->time_ms += st->dt_ms; st->tick += 1; }
+                break;
+            }
             // (the next sweep's first thread, or a launch behind the loop, tells the side stream's thread that this tick's
             // launches on the compute stream are over)
             const int eparts = ens ? nblocks((int64_t)EL.next.S * EL.next.R, kCompBlock) : 0;
@@ -3414,8 +3614,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                 // collective never delays a launch on the compute stream.
                 it.raise = fx->flag; it.raise_value = ++fx->seq;
                 held.on = true; held.it = it; held.slot = slot; held.list = list;
-            } else {
-                side_enqueue(sd, it);
+            } else if ((rc = side_enqueue(ctx, sd, it)) != 0) {
+                break;
             }
             side_last = side_slot;
             if (side_slot == Side::kMasks) ctx->ring_clean[st->vis_cur] = false;
@@ -3424,7 +3624,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             continue;
         }
         // this slot's list was last sent ZRK_EXCHANGE_SLOTS ticks ago: that collective must have read it before it is rewritten
-        if (rc == 0 && xio && zrk_exchange_wait(xio->x, slot, stream) != 0) rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(xio->x));
+        if (rc == 0 && xio) { if (int rcw = zrk_exchange_wait(xio->x, slot, stream)) rc = fail(ctx, rcw, zrk_exchange_last_error(xio->x)); }
         if (rc == 0 && two_vis) { ctx->ring_clean[st->vis_cur] = false; ctx->ring_clean[st->vis_cur ^ 1] = true; }
         if (rc == 0 && (det_idx || list))
             rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, list,
@@ -3455,20 +3655,32 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             hipLaunchKernelGGL(k_raise_flag_system, dim3(1), dim3(1), 0, s, sd->hflag_dev, sd->seq);
             rc = check_launch(ctx, "k_raise_flag");
         }
-        if (rc == 0 && side_last >= 0 && !ens && m > 0) {
-            // the last tick's removals are still marks: tombstones now, and the call's marks cleared
+        if (marks_used && sd->pend && sd->pend_rows >= e->capacity) {
+            // the last tick's removals are still marks: tombstones now, and the call's marks cleared -- also when the call
+            // has failed (a helper that gave up, a wait that ran out): the table then stands as after the st->tick ticks
+            // that were swept, only the lists of this call are not valid
             hipLaunchKernelGGL(k_apply_marks, dim3(nblocks(st->n, 256)), dim3(256), 0, s, sd->pend, e->alive, e->pos[st->cur],
                                e->pos[st->cur ^ 1], e->capacity, st->n);
-            rc = check_launch(ctx, "k_apply_marks");
+            const int rcm = check_launch(ctx, rc == 0 ? "k_apply_marks" : ctx->err.c_str());
+            if (rc == 0) rc = rcm;
+        }
+        if (rc != 0) {
+            // the call has failed: nobody will raise the word for the items the side stream's thread still holds -- do it
+            // from here, behind everything the compute stream has, so that the thread is not left to sit out its limit
+            (void)hipStreamSynchronize(s);
+            *sd->hflag = sd->seq;
         }
         const int rc_side = side_drain(ctx, sd, sd->head.load());
         if (rc == 0) rc = rc_side;
+        if (xio) xio->x->via_side = nullptr;                 // (everything it carried has been issued, or has failed with it)
         if (rc != 0) { sd->masks_dirty = true; sd->pend_rows = 0; }  // (marks: allocated and cleared anew)
         if (rc == 0 && side_last >= 0 && sd->posted[side_last]) {
             if (hipStreamWaitEvent(s, sd->done[side_last], 0) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipStreamWaitEvent");
             else { sd->joined_upto = sd->head.load(); sd->joined_stream = s; }
         }
     }
+    // a collective whose hand-over never came went out poisoned (k_wait_flag): the host knows without a synchronisation
+    if (rc == 0 && xio && exchange_gave_up(xio->x) != 0) rc = fail(ctx, ZRK_E_STATE, zrk_exchange_last_error(xio->x));
     if (n_prof && !deferred) {
         if (hipStreamSynchronize(s) != hipSuccess && rc == 0) rc = fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
         for (int k = 0; k < n_prof; ++k) {

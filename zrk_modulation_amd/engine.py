@@ -316,24 +316,27 @@ class HotPathEngine:
         ms_ptr = sweep_ms.ctypes.data_as(C.POINTER(C.c_float)) if sweep_ms is not None else None
         det = (self.det_idx.data_ptr() if self.det_idx is not None else None,
                self.det_stride if self.det_idx is not None else 0, self.det_cnt.data_ptr())
-        if exchange is not None:
-            self.loop.flags |= self._lib.F_UNION_BITS
-            st.ctx.check(st.lib.zrk_run_ticks_x(
-                st.ctx.handle, C.byref(st.ents), C.byref(st.mis), st.m, C.byref(self.loop), self.c_radars, self.c_scan,
-                self.R, st.workspace().data_ptr(), det[0], det[1], det[2], None, 0, C.byref(exchange.io), int(K), ms_ptr,
-                int(prof_stride), st._stream()), "zrk_run_ticks_x")
-        else:
-            st.ctx.check(st.lib.zrk_run_ticks(
-                st.ctx.handle, C.byref(st.ents), C.byref(st.mis), st.m, C.byref(self.loop), self.c_radars, self.c_scan,
-                self.R, st.workspace().data_ptr(), det[0], det[1], det[2],
-                self.packed.data_ptr() if self.packed is not None else None,
-                self.packed.numel() if self.packed is not None else 0, int(K), ms_ptr, int(prof_stride), st._stream()),
-                "zrk_run_ticks")
-        st.cur = int(self.loop.cur)
-        st.vis_cur = int(self.loop.vis_cur)
-        st.time_ms = int(self.loop.time_ms) - self.dt_ms
-        st.n_stepped = st.n_uploaded
-        st._bump()
+        try:
+            if exchange is not None:
+                self.loop.flags |= self._lib.F_UNION_BITS
+                st.ctx.check(st.lib.zrk_run_ticks_x(
+                    st.ctx.handle, C.byref(st.ents), C.byref(st.mis), st.m, C.byref(self.loop), self.c_radars, self.c_scan,
+                    self.R, st.workspace().data_ptr(), det[0], det[1], det[2], None, 0, C.byref(exchange.io), int(K), ms_ptr,
+                    int(prof_stride), st._stream()), "zrk_run_ticks_x")
+            else:
+                st.ctx.check(st.lib.zrk_run_ticks(
+                    st.ctx.handle, C.byref(st.ents), C.byref(st.mis), st.m, C.byref(self.loop), self.c_radars, self.c_scan,
+                    self.R, st.workspace().data_ptr(), det[0], det[1], det[2],
+                    self.packed.data_ptr() if self.packed is not None else None,
+                    self.packed.numel() if self.packed is not None else 0, int(K), ms_ptr, int(prof_stride), st._stream()),
+                    "zrk_run_ticks")
+        finally:
+            # (also when the call failed: the loop state says how many ticks were swept, and the table stands as after those)
+            st.cur = int(self.loop.cur)
+            st.vis_cur = int(self.loop.vis_cur)
+            st.time_ms = int(self.loop.time_ms) - self.dt_ms
+            st.n_stepped = st.n_uploaded
+            st._bump()
 
     def read_sweep_ms(self, n):
         """Durations [ms] of the sweeps a run(..., prof_stride < 0) call recorded events around (waits for them)."""

@@ -40,10 +40,24 @@ def encode_union_bits(vis, R, words):
     return out
 
 
+class PoisonedList(RuntimeError):
+    """A rank's collective went out although its list was never handed over (the wait kernel in front of it gave up,
+    include/zrk_hot.h: zrk_exchange_wait): that rank wrote count -1 over the list instead of letting an unfinished one
+    pass for a tick's detections."""
+
+
+def check_not_poisoned(gathered):
+    """Raises PoisonedList if any rank's buffer carries the poison (count < 0).  Synchronises."""
+    bad = torch.nonzero(gathered[:, 0] < 0).reshape(-1).cpu().tolist()
+    if bad:
+        raise PoisonedList(f"the list of rank(s) {bad} is poisoned: its producer never handed it over to the collective")
+
+
 def decode_union_bits(gathered, R, offsets, ev_capacity=0):
     """Global union list from gathered wire-format buffers int64[world, words]: (indices int64, masks int64) in index
     order.  Synchronises."""
     world, words = gathered.shape
+    check_not_poisoned(gathered)
     tail = 1 + int(ev_capacity) if ev_capacity else 0
     idx, msk = [], []
     shifts = torch.arange(64, dtype=torch.int64, device=gathered.device)
@@ -67,6 +81,7 @@ def decode_events(gathered, ev_capacity):
     out = []
     if not ev_capacity:
         return out
+    check_not_poisoned(gathered)
     tail = gathered[:, gathered.shape[1] - 1 - int(ev_capacity):].cpu().numpy()
     for g in range(tail.shape[0]):
         k = min(int(tail[g, 0]), int(ev_capacity))
@@ -160,6 +175,8 @@ class RcclExchange:
 
     def overflowed(self):
         self.sync()
+        for r in self.recv:
+            check_not_poisoned(r)
         room = self.room()
         ev_over = self.ev_capacity and any(int(r[:, self.words - 1 - self.ev_capacity].max().item()) > self.ev_capacity for r in self.recv)
         return any(c > room for r in self.recv for c in r[:, 0].cpu().tolist()) or bool(ev_over)
