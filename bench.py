@@ -397,9 +397,11 @@ def main():
     if exchanging:
         size_exchange(eng.store.cap)     # (may settle for the Python exchange: decided before anything depends on it)
 
-    # every 4th tick's sweep is timed when the run is short, every 8th otherwise (a timed launch costs the stream ~4 us,
-    # whether the events ride on the dispatch or are recorded around it); the events are read after the timed region
-    stride = int(os.environ.get("ZRK_BENCH_STRIDE", 0)) or (4 if args.steps <= 64 else 8)
+    # every 10th tick's sweep is timed when the run is short (the last tick of each window of ten: two samples in the
+    # driver's 20-step run), every 8th otherwise: a timed launch costs the stream 5-13 us of idle device around it, whether
+    # the events ride on the dispatch or are recorded around it (profiles/r03_timeline_20steps.txt: five samples cost the
+    # 20-step run 3 us per tick); the events are read after the timed region
+    stride = int(os.environ.get("ZRK_BENCH_STRIDE", 0)) or (10 if args.steps <= 64 else 8)
     if exchanging and not state["c_side"]:
         stride = 64                      # ticks driven one call at a time: reading the events drains the stream
     deferred = not (exchanging and not state["c_side"])
@@ -465,6 +467,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run_ticks(args.steps, sweep_ms)
+    t_issued = time.perf_counter()
     if exchanging:
         drain_exchange()
     barrier()
@@ -476,6 +479,7 @@ def main():
     if exchanging:
         overflow = xchg["x"].overflowed() if state["c_side"] else any(e.overflowed() for e in xchg["ex"])
 
+    elapsed_rank0 = elapsed
     el = coll_device(torch.tensor([elapsed], dtype=torch.float64))
     units = coll_device(torch.tensor([float(min(live0, live1)) * args.steps], dtype=torch.float64))
     all_reduce(el, dist.ReduceOp.MAX)
@@ -527,7 +531,10 @@ def main():
                          # the same algorithmic bytes over the whole tick (this rank's): what the loop around the kernel leaves of it
                          "whole_tick": {"achieved": alg_bytes / (elapsed / args.steps) / 1e9,
                                         "frac": alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}},
-            "setup": {"clock_spinup_ms": SPINUP_MS},
+            "setup": {"clock_spinup_ms": SPINUP_MS, "sweep_timing_stride": stride,
+                      # of the timed region: until the one zrk_run_ticks call returned (everything issued, the side stream's
+                      # work handed over), and the synchronisation behind it
+                      "call_returned_after_us": (t_issued - t0) * 1e6, "sync_us": (elapsed_rank0 - (t_issued - t0)) * 1e6},
         }
         if exchanging:
             out["config"]["exchange"] = "rccl, C side" if state["c_side"] else f"torch.distributed {backend}"

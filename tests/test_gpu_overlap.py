@@ -232,9 +232,9 @@ def test_a_missile_whose_target_is_a_missile(monkeypatch):
         eng = HotPathEngine(device="cuda:0", dt_ms=dt, seed=8, noise="philox", gid0=0)
         eng.load(ids, sp, vel, t0, radars, missile_capacity=2 * pairs).enable_lists()
         # the A's: every other one would run out of time in its second tick in the air (1.5 ticks of fuse)
-        period_a = np.where(np.arange(pairs) % 2 == 0, 1.5 * dt / 1000, 40.0)
-        k = eng.launch_missiles(tgt, speed=2500.0, radius=300.0, period=period_a)
+        k = eng.launch_missiles(tgt, speed=2500.0, radius=300.0, period=40.0)
         assert k > pairs // 2
+        eng.store.dm_period[0:k:2] = 1.5 * dt / 1000       # (a launch with so short a fuse would be cancelled: Missile.py:98-99)
         # the B's fly the same lines (same launcher, same target, same speed: the same solves succeed) -- and are then
         # aimed at their A
         assert eng.launch_missiles(tgt, speed=2500.0, radius=50.0, period=40.0) == k

@@ -2034,6 +2034,29 @@ double d2_threshold(double m)
 
 }  // namespace
 
+// Diagnostics (ZRK_TRACE=1): host time stamps of one zrk_run_ticks call -- the calling thread's and the side stream's
+// thread's -- printed to stderr when the call returns.  Off: one predictable branch per stamp.
+namespace {
+struct HostTrace {
+    bool on = false;
+    std::mutex mu;
+    std::vector<std::pair<const char *, int64_t>> marks;
+    static int64_t now() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void mark(const char *what) { if (on) { std::lock_guard<std::mutex> lk(mu); marks.emplace_back(what, now()); } }
+    void dump()
+    {
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(mu);
+        if (marks.empty()) return;
+        std::stable_sort(marks.begin(), marks.end(), [](const auto &a, const auto &b) { return a.second < b.second; });
+        const int64_t t0 = marks.front().second;
+        for (const auto &m : marks) std::fprintf(stderr, "[zrk trace] %10.1f us  %s\n", (double)(m.second - t0) / 1e3, m.first);
+        marks.clear();
+    }
+};
+HostTrace g_trace;
+}  // namespace
+
 // Every host-side wait of this library is bounded (a dead peer rank, a helper thread that failed, a device that does
 // not come back must end in ZRK_E_STATE, not in a process that spins for ever): ZRK_HOST_WAIT_MS, default 30 s.
 namespace {
@@ -2098,6 +2121,9 @@ struct SideItem {
     int done_slot;                  // done[done_slot] is recorded last
     // one helper thread per rank (few host cores per rank): this thread also issues the tick's collective, right behind
     // the launch that raises the word it waits for (otherwise the exchange's own thread does)
+    // the LAST tick of a call has no next sweep to raise the word: its compaction waits, on the device, for an event recorded
+    // behind that sweep (an event record costs the compute stream a barrier packet -- harmless where no sweep follows)
+    hipEvent_t wait_event;
     zrk_exchange *post_x;
     int post_slot;
     const int64_t *post_send;
@@ -2128,6 +2154,8 @@ struct Side {
     bool masks_dirty = false;       // a call failed half-way: clear them before the next use
     uint64_t mask_pos = 0;
     hipEvent_t done[kMasks + 1] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t last_sweep = nullptr;   // recorded behind the last sweep of a call (SideItem::wait_event)
+    int cu_count = 0;                  // ZRK_SIDE_CUS: the side stream is confined to this many compute units (0: all)
     bool posted[kMasks + 1] = {false, false, false, false};
     uint64_t item_no[kMasks + 1] = {0, 0, 0, 0};
     uint64_t joined_upto = 0;       // items up to this number belong to calls whose side work joined_stream has taken in
@@ -2189,6 +2217,11 @@ struct zrk_ctx {
     int64_t grec_rows = 0, grec_n = 0;
     const void *grec_key = nullptr;
     bool grec_enabled = true;          // ZRK_GATHER_RECORDS=0: the columns
+    struct RadarBlock *rb_cache = nullptr;   // the next tick's radar records, derived ahead (fill_radar_block)
+    zrk_radar rb_cache_radars[ZRK_MAX_RADARS];
+    int rb_cache_R = -1;
+    uint32_t rb_cache_flags = 0;
+    bool tail_by_event = true;         // ZRK_TAIL_EVENT=0: the last compaction of a call is released by a launch that raises the host word
 };
 
 namespace {
@@ -2264,6 +2297,7 @@ ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
 {
     if (!c) return;
     host_wait_reload();
+    { const char *v = std::getenv("ZRK_TRACE"); g_trace.on = v && v[0] == '1'; }
     c->order_enabled = true; c->diag = 0; c->env_items = 0; c->env_order = -1;
     if (const char *v = std::getenv("ZRK_SWEEP_ORDER")) c->order_enabled = std::atoi(v) != 0;
     if (const char *v = std::getenv("ZRK_DIAG")) c->diag = (uint32_t)std::strtoul(v, nullptr, 0);
@@ -2272,6 +2306,7 @@ ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
     { const char *v = std::getenv("ZRK_OVERLAP_MIN"); c->overlap_min = v ? std::max(2, std::atoi(v)) : 4; }
     { const char *v = std::getenv("ZRK_OVERLAP_MIN_ROWS"); c->overlap_min_rows = v ? std::atoll(v) : 400000; }
     { const char *v = std::getenv("ZRK_GATHER_RECORDS"); c->grec_enabled = !(v && v[0] == '0'); }
+    { const char *v = std::getenv("ZRK_TAIL_EVENT"); c->tail_by_event = !(v && v[0] == '0'); }
     if (const char *v = std::getenv("ZRK_COMPACT_ITEMS")) c->env_items = std::max(1, std::atoi(v));
     if (const char *v = std::getenv("ZRK_COMPACT_ORDER")) c->env_order = std::strcmp(v, "block") != 0;
     c->fused_max_blocks = kFusedMaxBlocks;
@@ -2303,6 +2338,7 @@ ZRK_API void zrk_ctx_destroy(zrk_ctx *ctx)
 {
     if (!ctx) return;
     side_destroy(ctx->side);
+    std::free(ctx->rb_cache);
     if (ctx->grec) (void)hipFree(ctx->grec);
     for (hipEvent_t e : ctx->tev) (void)hipEventDestroy(e);
     delete ctx;
@@ -2343,9 +2379,17 @@ MissileArgs missile_args(const zrk_entities *e, int cur, const zrk_missiles *mis
     return M;
 }
 
-// The records of one scenario's radars, derived on the host from their current angles.
+// The records of one scenario's radars, derived on the host from their current angles.  Sixteen radars cost ~6 us of
+// trigonometry; the loop derives the NEXT tick's block right behind a launch (radar_block_ahead), so that the launch of
+// a tick -- the first one of a call above all, with the device idle -- finds it ready (keyed by the radars' bytes).
 void fill_radar_block(zrk_ctx *ctx, const zrk_radar *radars, int R, uint32_t flags, RadarBlock &rb)
 {
+    const uint32_t key_flags = flags & (ZRK_F_EXACT_ONLY | ZRK_F_PHILOX);
+    if (ctx->rb_cache && ctx->rb_cache_R == R && ctx->rb_cache_flags == key_flags && R > 0 &&
+        std::memcmp(ctx->rb_cache_radars, radars, sizeof(zrk_radar) * (size_t)R) == 0) {
+        std::memcpy(&rb, ctx->rb_cache, sizeof(rb));
+        return;
+    }
     std::memset(&rb, 0, sizeof(rb));
     for (int r = 0; r < ZRK_MAX_RADARS; ++r) {
         RadarPre pre;
@@ -2359,6 +2403,18 @@ void fill_radar_block(zrk_ctx *ctx, const zrk_radar *radars, int R, uint32_t fla
         }
         std::memcpy(rb.prew[r], &pre, sizeof(pre));
     }
+}
+
+void radar_block_ahead(zrk_ctx *ctx, const zrk_radar *radars, int R, uint32_t flags)
+{
+    if (R <= 0 || !radars) return;
+    if (!ctx->rb_cache) ctx->rb_cache = (RadarBlock *)std::malloc(sizeof(RadarBlock));
+    if (!ctx->rb_cache) return;
+    ctx->rb_cache_R = -1;                                 // (derive afresh)
+    RadarBlock *dst = ctx->rb_cache;
+    fill_radar_block(ctx, radars, R, flags, *dst);
+    std::memcpy(ctx->rb_cache_radars, radars, sizeof(zrk_radar) * (size_t)R);
+    ctx->rb_cache_R = R; ctx->rb_cache_flags = flags & (ZRK_F_EXACT_ONLY | ZRK_F_PHILOX);
 }
 
 // What a batched ensemble adds to the two launches of a tick.
@@ -3129,18 +3185,22 @@ int side_issue(Side *sd, const SideItem &it)
     // ahead of their input -- deadlocks the device as soon as anything else on it needs whole compute units in dispatch
     // order (e.g. another engine's single-launch compaction), and a one-lane wait kernel in front of it costs the side
     // stream 5 us a tick.  This thread has nothing else to do.
-    if (!spin_until([&] { return (int32_t)(*sd->hflag - it.flag_value) >= 0 || sd->stop.load(); })) {
+    if (it.wait_event) {
+        if (hipStreamWaitEvent(it.stream, it.wait_event, 0) != hipSuccess) { sd->err = "side stream: hipStreamWaitEvent failed"; return ZRK_E_HIP; }
+    } else if (!spin_until([&] { return (int32_t)(*sd->hflag - it.flag_value) >= 0 || sd->stop.load(); })) {
         // (the caller queued more work in front of the loop than the limit allows for, or the device is gone)
         sd->err = "side stream: the compute stream did not reach the next sweep within the host wait limit (ZRK_HOST_WAIT_MS)";
         return ZRK_E_STATE;
     }
-    if ((int32_t)(*sd->hflag - it.flag_value) < 0) { sd->err = "side stream: stopped"; return ZRK_E_STATE; }
+    if (!it.wait_event && (int32_t)(*sd->hflag - it.flag_value) < 0) { sd->err = "side stream: stopped"; return ZRK_E_STATE; }
+    g_trace.mark("side: flag seen");
     hipLaunchKernelGGL(k_compact_side, dim3(it.C.nb + (it.M.m > 0 ? 1 : 0)), dim3(kCompBlock), 0, it.stream, it.C, it.by_ticket, it.M);
     // an exchange's collective (on the exchange's own stream) waits for this word: the list and its events are complete
     if (it.raise) hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, it.stream, it.raise, it.raise_value);
     if (hipGetLastError() != hipSuccess) { sd->err = "side stream: compaction launch failed"; return ZRK_E_HIP; }
     if (hipEventRecord(sd->done[it.done_slot], it.stream) != hipSuccess) { sd->err = "side stream: hipEventRecord failed"; return ZRK_E_HIP; }
     sd->posted[it.done_slot] = true;
+    g_trace.mark("side: compaction issued");
     if (it.post_x && exchange_post_behind_flag(it.post_x, it.post_slot, it.post_send, it.post_recv, it.post_words, it.raise_value) != 0) {
         sd->err = std::string("side stream: ") + it.post_x->err;
         return ZRK_E_HIP;
@@ -3177,7 +3237,22 @@ Side *side_of(zrk_ctx *ctx)
 {
     if (ctx->side) return ctx->side;
     Side *sd = new Side;
-    bool ok = hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking) == hipSuccess &&
+    // ZRK_SIDE_CUS=n[,first]: confine the side stream to n compute units (mask bits first .. first + n - 1; on this part
+    // consecutive bits fall on different XCDs), so that the compaction beside a sweep takes whole compute units from it
+    // instead of wave slots on every one
+    bool made = false;
+    if (const char *v = std::getenv("ZRK_SIDE_CUS")) {
+        int n = 0, first = 0;
+        if (std::sscanf(v, "%d,%d", &n, &first) >= 1 && n > 0 && first >= 0 && first + n <= 512) {
+            uint32_t mask[16] = {};
+            for (int b = first; b < first + n; ++b) mask[b / 32] |= 1u << (b % 32);
+            const uint32_t words = (uint32_t)((std::max(ctx->cus, first + n) + 31) / 32);
+            made = hipExtStreamCreateWithCUMask(&sd->stream, words, mask) == hipSuccess;
+            if (made) sd->cu_count = n; else (void)hipGetLastError();
+        }
+    }
+    bool ok = (made || hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking) == hipSuccess) &&
+              hipEventCreateWithFlags(&sd->last_sweep, hipEventDisableTiming) == hipSuccess &&
               hipHostMalloc((void **)&sd->hflag, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
               hipHostGetDevicePointer((void **)&sd->hflag_dev, (void *)sd->hflag, 0) == hipSuccess;
     if (ok) *sd->hflag = 0u;
@@ -3185,6 +3260,7 @@ Side *side_of(zrk_ctx *ctx)
     if (!ok) {
         (void)hipGetLastError();
         for (int k = 0; k <= Side::kMasks; ++k) if (sd->done[k]) (void)hipEventDestroy(sd->done[k]);
+        if (sd->last_sweep) (void)hipEventDestroy(sd->last_sweep);
         if (sd->hflag) (void)hipHostFree((void *)sd->hflag);
         if (sd->stream) (void)hipStreamDestroy(sd->stream);
         delete sd;
@@ -3250,6 +3326,7 @@ void side_destroy(Side *sd)
     }
     if (sd->stream) { (void)hipStreamSynchronize(sd->stream); (void)hipStreamDestroy(sd->stream); }
     for (int k = 0; k <= Side::kMasks; ++k) if (sd->done[k]) (void)hipEventDestroy(sd->done[k]);
+    if (sd->last_sweep) (void)hipEventDestroy(sd->last_sweep);
     for (int k = 0; k < Side::kMasks; ++k) if (sd->masks[k]) (void)hipFree(sd->masks[k]);
     for (int k = 0; k < Side::kMasks; ++k) if (sd->codes[k]) (void)hipFree(sd->codes[k]);
     if (sd->pend) (void)hipFree(sd->pend);
@@ -3290,6 +3367,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (!(st->flags & ZRK_F_UNION_BITS)) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: the exchange carries the wire format (ZRK_F_UNION_BITS)");
     }
     hipStream_t s = (hipStream_t)stream;
+    g_trace.mark("run_ticks: entry");
     // a batched ensemble: S scenarios of rows_per_scenario rows each, radars and scan state on the device
     EnsLaunch EL;
     std::memset(&EL, 0, sizeof(EL));
@@ -3485,7 +3563,9 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         // (a tick that fails before its sweep is launched leaves the loop state as the last complete tick left it)
         const int32_t cur_before = st->cur, vis_cur_before = st->vis_cur;
         st->cur ^= 1;
-        const bool prof = n_prof && (k % stride == 0);
+        // (the LAST tick of every window of `stride` ticks is the timed one, and the call's last tick: the first launch of a
+        // call, from an idle stream, is not what a tick of the loop looks like, and a timed launch costs the stream ~5 us)
+        const bool prof = n_prof && ((k + 1) % stride == 0 || k + 1 == K);
         const bool on_dispatch = prof && ctx->time_on_dispatch && (st->n > 0 || (m > 0 && m <= 1024 * (int64_t)kMissileItems));
         if (prof && !on_dispatch && hipEventRecord(ev[2 * (k / stride)], s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "hipEventRecord"); st->cur = cur_before; break; }
         const int slot = (int)(st->tick % (uint64_t)ZRK_EXCHANGE_SLOTS);
@@ -3558,6 +3638,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                           on_dispatch ? ev[2 * (k / stride)] : nullptr, on_dispatch ? ev[2 * (k / stride) + 1] : nullptr,
                           w.order_ctr + kOrderCtrSet * (oph ^ 1), w.order_ctr + kOrderCtrSet * oph, marks ? sd->pend : nullptr, mark);
         rc = rc_sweep;
+        g_trace.mark("run_ticks: sweep launched");
         if (rc_sweep == 0 && marks) marks_used = true;
         if (rc == 0 && ordering) { ctx->order_ready = true; ctx->order_phase = oph ^ 1; }
         if (rc == 0 && held.on) rc = issue_held();                           // (the previous tick's item, see below)
@@ -3574,6 +3655,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             pend.on = false;
         }
         if (!ens && rc_sweep == 0) zrk_scan_advance(radars, scan, R);         // Radar.py:205 (an ensemble's: on the device)
+        if (!ens && rc_sweep == 0 && !rb_through_memory) radar_block_ahead(ctx, radars, R, st->flags);
         if (rb_through_memory) {                                             // the next tick's records ride with this compaction
             fill_radar_block(ctx, radars, R, st->flags, put.rb);
             put.dst = (uint32_t *)rb_dev[(st->tick + 1) & 1u];
@@ -3606,6 +3688,10 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             if (ev_words && !fused && hipMemsetAsync(list + list_words, 0, sizeof(int64_t), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset events"); break; }
             it.stream = side_stream; it.flag_value = v; it.done_slot = side_slot;
             it.M = M; it.M.apply = 0;
+            if (k + 1 == K && ctx->tail_by_event) {
+                if (hipEventRecord(sd->last_sweep, s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "hipEventRecord"); break; }
+                it.wait_event = sd->last_sweep;
+            }
             if (xio) {
                 // The collective of this tick runs on the exchange's own stream, released by a launch behind the compaction.
                 // The list it sends was last sent ZRK_EXCHANGE_SLOTS ticks ago, and that collective must be through before the compaction
@@ -3647,11 +3733,12 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         st->time_ms += st->dt_ms;                                            // Manager.py:140
         st->tick += 1;
     }
+    g_trace.mark("run_ticks: loop done");
     if (sd) {
         if (held.on && rc == 0) rc = issue_held();
         // behind the last tick: its removals as tombstones, the word the side stream's thread waits for, then the side
         // stream's work is issued to the last item and the compute stream takes it in: the lists are the caller's
-        if (rc == 0 && side_last >= 0) {                  // (first: the last compaction may start as soon as the last sweep is over)
+        if (rc == 0 && side_last >= 0 && !ctx->tail_by_event) {   // (first: the last compaction may start as soon as the last sweep is over)
             hipLaunchKernelGGL(k_raise_flag_system, dim3(1), dim3(1), 0, s, sd->hflag_dev, sd->seq);
             rc = check_launch(ctx, "k_raise_flag");
         }
@@ -3672,6 +3759,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         }
         const int rc_side = side_drain(ctx, sd, sd->head.load());
         if (rc == 0) rc = rc_side;
+        g_trace.mark("run_ticks: side drained");
         if (xio) xio->x->via_side = nullptr;                 // (everything it carried has been issued, or has failed with it)
         if (rc != 0) { sd->masks_dirty = true; sd->pend_rows = 0; }  // (marks: allocated and cleared anew)
         if (rc == 0 && side_last >= 0 && sd->posted[side_last]) {
@@ -3679,6 +3767,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             else { sd->joined_upto = sd->head.load(); sd->joined_stream = s; }
         }
     }
+    g_trace.mark("run_ticks: exit");
+    g_trace.dump();
     // a collective whose hand-over never came went out poisoned (k_wait_flag): the host knows without a synchronisation
     if (rc == 0 && xio && exchange_gave_up(xio->x) != 0) rc = fail(ctx, ZRK_E_STATE, zrk_exchange_last_error(xio->x));
     if (n_prof && !deferred) {
