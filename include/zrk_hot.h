@@ -425,6 +425,11 @@ int zrk_run_ticks_ensemble(zrk_ctx *ctx, const zrk_entities *ents, const zrk_mis
 /* zrk_run_ticks* with prof_stride < 0 (sweep_ms may be NULL) only records the event pairs, every -prof_stride-th tick,
  * and returns without synchronising; this reads the first n durations [ms] afterwards (it waits for them). */
 int zrk_read_sweep_ms(zrk_ctx *ctx, float *sweep_ms /* HOST out */, int n);
+/* The overlapped loop of one scenario without an exchange sweeps TWO consecutive ticks per launch (the trajectory columns
+ * are read once for both; ZRK_PAIR=0: one tick per launch): how many ticks the launch behind each timing sample swept, and
+ * what the last zrk_run_ticks* call did (1 or 2). */
+int zrk_read_sweep_ticks(zrk_ctx *ctx, int32_t *ticks /* HOST out */, int n);
+int zrk_last_run_ticks_per_launch(zrk_ctx *ctx);
 
 /* Numerics self-test hooks used by tests/: y[i] = op(a[i], b[i]) in device binary64.
  * op: 0 sqrt(a), 1 a/b, 2 atan2(a,b), 3 asin(a), 4 fma-chain norm of (a,b,0). */

@@ -212,6 +212,8 @@ _PROTOTYPES = {
     "zrk_selftest_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64, C.c_void_p,
                                      C.c_int64, C.c_void_p]),
     "zrk_selftest_host_wait": (C.c_int, [C.c_int, C.c_int]),
+    "zrk_read_sweep_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
+    "zrk_last_run_ticks_per_launch": (C.c_int, [C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

@@ -19,6 +19,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <cfloat>
 #include <cmath>
 #include <cstddef>
@@ -52,6 +53,7 @@ __device__ long long *g_wave_probe;
 constexpr double kRad2Deg = 180.0 / 3.14159265358979323846;   // numpy.degrees factor
 constexpr int kCompBlock = 1024;          // list slots per compaction workgroup (count / scan / scatter unit)
 constexpr uint32_t kSparseVis = 1u << 16;  // internal sweep flag: write only non-zero masks
+constexpr uint32_t kSparseVis2 = 1u << 17; // ... the same for the second tick of a pair launch
 constexpr uint32_t kNoInside = 1u << 21;   // diagnostics (ZRK_DIAG bit 0): no wave-level "certainly visible" shortcut
 constexpr uint32_t kNoBoxCache = 1u << 22; // diagnostics (ZRK_DIAG bit 1): every wave takes its box from the rows it has just computed
 constexpr float kGuard = 3e-5f;                               // relative half-width of the "ambiguous" band
@@ -119,15 +121,25 @@ struct SweepParams {
     uint32_t *vis;              // indexed by LIST index
     const int32_t *order;       // row block of each workgroup, expensive ones first (NULL: identity)
     int32_t *order_next;        // the same for the next tick, built as this sweep goes (NULL: not built), see below
-    // overlapped loop: removals decided by this tick's missile phase are MARKS (pend[row] = this tick's mark value,
+    // overlapped loop: removals decided by this launch's missile phase are MARKS (pend[row] = the removal tick's mark value,
     // written only where there is none yet, never cleared inside a call) that the row's own thread carries out in the next
-    // tick -- flag down, position frozen in both buffers -- instead of a launch between two sweeps (AirEnv.py:33-40:
-    // effective from the next tick either way).  A mark other than this tick's means "removed before this tick".
-    // NULL: no marks
+    // LAUNCH -- flag down, position frozen in both buffers -- instead of a launch between two sweeps (AirEnv.py:33-40:
+    // effective from the next tick either way).  A mark value is 2 + 2 * (tick % 126) + b, b = the index of the position
+    // buffer that was current in the removal tick: pos_abs[b] holds the frozen position, pos_abs[b ^ 1] is to receive it.
+    // A mark other than this launch's means "removed before this launch".  NULL: no marks
     uint8_t *pend;
-    uint32_t mark, _pad3;       // this tick's mark value: 1 + tick % 255
+    uint32_t mark, mark2;       // this launch's mark values (mark2: the second tick of a pair, else = mark)
     uint8_t *alive_w;           // (the alive column again, writable)
-    const double *pos_prev;     // the other position buffer
+    double *pos_prev;           // the other position buffer: last tick's positions -- and, in a PAIR launch, the second tick's output
+    double *pos_abs[2];         // the two position buffers by absolute index (see the marks above)
+    // PAIR launch: two consecutive ticks t, t + 1 in one pass over the table -- the trajectory columns are read once, both
+    // ticks' positions, gates and noise computed from them (a tick's positions never depend on the tick before: the
+    // reference recomputes them from the trajectory, AirObject.py:23-25), tick t + 1's positions go to pos_prev, its masks to
+    // vis2, its radar records are rb2.  What tick t removes is not known to the row threads (its missile phase runs in
+    // this very grid): they sweep tick t + 1 as if nothing was removed, and the rows tick t did remove are put right
+    // afterwards -- mask bits by tick t's event builder (MissileArgs::clear_vis), flag and position by the next launch.
+    double t2;
+    uint32_t *vis2;
     uint32_t *order_ctr;        // kOrderRegions pairs (expensive / cheap row blocks recorded so far), kOrderCtrStride words apart
     uint32_t *order_ctr_next;   // the next tick's set, cleared here
     int64_t n, cap;
@@ -149,6 +161,11 @@ struct SweepParams {
     uint32_t flags;
     RadarBlock rb;
 };
+// a PAIR launch carries the second tick's records behind the first's (a plain launch does not pay for their 10 KB)
+struct SweepParamsPair : SweepParams {
+    RadarBlock rb2;
+};
+static_assert(sizeof(SweepParams) % 8 == 0 && sizeof(SweepParamsPair) == sizeof(SweepParams) + sizeof(RadarBlock), "rb2 sits right behind SweepParams");
 
 // The missile phase rides along in other kernels' grids (its own launches would cost more in kernel
 // boundaries than in work): the per-row step as extra workgroups of the sweep, the ordered event list
@@ -176,6 +193,17 @@ struct MissileArgs {
     // from one cache line instead of eight (ten thousand missiles' gathers were a tenth of the sweep's traffic); kept
     // by zrk_run_ticks (ensure_gather_records), NULL: the columns
     const double *grec;
+    const double *pos_abs[2];   // the two position buffers by absolute index: a removed target's frozen position is in
+                                // pos_abs[its mark & 1] (SweepParams::pend)
+    // PAIR launch (see SweepParams): the missile workgroups step tick t, meet at a barrier of their own (bar[0] counts
+    // arrivals up to bar_target; bar[1]: somebody gave up) so that tick t's marks are everybody's, and step tick t + 1
+    uint8_t *ev_code2;          // tick t + 1's per-row event codes
+    uint32_t mark2, bar_target;
+    uint32_t *bar;
+    double t2;
+    // compaction side: the event builder of a pair's FIRST tick clears, in the second tick's mask buffer, the bits of the rows
+    // its events removed (they were swept once more as if nothing had happened)
+    uint32_t *clear_vis;
 };
 
 // Dispatch order of the next sweep.  The sweep's duration is set by the expensive waves (rows inside some
@@ -225,7 +253,7 @@ __device__ __forceinline__ double floormod_small(double a, double b)
 // rb.cold) + r * sizeof(RadarCold) is a load from page 0x1000: the memory access fault of round 2.
 __device__ uint32_t g_device_fault;
 
-__device__ __noinline__ bool visible_exact(uint64_t cold_record, double dx, double dy, double dz)
+__device__ __forceinline__ bool visible_exact_body(uint64_t cold_record, double dx, double dy, double dz)
 {
     // radar r's cold record in the kernel-argument segment, by address (a by-value copy of the record would travel
     // through scratch memory); the address is wave-uniform, so the fourteen words come in through scalar loads
@@ -258,6 +286,13 @@ __device__ __noinline__ bool visible_exact(uint64_t cold_record, double dx, doub
     const double az = floormod_small(atan2(dy, dx) * kRad2Deg, 360.0);
     const double el = floormod_small(asin(dz / dist) * kRad2Deg, 180.0);
     return (c.az_lo <= az) && (az <= c.az_hi) && (c.el_lo <= el) && (el <= c.el_hi);
+}
+
+// Out of line: a rare path inside the sweep's hottest loop, kept small there.  (Inline it costs the kernel 126 vector
+// registers; what lives across a call sits in the callee-saved ranges, so calls are not free either: see the replay.)
+__device__ __noinline__ bool visible_exact(uint64_t cold_record, double dx, double dy, double dz)
+{
+    return visible_exact_body(cold_record, dx, dy, dz);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -458,13 +493,16 @@ __device__ __forceinline__ void noise_draw3(NoiseState &st, float out[3])
 // scalar-load burst per radar, no uniform branches (degenerate radars are encoded in the thresholds
 // by the host), predicates folded into two float minima, and only two divergent regions -- the
 // binary64 fallback for guard-band pairs and the noise draw for detections.
-__device__ uint8_t missile_step_row(const double *__restrict__ sp, const double *__restrict__ vel,
+__device__ __forceinline__ uint8_t missile_step_row(const double *__restrict__ sp, const double *__restrict__ vel,
                                     const double *__restrict__ t0, const uint8_t *alive,
                                     const int32_t *__restrict__ lidx, const double *pos_prev, int64_t cap,
                                     const int32_t *__restrict__ m_slot, const int32_t *__restrict__ m_tgt,
                                     const double *__restrict__ m_radius, double *__restrict__ m_period,
                                     uint8_t *__restrict__ m_status, int64_t row, double t, double dts,
-                                    uint8_t *pend = nullptr, uint32_t mark = 0, const double *grec = nullptr);
+                                    uint8_t *pend = nullptr, uint32_t mark = 0, const double *grec = nullptr,
+                                    const double *pos_abs0 = nullptr, const double *pos_abs1 = nullptr, uint32_t mark_first = 0,
+                                    const char *rb_first = nullptr, int R = 0, bool philox = false, uint64_t seed = 0,
+                                    uint64_t tick_first = 0, int64_t gid0 = 0, double t_first = 0.0);
 
 // Horizontal bounding box of the wave: two minima and two maxima over the 64 lanes, wave-uniform on return.
 // min / max are idempotent, so rotations inside each row of 16 (by 1, 2, 4, 8) and the two row broadcasts
@@ -641,7 +679,7 @@ __device__ __forceinline__ Cull cull_box(const PreTable &T, int R, bool shortcut
 // Radars in `c.cand`, in order, over the wave's rows at (x, y, z); leaves the visibility mask in `mask` and the
 // (perturbed) position in place.  Called with the whole wave converged (the early-outs are wave-level votes).
 template <bool PHILOX>
-__device__ __forceinline__ void sweep_rows(const SweepParams &P, const char *rbp, uint64_t seed, const Cull &c, int64_t li,
+__device__ __forceinline__ void sweep_rows(uint64_t tick, int64_t gid0, const char *rbp, uint64_t seed, const Cull &c, int64_t li,
                                            bool live, double &x, double &y, double &z, uint32_t &mask, int64_t probe_wave)
 {
     typedef const uint32_t __attribute__((address_space(4))) *ConstWords;
@@ -661,7 +699,7 @@ __device__ __forceinline__ void sweep_rows(const SweepParams &P, const char *rbp
                                                                (uint32_t)__builtin_amdgcn_readlane((int)c.pz_lo, r));
             const bool vis = live & (!by_plane | (z - rpz >= 0.0));
             if (PHILOX && !seeded && __ballot(vis)) {
-                ns = noise_init(seed, P.tick, (uint64_t)(P.gid0 + li));
+                ns = noise_init(seed, tick, (uint64_t)(gid0 + li));
                 seeded = true;
             }
             if (vis) {
@@ -724,7 +762,7 @@ __device__ __forceinline__ void sweep_rows(const SweepParams &P, const char *rbp
         const bool amb = in_range & ((fabsf(t) <= gd) | !(d2f < d2f_in));
         if (amb) vis = visible_exact((uint64_t)(rbp + offsetof(RadarBlock, cold) + (size_t)r * sizeof(RadarCold)), dx, dy, dz);
         if (PHILOX && !seeded && __ballot(vis)) {
-            ns = noise_init(seed, P.tick, (uint64_t)(P.gid0 + li));
+            ns = noise_init(seed, tick, (uint64_t)(gid0 + li));
             seeded = true;
         }
         if (vis) {
@@ -741,22 +779,166 @@ __device__ __forceinline__ void sweep_rows(const SweepParams &P, const char *rbp
 #endif
 }
 
+// One row's radar phase of tick `tick` once more, by ONE lane: every radar's gate in order by the reference's formula
+// (visible_exact -- the tiers in front of it in sweep_rows only ever settle pairs it would settle the same way, which the
+// ZRK_F_EXACT_ONLY tests pin), a noise draw per detection from the row's stream.  (x, y, z): in, the row's position by
+// its trajectory; out, what the sweep leaves in the position buffer.  For the missile phase of a PAIR launch's second tick,
+// which needs such a position of a row whose own thread, somewhere in the same grid, may not have run yet.  Rare (a target
+// removed in the pair's first tick, a target behind its missile in the list): the cost does not matter.
+struct Vec3d {
+    double x, y, z;
+};
+
+__device__ __noinline__ Vec3d replay_row_radar_phase(const char *rbp, int R, bool philox, uint64_t seed, uint64_t tick, uint64_t key,
+                                                     double x, double y, double z)
+{
+    NoiseState ns = NoiseState{0u, 0u, 0u, 0u};
+    bool seeded = false;
+    for (int r = 0; r < R; ++r) {
+        const double *hot = (const double *)(rbp + offsetof(RadarBlock, hotw) + (size_t)r * sizeof(RadarHot));   // px, py, pz
+        const double dx = x - hot[0], dy = y - hot[1], dz = z - hot[2];
+        if (!visible_exact((uint64_t)(rbp + offsetof(RadarBlock, cold) + (size_t)r * sizeof(RadarCold)), dx, dy, dz)) continue;
+        if (philox) {
+            if (!seeded) { ns = noise_init(seed, tick, key); seeded = true; }
+            float nz[3];
+            noise_draw3(ns, nz);
+            x += (double)nz[0]; y += (double)nz[1]; z += (double)nz[2];
+        }
+    }
+    return Vec3d{x, y, z};
+}
+
+// The barrier of a PAIR launch's missile workgroups (the `mb` leading workgroups of the grid -- dispatched first, a few
+// dozen, resident all at once on a device that holds nothing of this stream's but them): arrivals are counted up to
+// `target` (monotonic over launches, compared modulo 2^32); behind it tick t's marks and missile rows are everybody's.
+// Bounded: a workgroup that is not joined in time raises bar[1] (zrk_compact_status reports it) and goes on.
+__device__ __forceinline__ void missile_pair_barrier(uint32_t *bar, uint32_t target)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's marks and missile rows have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while ((int32_t)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            if (++spins > (1 << 22)) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+// The wave-level classification of one tick: from the block's box record grown to time `t` (first wave classifies, the
+// others take its result from LDS), or -- no usable record -- from the box of the positions just computed.  Returns whether the
+// record was used; `fresh` receives the box of the computed positions when it was not (for the record left behind).
+struct FreshBox {
+    float blx, bly, blz, bhx, bhy, bhz;
+    bool any_wild, any_live;
+};
+
+struct CullShared {
+    uint32_t cand, inside, plane, pad;
+    uint32_t pz_lo[ZRK_MAX_RADARS], pz_hi[ZRK_MAX_RADARS];
+};
+
+struct CullOrNot {
+    Cull c;
+    bool have;
+};
+
+__device__ __forceinline__ CullOrNot cull_from_record(const PreTable &T, CullShared &S, int R, bool shortcuts, double t, uint32_t bw0,
+                                                      uint32_t bw1, uint32_t bw2, uint32_t bw3, uint32_t bw4, uint32_t bw5, uint32_t bw6,
+                                                      uint32_t bw7, uint32_t bv0, uint32_t bstate, uint32_t tref_lo, uint32_t tref_hi)
+{
+    CullOrNot out;
+    out.c.cand = 0u; out.c.inside = 0u; out.c.plane = 0u; out.c.pz_lo = 0u; out.c.pz_hi = 0u;
+    out.have = false;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double t_ref = __builtin_bit_cast(double, ((uint64_t)tref_hi << 32) | tref_lo);
+    const float age = fabsf((float)(t - t_ref)) * 1.000001f + 1e-6f;      // seconds, rounded up
+    const float g0 = __builtin_bit_cast(float, bw6) * age, g1 = __builtin_bit_cast(float, bw7) * age;
+    const float g2 = __builtin_bit_cast(float, bv0) * age;
+    const float grow = fmaxf(fmaxf(g0, g1), g2);
+    if (bstate == kBoxEmpty) { out.have = true; return out; }   // nobody alive at t_ref, nobody is revived: nothing to sweep
+    if (!(bstate == kBoxOk && grow <= kBoxMaxGrow)) return out;
+    if (wv == 0) {
+        // (the 1e-3 m covers the rounding of the grown bounds; derive_pre's slack has a metre for the rest)
+        const Cull c0 = cull_box(T, R, shortcuts,
+                                 __builtin_bit_cast(float, bw0) - g0 - 1e-3f, __builtin_bit_cast(float, bw1) - g1 - 1e-3f,
+                                 __builtin_bit_cast(float, bw2) - g2 - 1e-3f, __builtin_bit_cast(float, bw3) + g0 + 1e-3f,
+                                 __builtin_bit_cast(float, bw4) + g1 + 1e-3f, __builtin_bit_cast(float, bw5) + g2 + 1e-3f);
+        if (lane == 0) { S.cand = c0.cand; S.inside = c0.inside; S.plane = c0.plane; }
+        if (lane < ZRK_MAX_RADARS) { S.pz_lo[lane] = c0.pz_lo; S.pz_hi[lane] = c0.pz_hi; }
+    }
+    __syncthreads();
+    out.c.cand = S.cand; out.c.inside = S.inside; out.c.plane = S.plane;
+    out.c.pz_lo = S.pz_lo[lane & (ZRK_MAX_RADARS - 1)]; out.c.pz_hi = S.pz_hi[lane & (ZRK_MAX_RADARS - 1)];
+    out.have = true;
+    return out;
+}
+
+struct CullAndBox {
+    Cull c;
+    FreshBox fb;
+};
+
+__device__ __forceinline__ CullAndBox cull_from_rows(const PreTable &T, int R, bool shortcuts, bool live, double x, double y, double z)
+{
+    CullAndBox out;
+    Cull &c = out.c;
+    FreshBox &fb = out.fb;
+    c.cand = 0u; c.inside = 0u; c.plane = 0u; c.pz_lo = 0u; c.pz_hi = 0u;
+    // the box of the positions just computed (wave-uniform after the reductions)
+    const float inf = __builtin_inff(), kBig = 1e30f;
+    const float fx0 = (float)x, fy0 = (float)y, fz0 = (float)z;
+    const bool wild = live & !((fabsf(fx0) < kBig) & (fabsf(fy0) < kBig) & (fabsf(fz0) < kBig));
+    fb.blx = live ? fx0 : inf; fb.bly = live ? fy0 : inf; fb.blz = live ? fz0 : inf;
+    fb.bhx = live ? fx0 : -inf; fb.bhy = live ? fy0 : -inf; fb.bhz = live ? fz0 : -inf;
+    wave_bbox(fb.blx, fb.bly, fb.bhx, fb.bhy);
+    wave_minmax(fb.blz, fb.bhz);
+    fb.any_wild = __ballot(wild) != 0ull; fb.any_live = __ballot(live) != 0ull;
+    const uint32_t all = (R >= 32) ? 0xFFFFFFFFu : ((1u << R) - 1u);
+    if (!fb.any_live) { c.cand = 0u; c.inside = 0u; c.plane = 0u; }
+    else if (fb.any_wild) { c.cand = all; c.inside = 0u; c.plane = 0u; }   // min / max drop NaNs: never cull such a wave
+    else c = cull_box(T, R, shortcuts, fb.blx, fb.bly, fb.blz, fb.bhx, fb.bhy, fb.bhz);
+    return out;
+}
+
 // One pass over the table: 64 consecutive rows per wave.  ADVANCE / LIDX mirror ZRK_F_ADVANCE and
 // list_index != NULL as template parameters so that the row's column loads sit in one basic block and are all in
-// flight before anything waits for one.
-template <bool PHILOX, bool ADVANCE, bool LIDX, bool MARKS = false>
-__global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, const MissileArgs M)
+// flight before anything waits for one.  PAIR: two consecutive ticks in the one pass (SweepParams::t2).
+template <bool PHILOX, bool ADVANCE, bool LIDX, bool MARKS = false, bool PAIR = false>
+// (amdgpu_num_sgpr: up to 80 scalar registers a compute unit holds eight workgroups, up to 96 seven; the pair variant, which
+// calls out of line from its missile phase, would take 102 -- six -- if left alone)
+__global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) void k_tick_sweep(const std::conditional_t<PAIR, SweepParamsPair, SweepParams> P, const MissileArgs M)
 {
+    static_assert(!PAIR || (MARKS && ADVANCE), "a pair launch advances and carries removals as marks");
     // the previous tick's compaction is over and visible once this grid starts: tell the exchange stream, which waits
     // for this word instead of an event (an event record costs the compute stream a barrier packet per tick)
     if (P.flag && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store(P.flag, P.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // one scenario: the radar records travel in this launch's kernel-argument segment (THE ONLY PLACE where that address is
+    // formed: see g_device_fault); a batched ensemble: a table in device memory, indexed below
+    const char *const kernarg = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
     if ((int)blockIdx.x < P.mb) {              // leading workgroups: Missile.step for every in-flight row (a long
         // dependent chain -- dispatched first, it is over long before the sweep's last wave is)
         const int64_t row = (int64_t)blockIdx.x * ZRK_BLOCK + threadIdx.x;
+        const char *rb_first = P.rb_table ? P.rb_table : kernarg + offsetof(SweepParams, rb);
         if (row < M.m)
             M.ev_code[row] = missile_step_row(M.sp, M.vel, M.t0, M.alive, M.lidx, M.pos_prev, M.cap, M.m_slot, M.m_tgt,
-                                              M.m_radius, M.m_period, M.m_status, row, M.t, M.dts, M.pend, M.mark, M.grec);
+                                              M.m_radius, M.m_period, M.m_status, row, M.t, M.dts, M.pend, M.mark, M.grec,
+                                              M.pos_abs[0], M.pos_abs[1]);
+        if (PAIR) {
+            missile_pair_barrier(M.bar, M.bar_target);
+            if (row < M.m)
+                M.ev_code2[row] = missile_step_row(M.sp, M.vel, M.t0, M.alive, M.lidx, M.pos_cur, M.cap, M.m_slot, M.m_tgt,
+                                                   M.m_radius, M.m_period, M.m_status, row, M.t2, M.dts, M.pend, M.mark2, M.grec,
+                                                   M.pos_abs[0], M.pos_abs[1], /* second tick of a pair: */ M.mark, rb_first, P.R,
+                                                   PHILOX, P.seed, P.tick, P.gid0, M.t);
+        }
         return;
     }
     const int tid = threadIdx.x;
@@ -770,18 +952,21 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     }
     const int64_t wave = (int64_t)blk * (ZRK_BLOCK / 64) + (tid >> 6);
     const int64_t cap = P.cap;
-    // one scenario: the radar records travel in this launch's kernel-argument segment; a batched ensemble: block `scen`
-    // of a table in device memory (written by the previous tick's compaction launch), its own noise key, its own lists
+    // a batched ensemble: block `scen` of a table in device memory (written by the previous tick's compaction launch),
+    // its own noise key, its own lists
     const int scen = P.bps ? (int)__umulhi((uint32_t)blk, P.bps_magic) : 0;
-    const char *rbp = P.rb_table ? P.rb_table + (size_t)scen * sizeof(RadarBlock)
-                                 : (const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SweepParams, rb);
+    const char *rbp = P.rb_table ? P.rb_table + (size_t)scen * sizeof(RadarBlock) : kernarg + offsetof(SweepParams, rb);
+    const char *rbp2 = kernarg + sizeof(SweepParams);             // (PAIR: SweepParamsPair::rb2)
     uint64_t seed = P.seed;
     if (P.seeds) {
         const uint64_t *ps = P.seeds + scen;
         asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seed) : "s"(ps) : "memory");
     }
     __shared__ PreTable s_pre;
+    __shared__ PreTable s_pre2;                                   // (PAIR)
     uint4 pre_piece = pre_table_fetch(rbp);
+    uint4 pre_piece2 = pre_piece;
+    if (PAIR) pre_piece2 = pre_table_fetch(rbp2);
     ZRK_WAVE_PROBE(wave, 0, wall_clock64());
     // where the wave runs: HW_REG_HW_ID (wave / simd / cu / sh / se) and HW_REG_XCC_ID
     ZRK_WAVE_PROBE(wave, 6, (long long)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
@@ -802,7 +987,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     } else {
         sx0 = P.pos[ic]; sy0 = P.pos[cap + ic]; sz0 = P.pos[2 * cap + ic];
     }
-    const bool removed = MARKS && (pk != 0u) & (pk != P.mark);   // marked in an earlier tick of this call
+    const bool removed = MARKS && (pk != 0u) & (pk != P.mark) & (pk != P.mark2);   // marked in an earlier launch of this call
     const bool live = (i < P.n) & (al != 0) & !removed;
     const int64_t li = (LIDX && i < P.n) ? (int64_t)lix : i;     // where this row sits in (its scenario's) AirEnv list
     // the wave's box record, if the caller keeps any (zrk_run_ticks does): twelve scalar words
@@ -815,69 +1000,55 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
                      : "=&s"(b0), "=&s"(b1), "=&s"(bv) : "s"(pb) : "memory");
     }
     const uint32_t bw[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-    stage_pre_table<1 + (LIDX ? 1 : 0) + (ADVANCE ? 7 : 3)>(s_pre, pre_piece);
+    constexpr int kRowLoads = 1 + (MARKS ? 1 : 0) + (LIDX ? 1 : 0) + (ADVANCE ? 7 : 3);
+    stage_pre_table<(PAIR ? 1 : 0) + kRowLoads>(s_pre, pre_piece);
+    if (PAIR) stage_pre_table<kRowLoads>(s_pre2, pre_piece2);
     const bool shortcuts = !(P.flags & kNoInside);
-    Cull c;
+    Cull c, c2;
     c.cand = 0u; c.inside = 0u; c.plane = 0u; c.pz_lo = 0u; c.pz_hi = 0u;
-    bool have = false;                                   // classified from the record, before the rows are here
+    c2 = c;
+    bool have = false, have2 = !PAIR;                    // classified from the record, before the rows are here
     const uint32_t bstate = bv[1];
-    __shared__ struct { uint32_t cand, inside, plane, pad; uint32_t pz_lo[ZRK_MAX_RADARS], pz_hi[ZRK_MAX_RADARS]; } s_cull;
+    __shared__ CullShared s_cull, s_cull2;
     __shared__ float s_wbox[ZRK_BLOCK / 64][12];
     const int wv = tid >> 6, lane = tid & 63;
     // (every wave of the workgroup reads the same record, so all of them take the same way through here)
     if (cached && bstate != 0u && !(P.flags & kNoBoxCache)) {
-        const double t_ref = __builtin_bit_cast(double, ((uint64_t)bv[3] << 32) | bv[2]);
-        const float age = fabsf((float)(P.t - t_ref)) * 1.000001f + 1e-6f;      // seconds, rounded up
-        const float g0 = __builtin_bit_cast(float, bw[6]) * age, g1 = __builtin_bit_cast(float, bw[7]) * age;
-        const float g2 = __builtin_bit_cast(float, bv[0]) * age;
-        const float grow = fmaxf(fmaxf(g0, g1), g2);
-        if (bstate == kBoxEmpty) {                      // nobody alive at t_ref, nobody is revived: nothing to sweep
-            have = true;
-        } else if (bstate == kBoxOk && grow <= kBoxMaxGrow) {
-            if (wv == 0) {
-                // (the 1e-3 m covers the rounding of the grown bounds; derive_pre's slack has a metre for the rest)
-                const Cull c0 = cull_box(s_pre, P.R, shortcuts,
-                                         __builtin_bit_cast(float, bw[0]) - g0 - 1e-3f, __builtin_bit_cast(float, bw[1]) - g1 - 1e-3f,
-                                         __builtin_bit_cast(float, bw[2]) - g2 - 1e-3f, __builtin_bit_cast(float, bw[3]) + g0 + 1e-3f,
-                                         __builtin_bit_cast(float, bw[4]) + g1 + 1e-3f, __builtin_bit_cast(float, bw[5]) + g2 + 1e-3f);
-                if (lane == 0) { s_cull.cand = c0.cand; s_cull.inside = c0.inside; s_cull.plane = c0.plane; }
-                if (lane < ZRK_MAX_RADARS) { s_cull.pz_lo[lane] = c0.pz_lo; s_cull.pz_hi[lane] = c0.pz_hi; }
-            }
-            __syncthreads();
-            c.cand = s_cull.cand; c.inside = s_cull.inside; c.plane = s_cull.plane;
-            c.pz_lo = s_cull.pz_lo[lane & (ZRK_MAX_RADARS - 1)]; c.pz_hi = s_cull.pz_hi[lane & (ZRK_MAX_RADARS - 1)];
-            have = true;
+        const CullOrNot r1 = cull_from_record(s_pre, s_cull, P.R, shortcuts, P.t, bw[0], bw[1], bw[2], bw[3], bw[4], bw[5], bw[6], bw[7],
+                                              bv[0], bstate, bv[2], bv[3]);
+        if (r1.have) { c = r1.c; have = true; }
+        if (PAIR) {
+            const CullOrNot r2 = cull_from_record(s_pre2, s_cull2, P.R, shortcuts, P.t2, bw[0], bw[1], bw[2], bw[3], bw[4], bw[5], bw[6],
+                                                  bw[7], bv[0], bstate, bv[2], bv[3]);
+            if (r2.have) { c2 = r2.c; have2 = true; }
         }
     }
-    double x = sx0, y = sy0, z = sz0;
+    double x = sx0, y = sy0, z = sz0, x2 = sx0, y2 = sy0, z2 = sz0;
     if (ADVANCE) {
         // Trajectory.get_pos: three separate roundings per axis
         const double d = P.t - t0;
         const double sx = vx * d, sy = vy * d, sz = vz * d;
         x = sx0 + sx; y = sy0 + sy; z = sz0 + sz;
+        if (PAIR) {
+            const double d2 = P.t2 - t0;
+            const double ux = vx * d2, uy = vy * d2, uz = vz * d2;
+            x2 = sx0 + ux; y2 = sy0 + uy; z2 = sz0 + uz;
+        }
     }
 #ifdef ZRK_PROBE_BUILD
     asm volatile("" ::"v"(x), "v"(y), "v"(z) : "memory");
 #endif
     ZRK_WAVE_PROBE(wave, 1, wall_clock64());
     if (!have) {
-        // no usable record: the box of the positions just computed (wave-uniform after the reductions)
-        const float inf = __builtin_inff(), kBig = 1e30f;
-        const float fx0 = (float)x, fy0 = (float)y, fz0 = (float)z;
-        const bool wild = live & !((fabsf(fx0) < kBig) & (fabsf(fy0) < kBig) & (fabsf(fz0) < kBig));
-        float blx = live ? fx0 : inf, bly = live ? fy0 : inf, blz = live ? fz0 : inf;
-        float bhx = live ? fx0 : -inf, bhy = live ? fy0 : -inf, bhz = live ? fz0 : -inf;
-        wave_bbox(blx, bly, bhx, bhy);
-        wave_minmax(blz, bhz);
-        const bool any_wild = __ballot(wild) != 0ull, any_live = __ballot(live) != 0ull;
-        const uint32_t all = (P.R >= 32) ? 0xFFFFFFFFu : ((1u << P.R) - 1u);
-        if (!any_live) { c.cand = 0u; c.inside = 0u; c.plane = 0u; }
-        else if (any_wild) { c.cand = all; c.inside = 0u; c.plane = 0u; }   // min / max drop NaNs: never cull such a wave
-        else c = cull_box(s_pre, P.R, shortcuts, blx, bly, blz, bhx, bhy, bhz);
+        // no usable record: the box of the positions just computed
+        const CullAndBox fresh = cull_from_rows(s_pre, P.R, shortcuts, live, x, y, z);
+        c = fresh.c;
+        const FreshBox fb = fresh.fb;
         if (cached) {
             // leave a record behind: every wave puts its box to LDS, the first wave joins them and lanes 0..11 store
             // one word each.  The speeds are taken over every row of the block, live or not (rows past the end read
             // row 0's: harmless, it only widens), once per record's life.
+            const float inf = __builtin_inff(), kBig = 1e30f;
             float m0 = __builtin_bit_cast(float, bw[6]), m1 = __builtin_bit_cast(float, bw[7]), m2 = __builtin_bit_cast(float, bv[0]);
             if (bstate == 0u) {
                 float n0 = fabsf((float)vx) * 1.000001f, n1 = fabsf((float)vy) * 1.000001f, n2 = fabsf((float)vz) * 1.000001f;
@@ -890,9 +1061,9 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
             }
             if (lane == 0) {
                 float *wb = s_wbox[wv];
-                wb[0] = blx; wb[1] = bly; wb[2] = blz; wb[3] = bhx; wb[4] = bhy; wb[5] = bhz;
+                wb[0] = fb.blx; wb[1] = fb.bly; wb[2] = fb.blz; wb[3] = fb.bhx; wb[4] = fb.bhy; wb[5] = fb.bhz;
                 wb[6] = m0; wb[7] = m1; wb[8] = m2;
-                wb[9] = any_wild ? 1.f : 0.f; wb[10] = any_live ? 1.f : 0.f;
+                wb[9] = fb.any_wild ? 1.f : 0.f; wb[10] = fb.any_live ? 1.f : 0.f;
             }
             __syncthreads();
             if (wv == 0 && lane < 12) {
@@ -916,10 +1087,21 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
             }
         }
     }
-    const int walked = __builtin_popcount(c.cand);     // wave-uniform: what this wave costs, for next tick's order
-    ZRK_WAVE_PROBE(wave, 7, (long long)(walked | (__builtin_popcount(c.inside) << 8) | (__builtin_popcount(c.plane) << 16) | ((int)have << 24)));
+    if (PAIR && !have2) {                                // (the record, if any, did not reach to t2 either: classify from the rows)
+        c2 = cull_from_rows(s_pre2, P.R, shortcuts, live, x2, y2, z2).c;
+    }
+    // wave-uniform: what this wave costs, for the next launch's order
+    const int walked = __builtin_popcount(c.cand) + (PAIR ? __builtin_popcount(c2.cand) : 0);
+    ZRK_WAVE_PROBE(wave, 7, (long long)(__builtin_popcount(c.cand) | (__builtin_popcount(c.inside) << 8) | (__builtin_popcount(c.plane) << 16) | ((int)have << 24)));
     uint32_t mask = 0u;
-    if (walked) sweep_rows<PHILOX>(P, rbp, seed, c, li, live, x, y, z, mask, wave);
+    // (PAIR: the second tick's positions wait in LDS while a wave walks the first tick's radars -- the walk calls out of line
+    // for guard-band pairs, and every value that lives across a call costs the kernel registers for all its waves)
+    __shared__ double s_hold[PAIR ? 3 : 1][PAIR ? ZRK_BLOCK : 1];
+    if (c.cand) {
+        if (PAIR) { s_hold[0][tid] = x2; s_hold[1][tid] = y2; s_hold[2][tid] = z2; }
+        sweep_rows<PHILOX>(P.tick, P.gid0, rbp, seed, c, li, live, x, y, z, mask, wave);
+        if (PAIR) { x2 = s_hold[0][tid]; y2 = s_hold[1][tid]; z2 = s_hold[2][tid]; }
+    }
     // (the number is asked for here and used at the very end: its round trip hides behind the rows' stores)
     int next_slot = -1;
     if (P.order_next && tid == 0) {
@@ -936,13 +1118,24 @@ __global__ __launch_bounds__(ZRK_BLOCK) void k_tick_sweep(const SweepParams P, c
     // sparse mode: the buffer is known to be all zero (the previous tick's compaction cleared it), so only
     // detections are written -- list-indexed stores are scattered when the table is spatially sorted
     if (i < P.n && (mask || !(P.flags & kSparseVis))) P.vis[(int64_t)scen * P.rows_ps + li] = mask;
+    if (PAIR) {
+        // the second tick: same rows, the next radar records, the next noise key.  (A row that tick t's missile phase removes
+        // is swept here all the same -- its thread cannot know; see SweepParams::t2 for who puts that right.)
+        uint32_t mask2 = 0u;
+        if (c2.cand) sweep_rows<PHILOX>(P.tick + 1, P.gid0, rbp2, seed, c2, li, live, x2, y2, z2, mask2, wave);
+        if (live) { P.pos_prev[i] = x2; P.pos_prev[cap + i] = y2; P.pos_prev[2 * cap + i] = z2; }
+        if (i < P.n && (mask2 || !(P.flags & kSparseVis2))) P.vis2[li] = mask2;
+    }
     if (MARKS && removed && al != 0 && i < P.n) {            // carry the removal out: once, by the row's own thread
         P.alive_w[i] = 0;
-        P.pos[i] = P.pos_prev[i]; P.pos[cap + i] = P.pos_prev[cap + i]; P.pos[2 * cap + i] = P.pos_prev[2 * cap + i];
+        const double *src = P.pos_abs[pk & 1u];
+        double *dst = P.pos_abs[(pk & 1u) ^ 1u];
+        dst[i] = src[i]; dst[cap + i] = src[cap + i]; dst[2 * cap + i] = src[2 * cap + i];
     }
     if (P.order_next && tid == 0 && (unsigned)next_slot < (unsigned)P.nb) P.order_next[next_slot] = blk;
     ZRK_WAVE_PROBE(wave, 3, wall_clock64());
 }
+
 
 // Compaction, phase 1: per-block detection counts per radar (row R: seen by any radar) from vis_mask,
 // in list order.  Lane r of each wave collects the wave's count for radar r, then one LDS add per lane.
@@ -1468,24 +1661,31 @@ __global__ void k_noise_apply(double *__restrict__ pos, int64_t cap, const int32
 }
 
 // Missile.step 'active' branch for one row (modules/Missile.py:162-193).  Returns 0 none, 1 hit, 2 timeout.
-__device__ uint8_t missile_step_row(const double *__restrict__ sp, const double *__restrict__ vel,
+// With removal marks (`pend`, the overlapped loop; SweepParams::pend) a row's state is read through them: a mark other than
+// this tick's -- and, in the second tick of a PAIR launch (mark_first != 0), the first tick's mark as well -- means "removed
+// before this tick" whatever the flag says, because the flag is lowered by the row's own thread somewhere in this very grid.
+// The position a removed target froze at: pos_abs[its mark & 1] when an earlier launch removed it.  In a pair's second tick
+// the positions "after the tick before" are the first tick's, which this grid is still computing: a target that the first
+// tick removed, or that stands behind its missile in the list, has its first-tick radar phase replayed here
+// (replay_row_radar_phase) instead of being read.
+__device__ __forceinline__ uint8_t missile_step_row(const double *__restrict__ sp, const double *__restrict__ vel,
                                     const double *__restrict__ t0, const uint8_t *alive,
                                     const int32_t *__restrict__ lidx, const double *pos_prev, int64_t cap,
                                     const int32_t *__restrict__ m_slot, const int32_t *__restrict__ m_tgt,
                                     const double *__restrict__ m_radius, double *__restrict__ m_period,
                                     uint8_t *__restrict__ m_status, int64_t row, double t, double dts,
-                                    uint8_t *pend, uint32_t mark, const double *grec)
+                                    uint8_t *pend, uint32_t mark, const double *grec, const double *pos_abs0, const double *pos_abs1,
+                                    uint32_t mark_first, const char *rb_first, int R, bool philox, uint64_t seed, uint64_t tick_first,
+                                    int64_t gid0, double t_first)
 {
     uint8_t code = 0;
     const int32_t s = m_slot[row];
-    // (overlapped loop: a missile that is itself somebody's target and was hit LAST tick is removed from this tick on
-    // -- AirEnv.py:33-40 -- but only its own row thread, somewhere in this very grid, lowers the flag: the mark says it)
+    const bool second = mark_first != 0u;
+    // (a missile that is itself somebody's target and was hit LAST tick is removed from this tick on -- AirEnv.py:33-40 --
+    // but only its own row thread, somewhere in this very grid, lowers the flag: the mark says it)
     bool flying = m_status[row] == 1 && alive[s] != 0;
     if (pend && flying) { const uint32_t ps = pend[s]; flying = !(ps != 0u && ps != mark); }
     if (flying) {
-        const double d = t - t0[s];
-        const double px = sp[s] + vel[s] * d, py = sp[cap + s] + vel[cap + s] * d,
-                     pz = sp[2 * cap + s] + vel[2 * cap + s] * d;
         const int32_t j = m_tgt[row];
         double tx, ty, tz;
         // the target's trajectory and list index: one 64-byte record, or seven columns and the index column
@@ -1496,21 +1696,36 @@ __device__ uint8_t missile_step_row(const double *__restrict__ sp, const double 
 #pragma unroll
             for (int q = 0; q < 8; ++q) g[q] = r[q];
             lj = (int32_t)(uint32_t)__builtin_bit_cast(uint64_t, g[7]);
-        } else if (lidx) lj = lidx[j];
+        } else {
+            if (lidx) lj = lidx[j];
+            g[0] = sp[j]; g[1] = sp[cap + j]; g[2] = sp[2 * cap + j];
+            g[3] = vel[j]; g[4] = vel[cap + j]; g[5] = vel[2 * cap + j];
+            g[6] = t0[j];
+        }
         const bool earlier = lidx ? (lj < lidx[s]) : (j < s);
-        bool there = alive[j] != 0;
-        if (pend) { const uint32_t pj = pend[j]; there = there && !(pj != 0u && pj != mark); }   // (removed last tick: not yet carried out, perhaps)
+        const bool alive_j = alive[j] != 0;
+        const uint32_t pj = pend ? (uint32_t)pend[j] : 0u;
+        const bool old_mark = pj != 0u && pj != mark && pj != mark_first;     // removed by an earlier launch
+        const bool there = alive_j && !old_mark && !(second && pj == mark_first);
         if (there && earlier) {           // already stepped this tick (list order): fresh, noise-free
-            if (grec) {
-                const double dj = t - g[6];
-                tx = g[0] + g[3] * dj; ty = g[1] + g[4] * dj; tz = g[2] + g[5] * dj;
-            } else {
-                const double dj = t - t0[j];
-                tx = sp[j] + vel[j] * dj; ty = sp[cap + j] + vel[cap + j] * dj; tz = sp[2 * cap + j] + vel[2 * cap + j] * dj;
-            }
+            const double dj = t - g[6];
+            tx = g[0] + g[3] * dj; ty = g[1] + g[4] * dj; tz = g[2] + g[5] * dj;
+        } else if (old_mark) {            // removed, perhaps not carried out yet: where it froze
+            const double *fz = (pj & 1u) ? pos_abs1 : pos_abs0;
+            tx = fz[j]; ty = fz[cap + j]; tz = fz[2 * cap + j];
+        } else if (second && alive_j) {   // what it held after the pair's first tick, which nobody may have written yet
+            const double dj = t_first - g[6];
+            tx = g[0] + g[3] * dj; ty = g[1] + g[4] * dj; tz = g[2] + g[5] * dj;
+            const Vec3d after = replay_row_radar_phase(rb_first, R, philox, seed, tick_first, (uint64_t)(gid0 + (int64_t)(lidx ? lj : j)), tx, ty, tz);
+            tx = after.x; ty = after.y; tz = after.z;
         } else {                          // not stepped yet, or removed: what it held after last tick
             tx = pos_prev[j]; ty = pos_prev[cap + j]; tz = pos_prev[2 * cap + j];
         }
+        // (the missile's own position after the target's: the replay above calls out of line, and what lives across a call
+        // costs the whole kernel registers)
+        const double d = t - t0[s];
+        const double px = sp[s] + vel[s] * d, py = sp[cap + s] + vel[cap + s] * d,
+                     pz = sp[2 * cap + s] + vel[2 * cap + s] * d;
         const double dx = tx - px, dy = ty - py, dz = tz - pz;
         const double dist = sqrt(dot3(dx, dy, dz, dx, dy, dz));
         if (dist <= m_radius[row]) {
@@ -1562,7 +1777,7 @@ __device__ __forceinline__ void missile_finish_block(int *s_wave, const uint8_t 
                                                      int32_t *__restrict__ ev_count, int apply, uint8_t *alive,
                                                      const double *pos_cur, double *pos_prev, int64_t cap,
                                                      int64_t *ev_wire = nullptr, int ev_wire_cap = 0, int64_t gid0 = 0,
-                                                     const int32_t *__restrict__ lidx = nullptr)
+                                                     const int32_t *__restrict__ lidx = nullptr, uint32_t *clear_vis = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (int)((m + 1023) / 1024);                 // consecutive rows per thread (<= kMissileItems)
@@ -1600,6 +1815,10 @@ __device__ __forceinline__ void missile_finish_block(int *s_wave, const uint8_t 
                 ev_wire[1 + base] = (int64_t)(((uint64_t)(gid0 + (lidx ? lidx[ms] : ms)) << 32) |
                                               (ts >= 0 ? (uint64_t)(uint32_t)(gid0 + (lidx ? lidx[ts] : ts)) : 0xFFFFFFFFull));
             ++base;
+            if (clear_vis) {                                  // (a pair's first tick: these rows were swept once more -- not seen)
+                clear_vis[lidx ? lidx[ms] : ms] = 0u;
+                if (ts >= 0) clear_vis[lidx ? lidx[ts] : ts] = 0u;
+            }
             if (apply) {                                      // AirEnv.py:33-40, effective from the next tick
                 kill_one(alive, pos_cur, pos_prev, cap, ms);
                 if (ts >= 0) kill_one(alive, pos_cur, pos_prev, cap, ts);
@@ -1637,7 +1856,7 @@ __device__ void missile_kills(const MissileArgs &M, int part)
 __device__ void missile_finish_entry(int *s_wave, const MissileArgs &M)
 {
     missile_finish_block(s_wave, M.ev_code, M.m_slot, M.m_tgt, M.m, M.ev_missile, M.ev_target, M.ev_count, M.apply, M.alive,
-                         M.pos_cur, M.pos_prev, M.cap, M.ev_wire, M.ev_wire_cap, M.gid0, M.lidx);
+                         M.pos_cur, M.pos_prev, M.cap, M.ev_wire, M.ev_wire_cap, M.gid0, M.lidx, M.clear_vis);
 }
 
 // Ordered event list from ev_code: one workgroup walks the (short) missile table in row order.
@@ -1703,11 +1922,12 @@ __global__ void k_build_gather_records(const double *__restrict__ sp, const doub
 
 // Overlapped loop, behind the last tick of a call: the removals that tick decided (marks nobody has carried out yet)
 // as the tombstones the caller expects (kill_one), and every mark of the call cleared.
-__global__ void k_apply_marks(uint8_t *__restrict__ pend, uint8_t *alive, const double *pos_cur, double *pos_prev, int64_t cap, int64_t n)
+__global__ void k_apply_marks(uint8_t *__restrict__ pend, uint8_t *alive, double *pos0, double *pos1, int64_t cap, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || pend[i] == 0) return;
-    if (alive[i]) kill_one(alive, pos_cur, pos_prev, cap, (int32_t)i);
+    // (the mark's low bit: the buffer that was current in the removal tick, i.e. the one that holds the frozen position)
+    if (alive[i]) { if (pend[i] & 1u) kill_one(alive, pos1, pos0, cap, (int32_t)i); else kill_one(alive, pos0, pos1, cap, (int32_t)i); }
     pend[i] = 0;
 }
 
@@ -2142,7 +2362,7 @@ struct Side {
     // mask buffers of its own for all ticks of a call but the last (whose masks the caller may read): each is all zero
     // except between the sweep that writes it and the compaction that reads and clears it; slot kMasks stands for the
     // caller's buffer of the last tick
-    static constexpr int kMasks = 5;
+    static constexpr int kMasks = 8;
     uint32_t *masks[kMasks] = {nullptr, nullptr, nullptr};
     int64_t mask_rows = 0;
     // ... and, with the same lifetimes, the per-row event codes of the missile phase (written by a tick's sweep, read by
@@ -2155,6 +2375,8 @@ struct Side {
     uint64_t mask_pos = 0;
     hipEvent_t done[kMasks + 1] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t last_sweep = nullptr;   // recorded behind the last sweep of a call (SideItem::wait_event)
+    uint32_t *bar = nullptr;           // DEVICE: the barrier of a pair launch's missile workgroups (arrivals, gave-up word)
+    uint32_t bar_epoch = 0;            // arrivals asked for so far
     int cu_count = 0;                  // ZRK_SIDE_CUS: the side stream is confined to this many compute units (0: all)
     bool posted[kMasks + 1] = {false, false, false, false};
     uint64_t item_no[kMasks + 1] = {0, 0, 0, 0};
@@ -2217,10 +2439,13 @@ struct zrk_ctx {
     int64_t grec_rows = 0, grec_n = 0;
     const void *grec_key = nullptr;
     bool grec_enabled = true;          // ZRK_GATHER_RECORDS=0: the columns
-    struct RadarBlock *rb_cache = nullptr;   // the next tick's radar records, derived ahead (fill_radar_block)
-    zrk_radar rb_cache_radars[ZRK_MAX_RADARS];
-    int rb_cache_R = -1;
-    uint32_t rb_cache_flags = 0;
+    struct RadarBlock *rb_cache = nullptr;   // the next launch's radar records (two ticks' worth), derived ahead (fill_radar_block)
+    zrk_radar rb_cache_radars[2][ZRK_MAX_RADARS];
+    int rb_cache_R[2] = {-1, -1};
+    uint32_t rb_cache_flags[2] = {0, 0};
+    bool pair_enabled = true;          // ZRK_PAIR=0: one tick per launch in the overlapped loop
+    int last_ticks_per_launch = 1;     // of the last zrk_run_ticks* call
+    std::vector<int> tev_alias, tev_ticks;   // per timing sample: which event pair holds it, and the ticks its launch swept
     bool tail_by_event = true;         // ZRK_TAIL_EVENT=0: the last compaction of a call is released by a launch that raises the host word
 };
 
@@ -2307,6 +2532,7 @@ ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
     { const char *v = std::getenv("ZRK_OVERLAP_MIN_ROWS"); c->overlap_min_rows = v ? std::atoll(v) : 400000; }
     { const char *v = std::getenv("ZRK_GATHER_RECORDS"); c->grec_enabled = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_TAIL_EVENT"); c->tail_by_event = !(v && v[0] == '0'); }
+    { const char *v = std::getenv("ZRK_PAIR"); c->pair_enabled = !(v && v[0] == '0'); }
     if (const char *v = std::getenv("ZRK_COMPACT_ITEMS")) c->env_items = std::max(1, std::atoi(v));
     if (const char *v = std::getenv("ZRK_COMPACT_ORDER")) c->env_order = std::strcmp(v, "block") != 0;
     c->fused_max_blocks = kFusedMaxBlocks;
@@ -2376,6 +2602,8 @@ MissileArgs missile_args(const zrk_entities *e, int cur, const zrk_missiles *mis
     M.t = (double)time_ms / 1000.0; M.dts = (double)dt_ms / 1000.0;
     M.apply = apply; M.ev_wire_cap = 0; M.ev_wire = nullptr; M.gid0 = 0;
     M.pend = nullptr; M.mark = 0; M._pad3 = 0; M.grec = nullptr;
+    M.pos_abs[0] = e->pos[0]; M.pos_abs[1] = e->pos[1];
+    M.ev_code2 = nullptr; M.mark2 = 0; M.bar_target = 0; M.bar = nullptr; M.t2 = M.t; M.clear_vis = nullptr;
     return M;
 }
 
@@ -2385,10 +2613,12 @@ MissileArgs missile_args(const zrk_entities *e, int cur, const zrk_missiles *mis
 void fill_radar_block(zrk_ctx *ctx, const zrk_radar *radars, int R, uint32_t flags, RadarBlock &rb)
 {
     const uint32_t key_flags = flags & (ZRK_F_EXACT_ONLY | ZRK_F_PHILOX);
-    if (ctx->rb_cache && ctx->rb_cache_R == R && ctx->rb_cache_flags == key_flags && R > 0 &&
-        std::memcmp(ctx->rb_cache_radars, radars, sizeof(zrk_radar) * (size_t)R) == 0) {
-        std::memcpy(&rb, ctx->rb_cache, sizeof(rb));
-        return;
+    for (int k = 0; k < 2 && ctx->rb_cache && R > 0; ++k) {
+        if (ctx->rb_cache_R[k] == R && ctx->rb_cache_flags[k] == key_flags &&
+            std::memcmp(ctx->rb_cache_radars[k], radars, sizeof(zrk_radar) * (size_t)R) == 0) {
+            std::memcpy(&rb, ctx->rb_cache + k, sizeof(rb));
+            return;
+        }
     }
     std::memset(&rb, 0, sizeof(rb));
     for (int r = 0; r < ZRK_MAX_RADARS; ++r) {
@@ -2405,16 +2635,16 @@ void fill_radar_block(zrk_ctx *ctx, const zrk_radar *radars, int R, uint32_t fla
     }
 }
 
-void radar_block_ahead(zrk_ctx *ctx, const zrk_radar *radars, int R, uint32_t flags)
+void radar_block_ahead(zrk_ctx *ctx, const zrk_radar *radars, int R, uint32_t flags, int k = 0)
 {
     if (R <= 0 || !radars) return;
-    if (!ctx->rb_cache) ctx->rb_cache = (RadarBlock *)std::malloc(sizeof(RadarBlock));
+    if (!ctx->rb_cache) ctx->rb_cache = (RadarBlock *)std::malloc(2 * sizeof(RadarBlock));
     if (!ctx->rb_cache) return;
-    ctx->rb_cache_R = -1;                                 // (derive afresh)
-    RadarBlock *dst = ctx->rb_cache;
+    ctx->rb_cache_R[k] = -1;                              // (derive afresh: the two slots hold consecutive ticks, never the same)
+    RadarBlock *dst = ctx->rb_cache + k;
     fill_radar_block(ctx, radars, R, flags, *dst);
-    std::memcpy(ctx->rb_cache_radars, radars, sizeof(zrk_radar) * (size_t)R);
-    ctx->rb_cache_R = R; ctx->rb_cache_flags = flags & (ZRK_F_EXACT_ONLY | ZRK_F_PHILOX);
+    std::memcpy(ctx->rb_cache_radars[k], radars, sizeof(zrk_radar) * (size_t)R);
+    ctx->rb_cache_R[k] = R; ctx->rb_cache_flags[k] = flags & (ZRK_F_EXACT_ONLY | ZRK_F_PHILOX);
 }
 
 // What a batched ensemble adds to the two launches of a tick.
@@ -2426,19 +2656,32 @@ struct EnsLaunch {
     EnsembleArgs next;             // what the compaction's extra workgroups derive for the next tick
 };
 
+// A PAIR launch (SweepParams::t2): what the second tick adds.
+struct PairLaunch {
+    int64_t time2_ms;
+    const zrk_radar *radars2;      // the radars as they stand in the second tick
+    uint32_t *vis2;
+    uint32_t mark2;
+};
+
 int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_t time_ms, const zrk_radar *radars,
                  int R, uint32_t flags, uint64_t seed, uint64_t tick, int64_t gid0, void *workspace, void *stream,
                  const MissileArgs &M, uint32_t *vis = nullptr, int32_t *order_next = nullptr, const int32_t *order = nullptr,
                  WaveBox *boxes = nullptr, const EnsLaunch *ens = nullptr, const RadarBlock *rb_device = nullptr,
                  uint32_t *flag = nullptr, uint32_t flag_value = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
-                 uint32_t *order_ctr = nullptr, uint32_t *order_ctr_next = nullptr, uint8_t *pend = nullptr, uint32_t mark = 0)
+                 uint32_t *order_ctr = nullptr, uint32_t *order_ctr_next = nullptr, uint8_t *pend = nullptr, uint32_t mark = 0,
+                 const PairLaunch *pair = nullptr)
 {
     if (!ctx || !e || !workspace || (R > 0 && !radars && !ens && !rb_device)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
     if (R < 0 || R > ZRK_MAX_RADARS)
         return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: radar count out of range");
     if (n < 0 || n > e->capacity || (cur != 0 && cur != 1)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: n/cur out of range");
     if (n == 0 && M.m == 0) return 0;
-    SweepParams P;
+    static SweepParamsPair PP;                              // (20 KB: not on the stack; one host thread per context -- and the
+                                                            // launch copies it before it returns)
+    static std::mutex pp_mu;
+    std::lock_guard<std::mutex> pp_lock(pp_mu);             // (contexts on different threads share the buffer)
+    SweepParams &P = PP;
     P.sp = e->start_pos; P.vel = e->velocity; P.t0 = e->start_time; P.alive = e->alive; P.lidx = e->list_index;
     P.pos = e->pos[cur]; P.vis = vis ? vis : e->vis_mask;
     P.order = order; P.order_next = order_next; P.order_ctr = order_ctr; P.order_ctr_next = order_ctr_next;
@@ -2448,7 +2691,9 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
     P.R = R; P.nb = nblocks(n, ZRK_BLOCK); P.flags = flags;
     P.mb = nblocks(M.m, ZRK_BLOCK); P.flag = flag; P.flag_value = flag_value;
     P.boxes = boxes;
-    P.pend = pend; P.mark = mark; P._pad3 = 0; P.alive_w = e->alive; P.pos_prev = e->pos[cur ^ 1];
+    P.pend = pend; P.mark = mark; P.mark2 = pair ? pair->mark2 : mark; P.alive_w = e->alive; P.pos_prev = e->pos[cur ^ 1];
+    P.pos_abs[0] = e->pos[0]; P.pos_abs[1] = e->pos[1];
+    P.t2 = pair ? (double)pair->time2_ms / 1000.0 : P.t; P.vis2 = pair ? pair->vis2 : nullptr;
     P.rb_table = ens ? ens->rb_table : nullptr; P.seeds = ens ? ens->seeds : nullptr;
     P.rows_ps = ens ? ens->rows_ps : 0; P.bps = ens ? ens->bps : 0;
     P.bps_magic = ens ? (uint32_t)((0x100000000ull + (uint64_t)ens->bps - 1) / (uint64_t)ens->bps) : 0u;
@@ -2461,6 +2706,18 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
     if (ens || rb_device) std::memset(&P.rb, 0, sizeof(P.rb));
     else fill_radar_block(ctx, radars, R, flags, P.rb);
     const dim3 grid(P.nb + P.mb);                           // leading workgroups step the missiles
+    if (pair) {
+        if (!pend || !(flags & ZRK_F_ADVANCE) || ens || rb_device || !pair->radars2 || !pair->vis2)
+            return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: a pair launch advances, carries marks and has its records in its arguments");
+        fill_radar_block(ctx, pair->radars2, R, flags, PP.rb2);   // (derived ahead by the loop: radar_block_ahead)
+        using PairKernel = void (*)(const SweepParamsPair, const MissileArgs);
+        static const PairKernel pairs[4] = {k_tick_sweep<false, true, false, true, true>, k_tick_sweep<true, true, false, true, true>,
+                                            k_tick_sweep<false, true, true, true, true>,  k_tick_sweep<true, true, true, true, true>};
+        const int w = ((flags & ZRK_F_PHILOX) ? 1 : 0) + (P.lidx ? 2 : 0);
+        if (ev_start && ev_stop) hipExtLaunchKernelGGL(pairs[w], grid, dim3(ZRK_BLOCK), 0, (hipStream_t)stream, ev_start, ev_stop, 0, PP, M);
+        else hipLaunchKernelGGL(pairs[w], grid, dim3(ZRK_BLOCK), 0, (hipStream_t)stream, PP, M);
+        return check_launch(ctx, "k_tick_sweep (pair)");
+    }
     using Kernel = void (*)(const SweepParams, const MissileArgs);
     static const Kernel variants[12] = {
         k_tick_sweep<false, false, false>, k_tick_sweep<true, false, false>, k_tick_sweep<false, true, false>,
@@ -2623,6 +2880,13 @@ ZRK_API int zrk_compact_status(zrk_ctx *ctx, void *workspace, void *stream)
         return fail(ctx, ZRK_E_HIP, "zrk_compact_status: copy failed");
     if (ctx->side && ctx->side->rc.load() != 0)    // overlap mode: the side stream's thread gave up (its lists are not valid)
         return fail(ctx, ZRK_E_STATE, ctx->side->err);
+    if (ctx->side && ctx->side->bar) {
+        uint32_t bar[2] = {0, 0};
+        if (hipMemcpy(bar, ctx->side->bar, sizeof(bar), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(ctx, ZRK_E_HIP, "zrk_compact_status: the missile barrier's words could not be read");
+        if (bar[1] != 0)
+            return fail(ctx, ZRK_E_STATE, "a pair launch's missile workgroups did not all reach their barrier: the second tick's events are not valid");
+    }
     uint32_t dev_fault = 0;
     if (hipMemcpyFromSymbol(&dev_fault, HIP_SYMBOL(g_device_fault), sizeof(dev_fault)) != hipSuccess)
         return fail(ctx, ZRK_E_HIP, "zrk_compact_status: the device fault word could not be read");
@@ -3253,6 +3517,7 @@ Side *side_of(zrk_ctx *ctx)
     }
     bool ok = (made || hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking) == hipSuccess) &&
               hipEventCreateWithFlags(&sd->last_sweep, hipEventDisableTiming) == hipSuccess &&
+              hipMalloc((void **)&sd->bar, 64) == hipSuccess && hipMemset(sd->bar, 0, 64) == hipSuccess &&
               hipHostMalloc((void **)&sd->hflag, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
               hipHostGetDevicePointer((void **)&sd->hflag_dev, (void *)sd->hflag, 0) == hipSuccess;
     if (ok) *sd->hflag = 0u;
@@ -3261,6 +3526,7 @@ Side *side_of(zrk_ctx *ctx)
         (void)hipGetLastError();
         for (int k = 0; k <= Side::kMasks; ++k) if (sd->done[k]) (void)hipEventDestroy(sd->done[k]);
         if (sd->last_sweep) (void)hipEventDestroy(sd->last_sweep);
+        if (sd->bar) (void)hipFree(sd->bar);
         if (sd->hflag) (void)hipHostFree((void *)sd->hflag);
         if (sd->stream) (void)hipStreamDestroy(sd->stream);
         delete sd;
@@ -3330,6 +3596,7 @@ void side_destroy(Side *sd)
     for (int k = 0; k < Side::kMasks; ++k) if (sd->masks[k]) (void)hipFree(sd->masks[k]);
     for (int k = 0; k < Side::kMasks; ++k) if (sd->codes[k]) (void)hipFree(sd->codes[k]);
     if (sd->pend) (void)hipFree(sd->pend);
+    if (sd->bar) (void)hipFree(sd->bar);
     if (sd->hflag) (void)hipHostFree((void *)sd->hflag);
     delete sd;
 }
@@ -3342,6 +3609,8 @@ bool ensure_events(zrk_ctx *ctx, int pairs)
         if (hipEventCreate(&e) != hipSuccess) return false;
         ctx->tev.push_back(e);
     }
+    if ((int)ctx->tev_alias.size() < pairs) { ctx->tev_alias.resize(pairs); ctx->tev_ticks.resize(pairs); }
+    for (int k = 0; k < pairs; ++k) { ctx->tev_alias[k] = k; ctx->tev_ticks[k] = 1; }
     return true;
 }
 
@@ -3559,7 +3828,127 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     };
     int rc = 0;
     bool marks_used = false;                             // some sweep of this call ran with removal marks
-    for (int k = 0; k < K && rc == 0; ++k) {
+    // ---- the overlapped loop with TWO TICKS PER LAUNCH (SweepParams::t2) ---------------------------------------------------
+    // One scenario, no exchange: launch L sweeps ticks t and t + 1 in one pass over the table, the side stream compacts both
+    // ticks' lists (two launches, in order) beside launch L + 1.  An odd tick at the end of a call is a launch of one.
+    const bool pairing = sd && !ens && !xio && ctx->pair_enabled && K >= 2 && (m == 0 || m <= 1024 * (int64_t)kMissileItems);
+    ctx->last_ticks_per_launch = pairing ? 2 : 1;
+    for (int k = 0; pairing && k < K && rc == 0;) {
+        const int nt = (k + 1 < K) ? 2 : 1;
+        const int32_t cur_before = st->cur, vis_cur_before = st->vis_cur;
+        const int cur_a = st->cur ^ 1, cur_b = st->cur;                     // tick t's buffer, tick t + 1's
+        // timing: the launch that holds the last tick of a window of `stride` ticks (or the call's last tick)
+        int prof_idx = -1;
+        for (int j = k; j < k + nt; ++j)
+            if (n_prof && ((j + 1) % stride == 0 || j + 1 == K)) {
+                if (prof_idx >= 0) ctx->tev_alias[prof_idx] = j / stride;       // (both ticks are samples: one measurement)
+                prof_idx = j / stride;
+                ctx->tev_alias[prof_idx] = prof_idx; ctx->tev_ticks[prof_idx] = nt;
+            }
+        const bool fused = m > 0;
+        MissileArgs M = fused ? missile_args(e, cur_a, mis, m, st->time_ms, st->dt_ms, 0) : no_missiles();
+        M.pos_abs[0] = e->pos[0]; M.pos_abs[1] = e->pos[1];
+        if (fused) M.grec = grec;
+        // masks: every tick but the call's last writes into one of the loop's own buffers, the last one where the caller reads
+        uint32_t *vis_t[2] = {nullptr, nullptr};
+        int slot_t[2] = {Side::kMasks, Side::kMasks};
+        uint32_t sparse_t[2] = {kSparseVis, kSparseVis2};
+        const bool two_vis = e->vis_mask_alt != nullptr;
+        if (ctx->ring_key != (const void *)e->vis_mask) { ctx->ring_key = e->vis_mask; ctx->ring_clean[0] = ctx->ring_clean[1] = false; }
+        for (int j = 0; j < nt && rc == 0; ++j) {
+            if (two_vis) st->vis_cur ^= 1; else st->vis_cur = 0;
+            if (k + j + 1 < K) {
+                slot_t[j] = (int)(sd->mask_pos++ % Side::kMasks);
+                vis_t[j] = sd->masks[slot_t[j]];
+            } else {
+                vis_t[j] = st->vis_cur ? e->vis_mask_alt : e->vis_mask;
+                if (!(two_vis && ctx->ring_clean[st->vis_cur])) sparse_t[j] = 0u;
+            }
+            rc = side_wait(ctx, sd, slot_t[j], s);
+        }
+        if (rc != 0) { st->vis_cur = vis_cur_before; break; }
+        if (fused) {
+            if (slot_t[0] < Side::kMasks) M.ev_code = sd->codes[slot_t[0]];
+            M.ev_code2 = (nt == 2) ? ((slot_t[1] < Side::kMasks) ? sd->codes[slot_t[1]] : mis->ev_code) : nullptr;
+        }
+        const uint32_t mark_a = 2u + 2u * (uint32_t)(st->tick % 126u) + (uint32_t)cur_a;
+        const uint32_t mark_b = (nt == 2) ? 2u + 2u * (uint32_t)((st->tick + 1) % 126u) + (uint32_t)cur_b : mark_a;
+        M.pend = sd->pend; M.mark = mark_a; M.mark2 = mark_b; M.apply = 0;
+        M.t2 = (double)(st->time_ms + st->dt_ms) / 1000.0;
+        const int mb = nblocks(M.m, ZRK_BLOCK);
+        if (nt == 2 && mb > 0) { sd->bar_epoch += (uint32_t)mb; M.bar = sd->bar; M.bar_target = sd->bar_epoch; }
+        const int nbs = nblocks(st->n, ZRK_BLOCK);
+        const bool ordering = ctx->order_enabled && R > 0 && nbs > 8 * ctx->cus;
+        Workspace w = carve(workspace, 0, e->capacity);
+        if (ctx->box_ws != workspace || ctx->box_key != (const void *)e->start_pos || st->n < ctx->box_n) {
+            ctx->box_ws = workspace; ctx->box_key = e->start_pos; ctx->box_n = 0;
+        }
+        if (st->n != ctx->box_n) {
+            const int64_t w0 = ctx->box_n / ZRK_BLOCK, w1 = (st->n + ZRK_BLOCK - 1) / ZRK_BLOCK;
+            if (hipMemsetAsync(w.boxes + w0, 0, sizeof(WaveBox) * (size_t)(w1 - w0), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset boxes"); break; }
+            ctx->box_n = st->n;
+        }
+        if (ordering && (ctx->order_ws != workspace || ctx->order_nb != nbs || !ctx->order_ready)) {
+            if (hipMemsetAsync(w.order_ctr, 0, 2 * kOrderCtrSet * sizeof(uint32_t), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset order counters"); break; }
+            ctx->order_ws = workspace; ctx->order_nb = nbs; ctx->order_ready = false; ctx->order_phase = 0;
+        }
+        if (!ordering) ctx->order_ready = false;
+        const int oph = ctx->order_phase;
+        // the radars as they stand in the second tick
+        zrk_radar radars_b[ZRK_MAX_RADARS];
+        std::memcpy(radars_b, radars, sizeof(zrk_radar) * (size_t)R);
+        zrk_scan_advance(radars_b, scan, R);
+        PairLaunch pl{st->time_ms + st->dt_ms, radars_b, vis_t[1], mark_b};
+        const bool on_dispatch = prof_idx >= 0;
+        const int rc_sweep =
+            launch_sweep(ctx, e, st->n, cur_a, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse_t[0] | (nt == 2 ? sparse_t[1] : 0u),
+                         st->seed, st->tick, st->gid0, workspace, stream, M, vis_t[0], ordering ? w.order[oph ^ 1] : nullptr,
+                         (ordering && ctx->order_ready) ? w.order[oph] : nullptr, w.boxes, nullptr, nullptr,
+                         k > 0 ? sd->hflag_dev : nullptr, sd->seq,
+                         on_dispatch ? ev[2 * prof_idx] : nullptr, on_dispatch ? ev[2 * prof_idx + 1] : nullptr,
+                         w.order_ctr + kOrderCtrSet * (oph ^ 1), w.order_ctr + kOrderCtrSet * oph, sd->pend, mark_a, nt == 2 ? &pl : nullptr);
+        rc = rc_sweep;
+        g_trace.mark(nt == 2 ? "run_ticks: pair launched" : "run_ticks: sweep launched");
+        if (rc_sweep != 0) { st->vis_cur = vis_cur_before; break; }
+        marks_used = true;
+        if (ordering) { ctx->order_ready = true; ctx->order_phase = oph ^ 1; }
+        // the radars move on by the ticks swept, and the next launch's records are derived while this one runs
+        std::memcpy(radars, radars_b, sizeof(zrk_radar) * (size_t)R);
+        if (nt == 2) zrk_scan_advance(radars, scan, R);
+        if (k + nt < K) {
+            radar_block_ahead(ctx, radars, R, st->flags, 0);
+            if (k + nt + 1 < K) {
+                std::memcpy(radars_b, radars, sizeof(zrk_radar) * (size_t)R);
+                zrk_scan_advance(radars_b, scan, R);
+                radar_block_ahead(ctx, radars_b, R, st->flags, 1);
+            }
+        }
+        const bool last_launch = k + nt == K;
+        if (last_launch && ctx->tail_by_event && hipEventRecord(sd->last_sweep, s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipEventRecord");
+        // the side stream's work: one compaction per tick, in tick order, released when the NEXT launch starts
+        for (int j = 0; j < nt && rc == 0; ++j) {
+            SideItem it;
+            std::memset((void *)&it, 0, sizeof(it));
+            rc = launch_compact(ctx, vis_t[j], st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, packed, packed_capacity,
+                                st->gid0, stream, no_missiles(), (slot_t[j] < Side::kMasks) ? vis_t[j] : nullptr,
+                                (st->flags & ZRK_F_UNION_BITS) != 0, nullptr, nullptr, &it);
+            if (rc != 0) break;
+            it.stream = side_stream; it.flag_value = ++sd->seq; it.done_slot = slot_t[j];
+            it.M = M; it.M.apply = 0;
+            if (fused && j == 1) it.M.ev_code = M.ev_code2;
+            it.M.clear_vis = (fused && nt == 2 && j == 0) ? vis_t[1] : nullptr;
+            if (last_launch && ctx->tail_by_event) it.wait_event = sd->last_sweep;
+            rc = side_enqueue(ctx, sd, it);
+            side_last = slot_t[j];
+            if (slot_t[j] == Side::kMasks) ctx->ring_clean[st->vis_cur] = false;
+        }
+        st->cur = (nt == 2) ? cur_b : cur_a;
+        st->time_ms += nt * st->dt_ms;
+        st->tick += (uint64_t)nt;
+        k += nt;
+        (void)cur_before;
+    }
+    for (int k = pairing ? K : 0; k < K && rc == 0; ++k) {
         // (a tick that fails before its sweep is launched leaves the loop state as the last complete tick left it)
         const int32_t cur_before = st->cur, vis_cur_before = st->vis_cur;
         st->cur ^= 1;
@@ -3603,8 +3992,9 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (sd && side_slot < Side::kMasks && M.m > 0) M.ev_code = sd->codes[side_slot];
         // removals as marks (one scenario): carried out by the next sweep's own threads, or behind the call's last tick
         const bool marks = sd && !ens && M.m > 0;
-        const uint32_t mark = marks ? 1u + (uint32_t)(st->tick % 255u) : 0u;
-        if (marks) { M.pend = sd->pend; M.mark = mark; M.apply = 0; }
+        // (the mark's low bit: which position buffer is current in this tick, i.e. holds what a removed row froze at)
+        const uint32_t mark = marks ? 2u + 2u * (uint32_t)(st->tick % 126u) + (uint32_t)st->cur : 0u;
+        if (marks) { M.pend = sd->pend; M.mark = mark; M.mark2 = mark; M.apply = 0; }
         // next tick's dispatch order: this tick's sweep builds it as it goes
         const int nbs = nblocks(st->n, ZRK_BLOCK);
         // (a grid that is resident all at once has no "last": eight workgroups of four waves fit a compute unit)
@@ -3746,8 +4136,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             // the last tick's removals are still marks: tombstones now, and the call's marks cleared -- also when the call
             // has failed (a helper that gave up, a wait that ran out): the table then stands as after the st->tick ticks
             // that were swept, only the lists of this call are not valid
-            hipLaunchKernelGGL(k_apply_marks, dim3(nblocks(st->n, 256)), dim3(256), 0, s, sd->pend, e->alive, e->pos[st->cur],
-                               e->pos[st->cur ^ 1], e->capacity, st->n);
+            hipLaunchKernelGGL(k_apply_marks, dim3(nblocks(st->n, 256)), dim3(256), 0, s, sd->pend, e->alive, e->pos[0],
+                               e->pos[1], e->capacity, st->n);
             const int rcm = check_launch(ctx, rc == 0 ? "k_apply_marks" : ctx->err.c_str());
             if (rc == 0) rc = rcm;
         }
@@ -3775,7 +4165,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (hipStreamSynchronize(s) != hipSuccess && rc == 0) rc = fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
         for (int k = 0; k < n_prof; ++k) {
             float ms = 0.f;
-            if (rc != 0 || hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]) != hipSuccess) {
+            const int a = ctx->tev_alias[k];
+            if (rc != 0 || hipEventElapsedTime(&ms, ev[2 * a], ev[2 * a + 1]) != hipSuccess) {
                 ms = -1.f;
                 if (rc == 0) rc = fail(ctx, ZRK_E_HIP, "hipEventElapsedTime");
             }
@@ -3819,12 +4210,23 @@ ZRK_API int zrk_read_sweep_ms(zrk_ctx *ctx, float *sweep_ms, int n)
     if (!ctx || !sweep_ms || n < 0) return fail(ctx, ZRK_E_INVALID, "zrk_read_sweep_ms: null argument");
     if (n > ctx->tev_pending) return fail(ctx, ZRK_E_INVALID, "zrk_read_sweep_ms: fewer events were recorded");
     for (int k = 0; k < n; ++k) {
-        if (hipEventSynchronize(ctx->tev[2 * k + 1]) != hipSuccess ||
-            hipEventElapsedTime(&sweep_ms[k], ctx->tev[2 * k], ctx->tev[2 * k + 1]) != hipSuccess)
+        const int a = ctx->tev_alias[k];
+        if (hipEventSynchronize(ctx->tev[2 * a + 1]) != hipSuccess ||
+            hipEventElapsedTime(&sweep_ms[k], ctx->tev[2 * a], ctx->tev[2 * a + 1]) != hipSuccess)
             return fail(ctx, ZRK_E_HIP, "zrk_read_sweep_ms: event not readable");
     }
     return 0;
 }
+
+ZRK_API int zrk_read_sweep_ticks(zrk_ctx *ctx, int32_t *ticks, int n)
+{
+    if (!ctx || !ticks || n < 0) return fail(ctx, ZRK_E_INVALID, "zrk_read_sweep_ticks: null argument");
+    if (n > (int)ctx->tev_ticks.size()) return fail(ctx, ZRK_E_INVALID, "zrk_read_sweep_ticks: fewer samples were taken");
+    for (int k = 0; k < n; ++k) ticks[k] = ctx->tev_ticks[k];
+    return 0;
+}
+
+ZRK_API int zrk_last_run_ticks_per_launch(zrk_ctx *ctx) { return ctx ? ctx->last_ticks_per_launch : ZRK_E_INVALID; }
 
 ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int64_t m, zrk_loop *st,
                           zrk_radar *radars, const zrk_scan *scan, int R, void *workspace, int32_t *det_idx,

@@ -346,6 +346,14 @@ class HotPathEngine:
         st.ctx.check(st.lib.zrk_read_sweep_ms(st.ctx.handle, out.ctypes.data_as(C.POINTER(C.c_float)), int(n)), "zrk_read_sweep_ms")
         return out
 
+    def read_sweep_ticks(self, n):
+        """Ticks swept by the launch behind each timing sample of the last run (1, or 2 for a pair launch)."""
+        C = self._C
+        out = np.zeros(int(n), np.int32)
+        st = self.store
+        st.ctx.check(st.lib.zrk_read_sweep_ticks(st.ctx.handle, out.ctypes.data_as(C.POINTER(C.c_int32)), int(n)), "zrk_read_sweep_ticks")
+        return out
+
     # results (each synchronises) ---------------------------------------------------------------
     def alive_count(self):
         return int(self.store.d_alive[:self.store.n_uploaded].sum().item())
