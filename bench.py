@@ -175,7 +175,7 @@ def build_ensemble(workload, rank, world, device):
 
 def cpu_baseline(info, eng, budget_s=15.0):
     """Time the oracle's L1 tick on the same scene (test infrastructure used as the reported CPU
-    baseline only).  Single-threaded advance/missile loop + OpenMP radar phase on all host cores."""
+    baseline only), on all host cores (OpenMP: AirEnv step and radar phase) and on one."""
     import numpy as np
     from oracle import oracle as O
     L = O.lib()
@@ -199,10 +199,11 @@ def cpu_baseline(info, eng, budget_s=15.0):
     cores = usable_cores()
 
     def tick(k, threads):
-        nev = L.zo_airenv_step(n, cap, 10 * k, 10, O.dptr(hsp), O.dptr(hvel), O.dptr(ht0), O.u8ptr(alive),
-                               O.u8ptr(kind), O.i32ptr(mrow), O.dptr(pos), O.dptr(prev), O.u8ptr(pv),
-                               O.i32ptr(m_tgt), O.dptr(m_radius), O.dptr(m_period), O.u8ptr(m_status),
-                               O.i32ptr(evm), O.i32ptr(evt), O.u8ptr(evs))
+        # (AirEnv.step on `threads` cores: targets in parallel, missiles in list order; identical results to the literal loop)
+        nev = L.zo_airenv_step_mt(n, cap, 10 * k, 10, O.dptr(hsp), O.dptr(hvel), O.dptr(ht0), O.u8ptr(alive),
+                                  O.u8ptr(kind), O.i32ptr(mrow), O.dptr(pos), O.dptr(prev), O.u8ptr(pv),
+                                  O.i32ptr(m_tgt), O.dptr(m_radius), O.dptr(m_period), O.u8ptr(m_status),
+                                  O.i32ptr(evm), O.i32ptr(evt), O.u8ptr(evs), threads)
         arr = O.radar_array([(r["position"][0], r["position"][1], r["position"][2], r["max_distance"], r["caz"],
                               r["azimuth_range"], r["cel"], r["elevation_range"]) for r in rs])
         L.zo_radar_phase_fused(n, cap, O.dptr(pos), O.u8ptr(alive), len(rs), arr, 1, None, 1237, k, 0,
@@ -228,8 +229,8 @@ def cpu_baseline(info, eng, budget_s=15.0):
     t_b = time.perf_counter(); tick(1 + ticks, 1); t_1core = time.perf_counter() - t_b
     return {"value": live * ticks / t_all, "unit": "entity-timesteps/s", "cores": cores, "cpu_model": cpu_model(),
             "kind": "port",
-            "sample": f"same scene, {ticks} ticks, oracle/zrk_oracle.c: 1-thread AirEnv+missile loop, "
-                      f"OpenMP radar phase on {cores} threads",
+            "sample": f"same scene, {ticks} ticks, oracle/zrk_oracle.c on {cores} OpenMP threads: AirEnv step (targets in parallel, "
+                      f"the {m} missiles in list order), radar phase, per-radar compaction (one thread)",
             "value_1core": live / t_1core,
             "reference_python_note": "reference itself (pure Python) measured in the survey container: "
                                      "1.6 us/entity + 4.3 us/(radar x entity), 1 thread (BASELINE.md section 2)"}

@@ -60,6 +60,9 @@ def lib():
     L.zo_airenv_step.restype = i64
     L.zo_airenv_step.argtypes = [i64, i64, i64, i64, dp, dp, dp, u8p, u8p, i32p, dp, dp, u8p,
                                  i32p, dp, dp, u8p, i32p, i32p, u8p]
+    L.zo_airenv_step_mt.restype = i64
+    L.zo_airenv_step_mt.argtypes = [i64, i64, i64, i64, dp, dp, dp, u8p, u8p, i32p, dp, dp, u8p,
+                                    i32p, dp, dp, u8p, i32p, i32p, u8p, C.c_int]
     L.zo_radar_sweep.restype = i64
     L.zo_radar_sweep.argtypes = [i64, i64, dp, u8p, C.POINTER(ZoRadar), i32p]
     L.zo_noise_apply.restype = None

@@ -130,6 +130,66 @@ ZO_API int64_t zo_airenv_step(int64_t n, int64_t cap, int64_t time_ms, int64_t d
     return nev;
 }
 
+/*
+ * The same step on `threads` host cores, for the all-core CPU baseline of bench.py (the reference's own loop is one
+ * thread by construction, modules/Manager.py:130-131; this is what a host port of L1 could do at best).
+ * Targets do not depend on one another within a tick: phase 1 advances every live target (kind 0) in parallel.  Missiles
+ * keep the list order (phase 2, sequential: their events are ordered and a missile may chase a missile).  What the
+ * literal loop gives a missile whose target stands BEHIND it in the list -- the target's position of the tick before,
+ * because the target has not stepped yet -- is what phase 1 left in `prev`.  Results identical to zo_airenv_step
+ * (tests/test_oracle_golden.py).
+ */
+ZO_API int64_t zo_airenv_step_mt(int64_t n, int64_t cap, int64_t time_ms, int64_t dt_ms,
+                                 const double *sp, const double *vel, const double *t0,
+                                 const uint8_t *alive, const uint8_t *kind, const int32_t *mrow,
+                                 double *pos, double *prev, uint8_t *prev_valid,
+                                 const int32_t *m_tgt, const double *m_radius, double *m_period,
+                                 uint8_t *m_status,
+                                 int32_t *ev_missile, int32_t *ev_target, uint8_t *ev_self, int threads)
+{
+    double t = (double)time_ms / 1000.0;
+    double dts = (double)dt_ms / 1000.0;
+    int64_t nev = 0;
+    (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (int64_t i = 0; i < n; ++i) {
+        if (!alive[i] || kind[i] != 0) continue;
+        double p[3];
+        for (int c = 0; c < 3; ++c) prev[c * cap + i] = pos[c * cap + i];
+        prev_valid[i] = (t0[i] != t);
+        zo_get_pos(sp, vel, t0, cap, i, t, p);
+        for (int c = 0; c < 3; ++c) pos[c * cap + i] = p[c];
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        if (!alive[i] || kind[i] != 1) continue;
+        int32_t r = mrow[i];
+        if (m_status[r] != 1) continue;
+        double p[3];
+        for (int c = 0; c < 3; ++c) prev[c * cap + i] = pos[c * cap + i];
+        prev_valid[i] = (t0[i] != t);
+        zo_get_pos(sp, vel, t0, cap, i, t, p);
+        for (int c = 0; c < 3; ++c) pos[c * cap + i] = p[c];
+        int32_t j = m_tgt[r];
+        /* a live target behind the missile in the list has not stepped yet in the literal loop */
+        const double *tp = (kind[j] == 0 && j > i && alive[j]) ? prev : pos;
+        double dx = tp[0 * cap + j] - p[0], dy = tp[1 * cap + j] - p[1], dz = tp[2 * cap + j] - p[2];
+        double dist = zo_norm3(dx, dy, dz);
+        if (dist <= m_radius[r]) {
+            ev_missile[nev] = (int32_t)i; ev_target[nev] = j; ev_self[nev] = 0; ++nev;
+            m_status[r] = 2;
+            continue;
+        }
+        m_period[r] -= dts;
+        if (m_period[r] <= 0.0) {
+            ev_missile[nev] = (int32_t)i; ev_target[nev] = -1; ev_self[nev] = 1; ++nev;
+            m_status[r] = 2;
+        }
+    }
+    return nev;
+}
+
 /* Radar parameter block: 8 doubles per radar, the fields find_visible_objects reads. */
 typedef struct {
     double px, py, pz;       /* self.pos                    */

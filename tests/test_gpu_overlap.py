@@ -211,12 +211,15 @@ def test_overlapped_calls_match_the_oracle_directly():
 
 
 def test_a_missile_whose_target_is_a_missile(monkeypatch):
-    """A missile row may name another missile's row as its target (the C ABI takes any row).  When B hits A in tick t, A is
-    out of the air from tick t + 1 on (AirEnv.py:33-40) -- in the overlapped loop that removal is a mark which A's own row
-    thread carries out somewhere inside sweep t + 1, the very grid whose leading workgroups step the missiles: A's missile
-    thread must read the mark, not the flag.  Half of the A's would time out in exactly that tick if they were allowed
-    to step once more: an extra event, an extra removal.  Against the two-launch loop after every call, and against the
-    oracle tick by tick."""
+    """A missile row may name another missile's row as its target (the C ABI takes any row).
+    * B hits A in tick t: A is out of the air from tick t + 1 on (AirEnv.py:33-40) -- in the overlapped loop that removal is
+      a mark which A's own row thread carries out somewhere inside a later grid, the very grid whose leading workgroups step
+      the missiles: A's missile thread must read the mark, not the flag.  Half of these A's would time out in exactly that
+      tick if they were allowed to step once more: an extra event, an extra removal.
+    * A chases C, which stands BEHIND it in the list: A compares with what C held after the tick before -- radar noise
+      included -- which in the second tick of a pair launch no thread may have written yet (the missile phase then replays
+      C's radar phase of the first tick).  The chases end in hits at ticks of either parity.
+    Against the two-launch loop after every call, and against the oracle tick by tick."""
     from tests.test_gpu_engine import OracleMirror, _compare_tick, _device_noise_table
     from zrk_modulation_amd import scenario as S
     from zrk_modulation_amd.engine import HotPathEngine
@@ -230,38 +233,62 @@ def test_a_missile_whose_target_is_a_missile(monkeypatch):
         monkeypatch.setenv("ZRK_OVERLAP_MIN_ROWS", "0")
         monkeypatch.setenv("ZRK_OVERLAP", ov)
         eng = HotPathEngine(device="cuda:0", dt_ms=dt, seed=8, noise="philox", gid0=0)
-        eng.load(ids, sp, vel, t0, radars, missile_capacity=2 * pairs).enable_lists()
-        # the A's: every other one would run out of time in its second tick in the air (1.5 ticks of fuse)
-        k = eng.launch_missiles(tgt, speed=2500.0, radius=300.0, period=40.0)
+        eng.load(ids, sp, vel, t0, radars, missile_capacity=3 * pairs).enable_lists()
+        # the A's: slow, with different fuse radii (the chases below end at different times)
+        radius_a = 120.0 + 35.0 * (np.arange(pairs) % 10)
+        k = eng.launch_missiles(tgt, launcher_pos=(0.0, 0.0, 600.0), speed=2350.0, radius=radius_a, period=40.0)
+        ok_a = eng.launch_results["rc"] == 0
         assert k > pairs // 2
-        eng.store.dm_period[0:k:2] = 1.5 * dt / 1000       # (a launch with so short a fuse would be cancelled: Missile.py:98-99)
-        # the B's fly the same lines (same launcher, same target, same speed: the same solves succeed) -- and are then
-        # aimed at their A
-        assert eng.launch_missiles(tgt, speed=2500.0, radius=50.0, period=40.0) == k
+        # the B's fly the same lines (same launcher, same target, same speed: the same solves succeed); the C's leave at the
+        # same time from 600 m below, faster, for the same targets: the two lines converge, and what an A sees of its C --
+        # where C stood a tick ago, C being behind A in the list -- comes within A's fuse radius somewhere on the way
+        assert eng.launch_missiles(tgt, launcher_pos=(0.0, 0.0, 600.0), speed=2350.0, radius=50.0, period=40.0) == k
+        kc = eng.launch_missiles(tgt, speed=2500.0, radius=50.0, period=40.0)
+        ok_c = eng.launch_results["rc"] == 0
         st = eng.store
-        rows_a = np.asarray(st.hm_slot[:k], np.int32)
-        st.dm_tgt[k:2 * k] = torch.as_tensor(rows_a, device=st.device)
-        st.hm_tgt = np.concatenate([st.hm_tgt[:k], rows_a])
+        rows_m = np.asarray(st.hm_slot[:st.m], np.int32)
+        row_a = np.full(pairs, -1, np.int32); row_a[ok_a] = rows_m[:k]
+        row_b = np.full(pairs, -1, np.int32); row_b[ok_a] = rows_m[k:2 * k]
+        row_c = np.full(pairs, -1, np.int32); row_c[ok_c] = rows_m[2 * k:2 * k + kc]
+        mrow_of = {int(r): i for i, r in enumerate(rows_m)}              # table row -> missile row
+        new_tgt = np.asarray(st.hm_tgt[:st.m], np.int32).copy()
+        who = np.arange(pairs)
+        hit_by_b = ok_a & (who % 3 == 0)
+        chasing = ok_a & ok_c & (who % 3 == 1)
+        for i in np.nonzero(hit_by_b)[0]:
+            new_tgt[mrow_of[int(row_b[i])]] = row_a[i]                   # B_i -> A_i
+        for i in np.nonzero(chasing)[0]:
+            new_tgt[mrow_of[int(row_a[i])]] = row_c[i]                   # A_i -> C_i (behind it in the list)
+        st.dm_tgt[:st.m] = torch.as_tensor(new_tgt, device=st.device)
+        st.hm_tgt = new_tgt
+        rows_a, rows_c = row_a, row_c
+        # every sixth A would run out of time in its second tick in the air (a launch with so short a fuse would be
+        # cancelled, Missile.py:98-99: set afterwards)
+        st.dm_period[0:k:6] = 1.5 * dt / 1000
         engines.append(eng)
     ref, ovl = engines
     mir = OracleMirror(ref, radars)
     tick = 0
     seen = []
-    for calls, K in enumerate([6, 4, 9]):
+    for calls, K in enumerate([6, 4, 9, 5, 8]):
         events = None
         for _ in range(K):
             events = mir.tick(tick * dt, dt, 2, _device_noise_table(ref, tick, R, mir.n))
-            seen.append(len(events))
+            seen.append(events)
             tick += 1
         ref.run(K)
         ovl.run(K)
         assert ovl.store.lib.zrk_last_run_overlapped(ovl.store.ctx.handle) == 1
         _same(_state(ref), _state(ovl), f"after call {calls} of {K} ticks")
         _compare_tick(ovl, mir, events, f"overlapped loop after {tick} ticks")
-    # tick 0: every B hits its A (distance 0); tick 1: nothing -- the A's are gone, although half of them were due
-    assert seen[0] == k and seen[1] == 0, seen[:3]
-    alive = ovl.store.d_alive[:ovl.store.n_uploaded].cpu().numpy()
-    assert alive[np.asarray(ovl.store.hm_slot[:2 * k])].sum() == 0
+    # tick 0: every third B hits its A (distance 0); tick 1: none of those A's detonates, although half of them were due
+    list_a = set(int(x) for x in mir.lidx[rows_a[hit_by_b]])
+    assert sum(1 for ms, ts in seen[0] if ts in list_a) == len(list_a)
+    assert not any(ms in list_a for ms, ts in seen[1])
+    # the chases A_i -> C_i: hits in ticks of both parities
+    list_c = set(int(x) for x in mir.lidx[rows_c[chasing]])
+    hit_ticks = [t for t, evs in enumerate(seen) for ms, ts in evs if ts in list_c]
+    assert len(hit_ticks) > 20 and len({t % 2 for t in hit_ticks}) == 2, hit_ticks[:40]
 
 
 def test_a_failed_side_stream_is_not_sticky(monkeypatch):

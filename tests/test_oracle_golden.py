@@ -68,3 +68,46 @@ def test_oracle_association_equals_the_reference_loop_in_numpy():
         if m >= 0:
             u[m] = now
     assert np.array_equal(got, want) and (want >= 0).sum() > 20
+
+
+def test_multithreaded_airenv_step_equals_the_literal_loop():
+    """zo_airenv_step_mt (targets in parallel, missiles in list order -- the all-core CPU baseline of bench.py) against the
+    literal loop zo_airenv_step, which the fixtures pin: positions, prev positions, prev_valid, missile table, ordered
+    events, tick by tick -- with missiles that chase missiles in front of and behind them in the list, targets behind their
+    missiles, removals and time-outs on the way."""
+    L = O.lib()
+    g = np.random.Generator(np.random.PCG64(77))
+    n_t, n_m, ticks, dt = 3000, 400, 60, 100
+    n = n_t + n_m
+    kind = np.zeros(n, np.uint8)
+    slots_m = np.sort(g.choice(n, n_m, replace=False))           # missiles scattered through the list
+    kind[slots_m] = 1
+    mrow = np.full(n, -1, np.int32); mrow[slots_m] = np.arange(n_m, dtype=np.int32)
+    sp = g.uniform(-3e3, 3e3, (3, n)); vel = g.normal(0, 200, (3, n)); t0 = np.where(g.uniform(size=n) < 0.1, 0.3, 0.0)
+    m_tgt = g.integers(0, n, n_m).astype(np.int32)               # anything: targets, missiles, in front or behind
+    m_radius = g.uniform(200, 900, n_m); period0 = g.uniform(0.5, 8.0, n_m)
+
+    def state():
+        return dict(pos=np.ascontiguousarray(sp).reshape(-1).copy(), prev=np.ascontiguousarray(sp).reshape(-1).copy(),
+                    pv=np.zeros(n, np.uint8), alive=np.ones(n, np.uint8), period=period0.copy(), status=np.ones(n_m, np.uint8),
+                    ev=(np.zeros(n_m, np.int32), np.zeros(n_m, np.int32), np.zeros(n_m, np.uint8)))
+    a, b = state(), state()
+    spf, velf = np.ascontiguousarray(sp).reshape(-1), np.ascontiguousarray(vel).reshape(-1)
+    total = 0
+    for k in range(ticks):
+        out = []
+        for S, fn, extra in ((a, L.zo_airenv_step, ()), (b, L.zo_airenv_step_mt, (4,))):
+            nev = fn(n, n, k * dt, dt, O.dptr(spf), O.dptr(velf), O.dptr(t0), O.u8ptr(S["alive"]), O.u8ptr(kind), O.i32ptr(mrow),
+                     O.dptr(S["pos"]), O.dptr(S["prev"]), O.u8ptr(S["pv"]), O.i32ptr(m_tgt), O.dptr(m_radius), O.dptr(S["period"]),
+                     O.u8ptr(S["status"]), O.i32ptr(S["ev"][0]), O.i32ptr(S["ev"][1]), O.u8ptr(S["ev"][2]), *extra)
+            out.append([(int(S["ev"][0][j]), int(S["ev"][1][j]), int(S["ev"][2][j])) for j in range(nev)])
+        assert out[0] == out[1], f"tick {k}: events differ"
+        for key in ("pos", "prev", "pv", "period", "status"):
+            assert np.array_equal(a[key].view(np.uint8), b[key].view(np.uint8)), f"tick {k}: {key} differs"
+        for S in (a, b):                                          # AirEnv.py:33-40: removals take effect on the next tick
+            for ms, ts, _ in out[0]:
+                S["alive"][ms] = 0
+                if ts >= 0:
+                    S["alive"][ts] = 0
+        total += len(out[0])
+    assert total > 100
