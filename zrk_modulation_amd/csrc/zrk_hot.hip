@@ -204,6 +204,10 @@ struct MissileArgs {
     // compaction side: the event builder of a pair's FIRST tick clears, in the second tick's mask buffer, the bits of the rows
     // its events removed (they were swept once more as if nothing had happened)
     uint32_t *clear_vis;
+    // ... or, where the pair's two compactions are ONE launch (k_compact_pair), a list the sweep's missile threads append the
+    // removed rows' list indices to as they decide the first tick's events: rm[0] = entries, rm_cap of them fit
+    int32_t *rm;
+    int32_t rm_cap, _pad4;
 };
 
 // Dispatch order of the next sweep.  The sweep's duration is set by the expensive waves (rows inside some
@@ -927,10 +931,21 @@ __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) voi
         // dependent chain -- dispatched first, it is over long before the sweep's last wave is)
         const int64_t row = (int64_t)blockIdx.x * ZRK_BLOCK + threadIdx.x;
         const char *rb_first = P.rb_table ? P.rb_table : kernarg + offsetof(SweepParams, rb);
-        if (row < M.m)
-            M.ev_code[row] = missile_step_row(M.sp, M.vel, M.t0, M.alive, M.lidx, M.pos_prev, M.cap, M.m_slot, M.m_tgt,
-                                              M.m_radius, M.m_period, M.m_status, row, M.t, M.dts, M.pend, M.mark, M.grec,
-                                              M.pos_abs[0], M.pos_abs[1]);
+        if (row < M.m) {
+            const uint8_t code = missile_step_row(M.sp, M.vel, M.t0, M.alive, M.lidx, M.pos_prev, M.cap, M.m_slot, M.m_tgt,
+                                                  M.m_radius, M.m_period, M.m_status, row, M.t, M.dts, M.pend, M.mark, M.grec,
+                                                  M.pos_abs[0], M.pos_abs[1]);
+            M.ev_code[row] = code;
+            if (PAIR && M.rm && code) {            // the rows this event removes are swept once more below: say which (k_compact_pair)
+                const int cnt = code == 1 ? 2 : 1;
+                const int k = atomicAdd(M.rm, cnt);
+                const int32_t ms = M.m_slot[row], ts = M.m_tgt[row];
+                if (k + cnt <= M.rm_cap) {
+                    M.rm[1 + k] = M.lidx ? M.lidx[ms] : ms;
+                    if (code == 1) M.rm[2 + k] = M.lidx ? M.lidx[ts] : ts;
+                }
+            }
+        }
         if (PAIR) {
             missile_pair_barrier(M.bar, M.bar_target);
             if (row < M.m)
@@ -1633,6 +1648,254 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_side(const CompactArgs C
         return;
     }
     compact_block<kCompBlock>(S, C, by_ticket);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The two compactions of a PAIR launch's ticks in ONE launch (side stream): every workgroup squeezes the same slots of
+// both ticks' mask buffers, publishes ONE record with both ticks' R + 1 counts and waits ONCE for its predecessors -- the
+// single-launch compaction is a chain of dependent round trips, which two ticks then share.  The first tick's lists go to
+// buffers of the context's own (a call's intermediate lists are overwritten by the next tick's wherever they are
+// written: nobody can have read them), the second tick's where the caller reads.  C1 differs from C0 in vis / zero_next /
+// det_idx / det_cnt / packed only.  `rm`: list indices of the rows the first tick's missile phase removed (rm[0] = how
+// many), whose bits the sweep's second tick set all the same (SweepParams::t2): taken out of the second tick's masks here.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPairItems = kFusedMaxItems / 2;
+constexpr int kPairAggStride = 2 * kAggStride;
+
+struct CompactSharedPair {
+    int wcnt[2][kPairItems * (kCompBlock / 64)];
+    int cnt[2][ZRK_MAX_RADARS + 1];
+    int pre[2 * (ZRK_MAX_RADARS + 1)];
+    int ticket, found[2];
+    unsigned short idx[2][kPairItems * kCompBlock];
+    uint32_t msk[2][kPairItems * kCompBlock];
+};
+
+__device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const CompactArgs &C0, const CompactArgs &C1, const int32_t *rm,
+                                                   int rm_cap)
+{
+    constexpr int THREADS = kCompBlock, WAVES = kCompBlock / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) S.ticket = atomicAdd(&C0.ctl[0], 1);
+    if (tid < 2 * (ZRK_MAX_RADARS + 1)) S.pre[tid] = 0;
+    __syncthreads();
+    const int b = S.ticket;
+    if (b < 0 || b >= C0.nb) {                       // a workspace that was not ours: refuse rather than scribble
+        if (tid == 0) atomicExch(&C0.ctl[2], 1);
+        return;
+    }
+    const int R = C0.R, items = C0.items;
+    const int64_t blk0 = (int64_t)b * items * THREADS;
+    const bool last = b == C0.nb - 1;
+    // the rows the first tick removed (few, mostly none): their list indices
+    int rmn = rm ? __hip_atomic_load(rm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    rmn = rmn < rm_cap ? rmn : rm_cap;
+    uint32_t mk[2][kPairItems];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const CompactArgs &C = s ? C1 : C0;
+#pragma unroll
+        for (int it = 0; it < kPairItems; ++it) {    // every load in flight before anything looks at one
+            const int64_t i = blk0 + (int64_t)it * THREADS + tid;
+            mk[s][it] = (it < items && i < C.n) ? C.vis[i] : 0u;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const CompactArgs &C = s ? C1 : C0;
+#pragma unroll
+        for (int it = 0; it < kPairItems; ++it) {
+            if (it < items) {
+                const int64_t i = blk0 + (int64_t)it * THREADS + tid;
+                // (the loop's own mask buffers are cleared by the compaction that reads them: only the detections are not zero)
+                if (C.zero_next && i < C.n && (!C.zero_own || mk[s][it] != 0u)) C.zero_next[i] = 0u;
+            }
+        }
+    }
+    for (int q = 0; q < rmn; ++q) {                  // (wave-uniform trip count; every thread compares its own slots)
+        const int64_t off = (int64_t)rm[1 + q] - blk0;
+#pragma unroll
+        for (int it = 0; it < kPairItems; ++it)
+            if (off == (int64_t)it * THREADS + tid) mk[1][it] = 0u;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const CompactArgs &C = s ? C1 : C0;
+#pragma unroll
+        for (int it = 0; it < kPairItems; ++it) {
+            if (it < items) {
+                const unsigned long long bu = __ballot(mk[s][it] != 0u);
+                if (lane == 0) {
+                    S.wcnt[s][it * WAVES + wave] = (int)__popcll(bu);
+                    const int64_t word = (blk0 + (int64_t)it * THREADS + wave * 64) >> 6;      // 64 consecutive slots
+                    if (C.packed && C.bits.words && word < C.bits.words) C.packed[2 + word] = (int64_t)bu;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (wave < 2) {                                  // exclusive scans of the (item, wave) counts: wave s takes tick s
+        const int s = wave, m2 = items * WAVES;
+        const int a0 = (2 * lane < m2) ? S.wcnt[s][2 * lane] : 0, a1 = (2 * lane + 1 < m2) ? S.wcnt[s][2 * lane + 1] : 0;
+        int incl = a0 + a1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        const int excl = incl - a0 - a1;
+        if (2 * lane < m2) S.wcnt[s][2 * lane] = excl;
+        if (2 * lane + 1 < m2) S.wcnt[s][2 * lane + 1] = excl + a0;
+        if (lane == 63) S.found[s] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int it = 0; it < kPairItems; ++it) {
+            if (it < items) {
+                const unsigned long long bu = __ballot(mk[s][it] != 0u);
+                if (mk[s][it] != 0u) {
+                    const int k = S.wcnt[s][it * WAVES + wave] +
+                                  (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bu >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bu, 0u));
+                    S.idx[s][k] = (unsigned short)(it * THREADS + tid);
+                    S.msk[s][k] = mk[s][it];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // per-radar counts over the two short lists: 2 R (tick, radar) jobs dealt out to the waves
+    for (int job = wave; job < 2 * R; job += WAVES) {
+        const int s = job >= R ? 1 : 0, r = job - s * R;
+        const int found = S.found[s];
+        int run = 0;
+        for (int c = 0; c < found; c += 256) {
+            uint32_t q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = c + u * 64 + lane;
+                q[u] = (k < found) ? S.msk[s][k] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) run += (int)__popcll(__ballot((q[u] >> r) & 1u));
+        }
+        if (lane == 0) S.cnt[s][r] = run;
+    }
+    if (tid < 2) S.cnt[tid][R] = S.found[tid];
+    __syncthreads();
+    const int nctr = 2 * (R + 1);                    // counter c: tick c / (R + 1), radar (or R: the union) c % (R + 1)
+    if (tid < nctr)
+        __hip_atomic_store(&C0.agg[(int64_t)b * kPairAggStride + tid],
+                           ((unsigned long long)C0.epoch << 32) | (uint32_t)S.cnt[tid / (R + 1)][tid % (R + 1)], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    {
+        // lower tickets: record p, counter c is word p * lanes + c of a (p, c) grid dealt out to the threads
+        constexpr int kBatch = 8;
+        const int lanes = C0.lanes;                  // a power of two >= nctr
+        const int c = tid & (lanes - 1);
+        const int p_first = tid / lanes, p_step = THREADS / lanes;
+        int acc = 0;
+        bool timed_out = false;
+        if (c < nctr) {
+            for (int p0 = p_first; p0 < b; p0 += p_step * kBatch) {
+                unsigned long long v[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int p = p0 + u * p_step;
+                    v[u] = (p < b) ? agg_load(&C0.agg[(int64_t)p * kPairAggStride + c]) : ((unsigned long long)C0.epoch << 32);
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int p = p0 + u * p_step;
+                    int spins = 0;
+                    while ((uint32_t)(v[u] >> 32) != C0.epoch) {
+                        if (++spins > kSpinLimit) { timed_out = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        v[u] = agg_load(&C0.agg[(int64_t)p * kPairAggStride + c]);
+                    }
+                    acc += (int)(uint32_t)v[u];
+                }
+            }
+            if (acc) atomicAdd(&S.pre[c], acc);
+            if (timed_out) atomicExch(&C0.ctl[2], 2);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const CompactArgs &C = s ? C1 : C0;
+        const int found = S.found[s];
+        const int *pre = S.pre + s * (R + 1);
+        if (C.packed) {
+            const int64_t ubase = pre[R];
+            for (int k = tid; k < found; k += THREADS) {
+                const int64_t dst = ubase + k;
+                if (C.bits.words) union_bits_mask(C.packed, C.bits, dst, S.msk[s][k]);
+                else if (dst + 1 < C.packed_capacity) C.packed[dst + 1] = ((C.gid0 + blk0 + S.idx[s][k]) << 32) | (int64_t)S.msk[s][k];
+            }
+        }
+        if (last && tid <= R) {                          // the end of the list: totals
+            const int tot = pre[tid] + S.cnt[s][tid];
+            if (C.det_cnt) C.det_cnt[tid] = tot;
+            if (C.packed && tid == R) {
+                C.packed[0] = tot;
+                if (C.bits.words) C.packed[1] = C.n;
+            }
+        }
+    }
+    if (C0.det_idx) {
+        for (int job = wave; job < 2 * R; job += WAVES) {
+            const int s = job >= R ? 1 : 0, r = job - s * R;
+            const CompactArgs &C = s ? C1 : C0;
+            const int found = S.found[s];
+            int run = S.pre[s * (R + 1) + r];
+            int32_t *out = C.det_idx + (int64_t)r * C.det_stride;
+            const int32_t slot0 = C.base_index + (int32_t)blk0;
+            for (int c = 0; c < found; c += 256) {     // four steps of 64 entries, their LDS reads in flight together
+                uint32_t q[4];
+                unsigned short ix[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = c + u * 64 + lane;
+                    q[u] = (k < found) ? S.msk[s][k] : 0u;
+                    ix[u] = (k < found) ? S.idx[s][k] : (unsigned short)0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool bit = (q[u] >> r) & 1u;
+                    const unsigned long long bb = __ballot(bit);
+                    if (bit) {
+                        const int64_t dst = (int64_t)run + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u));
+                        if (dst < C.det_stride) out[dst] = slot0 + (int32_t)ix[u];
+                    }
+                    run += (int)__popcll(bb);
+                }
+            }
+        }
+    }
+    if (tid == 0) {
+        if (atomicAdd(&C0.ctl[1], 1) == C0.nb - 1) {     // everybody holds a ticket and is done with it
+            atomicExch(&C0.ctl[0], 0);
+            atomicExch(&C0.ctl[1], 0);
+            if (rm) __hip_atomic_store((int32_t *)rm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the list is this launch's to clear)
+        }
+    }
+}
+
+__global__ __launch_bounds__(kCompBlock) void k_compact_pair(const CompactArgs C0, const CompactArgs C1, const MissileArgs M0,
+                                                             const MissileArgs M1, const int32_t *rm, int rm_cap)
+{
+    __shared__ int s_wave[kCompBlock / 64];
+    __shared__ CompactSharedPair S;
+    if ((int)blockIdx.x >= C0.nb) {                  // two extra workgroups: the ticks' ordered event lists
+        if (M0.m > 0) {
+            if ((int)blockIdx.x == C0.nb) missile_finish_entry(s_wave, M0);
+            else missile_finish_entry(s_wave, M1);
+        }
+        return;
+    }
+    compact_block_pair(S, C0, C1, rm, rm_cap);
 }
 
 // Overlapped loop of an ENSEMBLE: what the next sweep needs of a tick's second launch -- the tombstones, every
@@ -2344,6 +2607,12 @@ struct SideItem {
     // the LAST tick of a call has no next sweep to raise the word: its compaction waits, on the device, for an event recorded
     // behind that sweep (an event record costs the compute stream a barrier packet -- harmless where no sweep follows)
     hipEvent_t wait_event;
+    // both ticks of a pair launch in one compaction launch (k_compact_pair): C / M are the first tick's, C2 / M2 the second's
+    int pair, done_slot2;
+    CompactArgs C2;
+    MissileArgs M2;
+    const int32_t *rm;
+    int rm_cap;
     zrk_exchange *post_x;
     int post_slot;
     const int64_t *post_send;
@@ -2377,6 +2646,13 @@ struct Side {
     hipEvent_t last_sweep = nullptr;   // recorded behind the last sweep of a call (SideItem::wait_event)
     uint32_t *bar = nullptr;           // DEVICE: the barrier of a pair launch's missile workgroups (arrivals, gave-up word)
     uint32_t bar_epoch = 0;            // arrivals asked for so far
+    // k_compact_pair: per ring slot the list of rows a pair's first tick removed (MissileArgs::rm), and where the FIRST tick's
+    // lists, union list and ordered events go (the second tick's go where the caller reads)
+    int32_t *rm[kMasks + 1] = {nullptr};
+    int rm_cap = 0;
+    int32_t *scratch_det = nullptr, *scratch_cnt = nullptr, *scratch_ev = nullptr;
+    int64_t *scratch_packed = nullptr;
+    int64_t scratch_det_ints = 0, scratch_packed_words = 0, scratch_ev_rows = 0;
     int cu_count = 0;                  // ZRK_SIDE_CUS: the side stream is confined to this many compute units (0: all)
     bool posted[kMasks + 1] = {false, false, false, false};
     uint64_t item_no[kMasks + 1] = {0, 0, 0, 0};
@@ -2444,6 +2720,7 @@ struct zrk_ctx {
     int rb_cache_R[2] = {-1, -1};
     uint32_t rb_cache_flags[2] = {0, 0};
     bool pair_enabled = true;          // ZRK_PAIR=0: one tick per launch in the overlapped loop
+    bool pair_compact = true;          // ZRK_PAIR_COMPACT=0: a pair's two compactions as two launches
     int last_ticks_per_launch = 1;     // of the last zrk_run_ticks* call
     std::vector<int> tev_alias, tev_ticks;   // per timing sample: which event pair holds it, and the ticks its launch swept
     bool tail_by_event = true;         // ZRK_TAIL_EVENT=0: the last compaction of a call is released by a launch that raises the host word
@@ -2476,7 +2753,7 @@ struct Workspace {
 };
 
 constexpr int64_t kFusedBytes = kFusedCtlInts * (int64_t)sizeof(int32_t) +
-                                (int64_t)kFusedMaxBlocks * kAggStride * (int64_t)sizeof(unsigned long long);
+                                (int64_t)kFusedMaxBlocks * kPairAggStride * (int64_t)sizeof(unsigned long long);
 
 inline int64_t order_ints(int64_t n) { return ((n + ZRK_BLOCK - 1) / ZRK_BLOCK + 64) & ~(int64_t)63; }
 inline int64_t box_ints(int64_t n) { return ((((n + ZRK_BLOCK - 1) / ZRK_BLOCK + 4) * (int64_t)(sizeof(WaveBox) / 4)) + 63) & ~(int64_t)63; }
@@ -2533,6 +2810,7 @@ ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
     { const char *v = std::getenv("ZRK_GATHER_RECORDS"); c->grec_enabled = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_TAIL_EVENT"); c->tail_by_event = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_PAIR"); c->pair_enabled = !(v && v[0] == '0'); }
+    { const char *v = std::getenv("ZRK_PAIR_COMPACT"); c->pair_compact = !(v && v[0] == '0'); }
     if (const char *v = std::getenv("ZRK_COMPACT_ITEMS")) c->env_items = std::max(1, std::atoi(v));
     if (const char *v = std::getenv("ZRK_COMPACT_ORDER")) c->env_order = std::strcmp(v, "block") != 0;
     c->fused_max_blocks = kFusedMaxBlocks;
@@ -2604,6 +2882,7 @@ MissileArgs missile_args(const zrk_entities *e, int cur, const zrk_missiles *mis
     M.pend = nullptr; M.mark = 0; M._pad3 = 0; M.grec = nullptr;
     M.pos_abs[0] = e->pos[0]; M.pos_abs[1] = e->pos[1];
     M.ev_code2 = nullptr; M.mark2 = 0; M.bar_target = 0; M.bar = nullptr; M.t2 = M.t; M.clear_vis = nullptr;
+    M.rm = nullptr; M.rm_cap = 0; M._pad4 = 0;
     return M;
 }
 
@@ -2767,7 +3046,7 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
                    int32_t *det_idx, int64_t det_stride, int32_t *det_cnt, int64_t *packed, int64_t packed_capacity,
                    int64_t gid0, void *stream, const MissileArgs &M, uint32_t *zero_next,
                    bool union_bits = false, const EnsLaunch *ens = nullptr, const PutArgs *put = nullptr,
-                   SideItem *defer = nullptr)
+                   SideItem *defer = nullptr, int force_items = 0)
 {
     if (!ctx || !vis_mask || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_compact: null argument");
     if ((det_idx && !det_cnt) || (!det_idx && !packed)) return fail(ctx, ZRK_E_INVALID, "zrk_compact: no output requested");
@@ -2789,11 +3068,11 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         return 0;
     }
     // single launch: about one workgroup per compute unit, each thread holding up to kFusedMaxItems slots
-    const int items = ens ? ens->items : fused_items(ctx, n);
+    const int items = force_items > 0 ? force_items : (ens ? ens->items : fused_items(ctx, n));
     const int64_t nbf = (n + (int64_t)kCompBlock * items - 1) / ((int64_t)kCompBlock * items);
     if (ens && (packed || nbf > kFusedMaxBlocks || nbf > ctx->fused_max_blocks))
         return fail(ctx, ZRK_E_INVALID, "zrk_compact: an ensemble takes the single-launch path and has no union list");
-    if (ens || compacts_in_one_launch(ctx, n)) {
+    if (ens || (force_items > 0 && nbf <= kFusedMaxBlocks) || compacts_in_one_launch(ctx, n)) {
         Workspace w = carve(workspace, 0, n);
         if (ctx->fused_ws != workspace) {          // first use by this context: no ticket, no record, no error
             if (hipMemsetAsync(workspace, 0, kFusedBytes, s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "memset workspace");
@@ -3458,12 +3737,20 @@ int side_issue(Side *sd, const SideItem &it)
     }
     if (!it.wait_event && (int32_t)(*sd->hflag - it.flag_value) < 0) { sd->err = "side stream: stopped"; return ZRK_E_STATE; }
     g_trace.mark("side: flag seen");
-    hipLaunchKernelGGL(k_compact_side, dim3(it.C.nb + (it.M.m > 0 ? 1 : 0)), dim3(kCompBlock), 0, it.stream, it.C, it.by_ticket, it.M);
+    if (it.pair)
+        hipLaunchKernelGGL(k_compact_pair, dim3(it.C.nb + (it.M.m > 0 ? 2 : 0)), dim3(kCompBlock), 0, it.stream, it.C, it.C2, it.M, it.M2,
+                           it.rm, it.rm_cap);
+    else
+        hipLaunchKernelGGL(k_compact_side, dim3(it.C.nb + (it.M.m > 0 ? 1 : 0)), dim3(kCompBlock), 0, it.stream, it.C, it.by_ticket, it.M);
     // an exchange's collective (on the exchange's own stream) waits for this word: the list and its events are complete
     if (it.raise) hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, it.stream, it.raise, it.raise_value);
     if (hipGetLastError() != hipSuccess) { sd->err = "side stream: compaction launch failed"; return ZRK_E_HIP; }
     if (hipEventRecord(sd->done[it.done_slot], it.stream) != hipSuccess) { sd->err = "side stream: hipEventRecord failed"; return ZRK_E_HIP; }
     sd->posted[it.done_slot] = true;
+    if (it.pair) {
+        if (hipEventRecord(sd->done[it.done_slot2], it.stream) != hipSuccess) { sd->err = "side stream: hipEventRecord failed"; return ZRK_E_HIP; }
+        sd->posted[it.done_slot2] = true;
+    }
     g_trace.mark("side: compaction issued");
     if (it.post_x && exchange_post_behind_flag(it.post_x, it.post_slot, it.post_send, it.post_recv, it.post_words, it.raise_value) != 0) {
         sd->err = std::string("side stream: ") + it.post_x->err;
@@ -3545,6 +3832,7 @@ int side_enqueue(zrk_ctx *ctx, Side *sd, const SideItem &it)
     sd->ring[h % Side::kRing] = it;
     sd->head.store(h + 1, std::memory_order_release);
     sd->item_no[it.done_slot] = h + 1;
+    if (it.pair) sd->item_no[it.done_slot2] = h + 1;
     if (sd->asleep.load()) { std::lock_guard<std::mutex> lk(sd->mu); sd->cv.notify_one(); }
     return 0;
 }
@@ -3597,6 +3885,11 @@ void side_destroy(Side *sd)
     for (int k = 0; k < Side::kMasks; ++k) if (sd->codes[k]) (void)hipFree(sd->codes[k]);
     if (sd->pend) (void)hipFree(sd->pend);
     if (sd->bar) (void)hipFree(sd->bar);
+    for (int k = 0; k <= Side::kMasks; ++k) if (sd->rm[k]) (void)hipFree(sd->rm[k]);
+    if (sd->scratch_det) (void)hipFree(sd->scratch_det);
+    if (sd->scratch_cnt) (void)hipFree(sd->scratch_cnt);
+    if (sd->scratch_ev) (void)hipFree(sd->scratch_ev);
+    if (sd->scratch_packed) (void)hipFree(sd->scratch_packed);
     if (sd->hflag) (void)hipHostFree((void *)sd->hflag);
     delete sd;
 }
@@ -3766,6 +4059,20 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                 if (hipMalloc((void **)&sd->codes[k], (size_t)rows) != hipSuccess)
                     return fail(ctx, ZRK_E_HIP, "zrk_run_ticks: the side stream's event-code buffers could not be allocated");
             }
+            // (with them: the lists of rows a pair's first tick removes, one per ring slot, and where that tick's events go)
+            const size_t rm_bytes = sizeof(int32_t) * (size_t)(1 + 2 * rows);
+            for (int k = 0; k <= Side::kMasks; ++k) {
+                if (sd->rm[k]) (void)hipFree(sd->rm[k]);
+                sd->rm[k] = nullptr;
+                if (hipMalloc((void **)&sd->rm[k], rm_bytes) != hipSuccess || hipMemsetAsync(sd->rm[k], 0, rm_bytes, s) != hipSuccess)
+                    return fail(ctx, ZRK_E_HIP, "zrk_run_ticks: the removed-row lists could not be allocated");
+            }
+            sd->rm_cap = (int)(2 * rows);
+            if (sd->scratch_ev) (void)hipFree(sd->scratch_ev);
+            sd->scratch_ev = nullptr;
+            if (hipMalloc((void **)&sd->scratch_ev, sizeof(int32_t) * (size_t)(2 * rows + 16)) != hipSuccess)
+                return fail(ctx, ZRK_E_HIP, "zrk_run_ticks: the scratch event list could not be allocated");
+            sd->scratch_ev_rows = rows;
             sd->code_rows = rows;
         }
         if (sd->seq > 0x7FFF0000u) {                     // far from wrapping: the comparison is on 32 bits
@@ -3877,6 +4184,22 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         M.t2 = (double)(st->time_ms + st->dt_ms) / 1000.0;
         const int mb = nblocks(M.m, ZRK_BLOCK);
         if (nt == 2 && mb > 0) { sd->bar_epoch += (uint32_t)mb; M.bar = sd->bar; M.bar_target = sd->bar_epoch; }
+        // the two compactions of the pair as ONE launch, where the table allows it (k_compact_pair)
+        bool pc = nt == 2 && ctx->pair_compact && st->n <= (int64_t)kPairItems * kCompBlock * kFusedMaxBlocks;
+        if (pc && det_idx && sd->scratch_det_ints < (int64_t)R * det_stride) {
+            if (sd->scratch_det) (void)hipFree(sd->scratch_det);
+            sd->scratch_det = nullptr; sd->scratch_det_ints = 0;
+            if (hipMalloc((void **)&sd->scratch_det, sizeof(int32_t) * (size_t)std::max<int64_t>(1, (int64_t)R * det_stride)) != hipSuccess) { (void)hipGetLastError(); pc = false; }
+            else sd->scratch_det_ints = (int64_t)R * det_stride;
+        }
+        if (pc && !sd->scratch_cnt && hipMalloc((void **)&sd->scratch_cnt, sizeof(int32_t) * 64) != hipSuccess) { (void)hipGetLastError(); pc = false; }
+        if (pc && packed && sd->scratch_packed_words < packed_capacity) {
+            if (sd->scratch_packed) (void)hipFree(sd->scratch_packed);
+            sd->scratch_packed = nullptr; sd->scratch_packed_words = 0;
+            if (hipMalloc((void **)&sd->scratch_packed, sizeof(int64_t) * (size_t)packed_capacity) != hipSuccess) { (void)hipGetLastError(); pc = false; }
+            else sd->scratch_packed_words = packed_capacity;
+        }
+        if (pc && fused) { M.rm = sd->rm[slot_t[1]]; M.rm_cap = sd->rm_cap; }
         const int nbs = nblocks(st->n, ZRK_BLOCK);
         const bool ordering = ctx->order_enabled && R > 0 && nbs > 8 * ctx->cus;
         Workspace w = carve(workspace, 0, e->capacity);
@@ -3925,8 +4248,40 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         }
         const bool last_launch = k + nt == K;
         if (last_launch && ctx->tail_by_event && hipEventRecord(sd->last_sweep, s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipEventRecord");
-        // the side stream's work: one compaction per tick, in tick order, released when the NEXT launch starts
-        for (int j = 0; j < nt && rc == 0; ++j) {
+        // the side stream's work, released when the NEXT launch starts: both ticks' compactions in one launch ...
+        if (pc && rc == 0) {
+            SideItem a, b;
+            std::memset((void *)&a, 0, sizeof(a));
+            std::memset((void *)&b, 0, sizeof(b));
+            const int items = std::min(kPairItems, fused_items(ctx, st->n));
+            rc = launch_compact(ctx, vis_t[0], st->n, R, st->base_index, workspace, det_idx ? sd->scratch_det : nullptr, det_stride,
+                                det_idx ? sd->scratch_cnt : nullptr, packed ? sd->scratch_packed : nullptr, packed_capacity, st->gid0, stream,
+                                no_missiles(), vis_t[0], (st->flags & ZRK_F_UNION_BITS) != 0, nullptr, nullptr, &a, items);
+            if (rc == 0)
+                rc = launch_compact(ctx, vis_t[1], st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, packed, packed_capacity,
+                                    st->gid0, stream, no_missiles(), (slot_t[1] < Side::kMasks) ? vis_t[1] : nullptr,
+                                    (st->flags & ZRK_F_UNION_BITS) != 0, nullptr, nullptr, &b, items);
+            if (rc == 0) {
+                a.pair = 1; a.C2 = b.C;
+                int lanes = 1;
+                while (lanes < 2 * (R + 1)) lanes <<= 1;
+                a.C.lanes = lanes;
+                a.stream = side_stream; a.flag_value = ++sd->seq; a.done_slot = slot_t[0]; a.done_slot2 = slot_t[1];
+                a.M = M; a.M.apply = 0; a.M.clear_vis = nullptr;
+                if (fused) {                               // the first tick's ordered events: a list of the context's own
+                    a.M.ev_missile = sd->scratch_ev; a.M.ev_target = sd->scratch_ev + sd->scratch_ev_rows;
+                    a.M.ev_count = sd->scratch_ev + 2 * sd->scratch_ev_rows;
+                }
+                a.M2 = M; a.M2.apply = 0; a.M2.ev_code = M.ev_code2; a.M2.clear_vis = nullptr;
+                a.rm = fused ? sd->rm[slot_t[1]] : nullptr; a.rm_cap = sd->rm_cap;
+                if (last_launch && ctx->tail_by_event) a.wait_event = sd->last_sweep;
+                rc = side_enqueue(ctx, sd, a);
+                side_last = slot_t[1];
+                if (slot_t[1] == Side::kMasks) ctx->ring_clean[st->vis_cur] = false;
+            }
+        }
+        // ... or one compaction per tick, in tick order
+        for (int j = 0; j < nt && rc == 0 && !pc; ++j) {
             SideItem it;
             std::memset((void *)&it, 0, sizeof(it));
             rc = launch_compact(ctx, vis_t[j], st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, packed, packed_capacity,
