@@ -1716,7 +1716,10 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
         const int64_t off = (int64_t)rm[1 + q] - blk0;
 #pragma unroll
         for (int it = 0; it < kPairItems; ++it)
-            if (off == (int64_t)it * THREADS + tid) mk[1][it] = 0u;
+            if (off == (int64_t)it * THREADS + tid) {
+                mk[1][it] = 0u;
+                const_cast<uint32_t *>(C1.vis)[blk0 + off] = 0u;     // (the call's last tick: the caller reads this buffer)
+            }
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
