@@ -292,11 +292,12 @@ typedef struct {
  * stores are scattered when the table is spatially sorted, so the zeros are not worth writing) into the
  * buffer the previous tick's compaction cleared; st->vis_cur says which buffer is current afterwards.
  * From the second tick on the two buffers belong to this loop, also between calls: do not write them.
- * If sweep_ms != NULL the sweep kernel of every prof_stride-th tick is timed with a pair of HIP events riding on its dispatch, the stream is synchronised at the
- * end and sweep_ms[k / prof_stride] receives the kernel's duration in milliseconds (prof_stride < 0: the events are
- * only recorded, zrk_read_sweep_ms reads them later).
+ * If sweep_ms != NULL the sweep launch that holds the LAST tick of every window of prof_stride ticks (and the call's last
+ * tick) is timed with a pair of HIP events riding on its dispatch, the stream is synchronised at the end and
+ * sweep_ms[k / prof_stride] receives the kernel's duration in milliseconds (prof_stride < 0: the events are only
+ * recorded, zrk_read_sweep_ms reads them later; zrk_read_sweep_ticks says how many ticks each timed launch swept).
  *
- * Calls of four ticks or more on a table of 4e5 rows or more, with compaction, a second mask buffer and a missile table
+ * Calls of four ticks or more on a table of 5e4 rows or more, with compaction, a second mask buffer and a missile table
  * the single-workgroup finisher covers, run OVERLAPPED: the lists and the ordered event list of tick t are compacted on
  * a side stream of the context beside the sweep of tick t + 1 (launched by a thread of the context's own when the
  * compute stream says, through a word of pinned host memory, that sweep t + 1 has started), and `stream` carries one
@@ -306,6 +307,16 @@ typedef struct {
  * a caller can see: the masks of all ticks but the LAST of such a call live in buffers of the context
  * (ents->vis_mask / vis_mask_alt hold the last tick's, as st->vis_cur says), likewise mis->ev_code; the dispatch order
  * of a sweep's workgroups is never the same twice (it does not enter any result).
+ *   One scenario without an exchange goes one step further: a sweep launch covers TWO consecutive ticks (a tick's
+ * positions never depend on the tick before -- Trajectory.get_pos recomputes them, modules/AirObject.py:23-25 -- so the
+ * trajectory columns are read once for both; the second tick's positions go to the other position buffer, its masks to
+ * a buffer of their own), and one launch on the side stream compacts both ticks' lists (the first tick's into buffers
+ * of the context: a call's intermediate lists are overwritten by the next tick's wherever they are written).  What the
+ * first tick's missile phase removes is swept once more by the row threads, which cannot know, and put right afterwards;
+ * a missile that needs, in the second tick, the position a row held after the first (a target removed by that tick, a
+ * target behind the missile in the list) replays that row's radar phase.  Same results, tested against the two-launch
+ * loop and the oracle (tests/test_gpu_overlap.py).  ZRK_PAIR=0: one tick per launch; ZRK_PAIR_COMPACT=0: two compaction
+ * launches per pair.
  * Environment (read at zrk_ctx_create / zrk_ctx_reload_env): ZRK_OVERLAP=0 never overlap; ZRK_OVERLAP_MIN=k from k
  * ticks per call; ZRK_OVERLAP_MIN_ROWS=n from n rows; ZRK_GATHER_RECORDS=0 the missile phase reads its targets from the
  * columns instead of the 64-byte records the loop keeps per row (64 B x capacity of device memory, the context's);

@@ -2709,7 +2709,7 @@ struct zrk_ctx {
     Side *side = nullptr;              // overlap mode, created on first use
     int overlap = 1;                   // ZRK_OVERLAP: 0 never, 1 (default) for calls of at least overlap_min ticks
     int overlap_min = 4;
-    int64_t overlap_min_rows = 400000; // ZRK_OVERLAP_MIN_ROWS: below, the compaction is too short for the third launch to pay
+    int64_t overlap_min_rows = 50000;  // ZRK_OVERLAP_MIN_ROWS: below, the side stream's machinery costs more than it hides
     int last_overlapped = 0;           // whether the last zrk_run_ticks* call ran overlapped
     // gather records of the table's rows for the missile phase (MissileArgs::grec), kept like the box records: for
     // this table (its start_pos column), up to this many rows; rebuilt when the key changes, when rows were rewritten
@@ -2809,7 +2809,7 @@ ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
     { const char *v = std::getenv("ZRK_TIME_BY_RECORDS"); c->time_on_dispatch = !(v && v[0] == '1'); }
     { const char *v = std::getenv("ZRK_OVERLAP"); c->overlap = v ? std::atoi(v) : 1; }
     { const char *v = std::getenv("ZRK_OVERLAP_MIN"); c->overlap_min = v ? std::max(2, std::atoi(v)) : 4; }
-    { const char *v = std::getenv("ZRK_OVERLAP_MIN_ROWS"); c->overlap_min_rows = v ? std::atoll(v) : 400000; }
+    { const char *v = std::getenv("ZRK_OVERLAP_MIN_ROWS"); c->overlap_min_rows = v ? std::atoll(v) : 50000; }
     { const char *v = std::getenv("ZRK_GATHER_RECORDS"); c->grec_enabled = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_TAIL_EVENT"); c->tail_by_event = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_PAIR"); c->pair_enabled = !(v && v[0] == '0'); }
@@ -4188,7 +4188,9 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         const int mb = nblocks(M.m, ZRK_BLOCK);
         if (nt == 2 && mb > 0) { sd->bar_epoch += (uint32_t)mb; M.bar = sd->bar; M.bar_target = sd->bar_epoch; }
         // the two compactions of the pair as ONE launch, where the table allows it (k_compact_pair)
-        bool pc = nt == 2 && ctx->pair_compact && st->n <= (int64_t)kPairItems * kCompBlock * kFusedMaxBlocks;
+        // (up to 512 workgroups: beyond, beside a sweep of that size, two launches of half as many fatter workgroups are faster
+        // -- 89 against 94 us per tick at 4e6 rows)
+        bool pc = nt == 2 && ctx->pair_compact && st->n <= (int64_t)kPairItems * kCompBlock * (kFusedMaxBlocks / 2);
         if (pc && det_idx && sd->scratch_det_ints < (int64_t)R * det_stride) {
             if (sd->scratch_det) (void)hipFree(sd->scratch_det);
             sd->scratch_det = nullptr; sd->scratch_det_ints = 0;
@@ -4241,14 +4243,11 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         // the radars move on by the ticks swept, and the next launch's records are derived while this one runs
         std::memcpy(radars, radars_b, sizeof(zrk_radar) * (size_t)R);
         if (nt == 2) zrk_scan_advance(radars, scan, R);
-        if (k + nt < K) {
-            radar_block_ahead(ctx, radars, R, st->flags, 0);
-            if (k + nt + 1 < K) {
-                std::memcpy(radars_b, radars, sizeof(zrk_radar) * (size_t)R);
-                zrk_scan_advance(radars_b, scan, R);
-                radar_block_ahead(ctx, radars_b, R, st->flags, 1);
-            }
-        }
+        // (also behind the call's last launch: the next call's first launch, from an idle device, then finds them ready)
+        radar_block_ahead(ctx, radars, R, st->flags, 0);
+        std::memcpy(radars_b, radars, sizeof(zrk_radar) * (size_t)R);
+        zrk_scan_advance(radars_b, scan, R);
+        radar_block_ahead(ctx, radars_b, R, st->flags, 1);
         const bool last_launch = k + nt == K;
         if (last_launch && ctx->tail_by_event && hipEventRecord(sd->last_sweep, s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipEventRecord");
         // the side stream's work, released when the NEXT launch starts: both ticks' compactions in one launch ...
