@@ -2621,6 +2621,10 @@ struct SideItem {
     const int64_t *post_send;
     int64_t *post_recv;
     int64_t post_words;
+    // (a pair's second tick: its collective behind the same compaction launch)
+    int post2_slot;
+    const int64_t *post2_send;
+    int64_t *post2_recv;
 };
 
 struct Side {
@@ -3759,6 +3763,11 @@ int side_issue(Side *sd, const SideItem &it)
         sd->err = std::string("side stream: ") + it.post_x->err;
         return ZRK_E_HIP;
     }
+    if (it.post_x && it.post2_send &&
+        exchange_post_behind_flag(it.post_x, it.post2_slot, it.post2_send, it.post2_recv, it.post_words, it.raise_value) != 0) {
+        sd->err = std::string("side stream: ") + it.post_x->err;
+        return ZRK_E_HIP;
+    }
     return 0;
 }
 
@@ -4141,7 +4150,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     // ---- the overlapped loop with TWO TICKS PER LAUNCH (SweepParams::t2) ---------------------------------------------------
     // One scenario, no exchange: launch L sweeps ticks t and t + 1 in one pass over the table, the side stream compacts both
     // ticks' lists (two launches, in order) beside launch L + 1.  An odd tick at the end of a call is a launch of one.
-    const bool pairing = sd && !ens && !xio && ctx->pair_enabled && K >= 2 && (m == 0 || m <= 1024 * (int64_t)kMissileItems);
+    const bool pairing = sd && !ens && ctx->pair_enabled && K >= 2 && (m == 0 || m <= 1024 * (int64_t)kMissileItems);
     ctx->last_ticks_per_launch = pairing ? 2 : 1;
     for (int k = 0; pairing && k < K && rc == 0;) {
         const int nt = (k + 1 < K) ? 2 : 1;
@@ -4159,6 +4168,11 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         MissileArgs M = fused ? missile_args(e, cur_a, mis, m, st->time_ms, st->dt_ms, 0) : no_missiles();
         M.pos_abs[0] = e->pos[0]; M.pos_abs[1] = e->pos[1];
         if (fused) M.grec = grec;
+        // an exchange: every tick's list goes to its own send buffer (slot tick % ZRK_EXCHANGE_SLOTS), the events behind it
+        const int xslot[2] = {(int)(st->tick % (uint64_t)ZRK_EXCHANGE_SLOTS), (int)((st->tick + 1) % (uint64_t)ZRK_EXCHANGE_SLOTS)};
+        int64_t *list_t[2] = {xio ? xio->send[xslot[0]] : packed, xio ? xio->send[xslot[1]] : packed};
+        const int64_t list_words = xio ? xio->words - ev_words : packed_capacity;
+        if (fused && ev_words) { M.ev_wire_cap = xio->ev_capacity; M.gid0 = st->gid0; }
         // masks: every tick but the call's last writes into one of the loop's own buffers, the last one where the caller reads
         uint32_t *vis_t[2] = {nullptr, nullptr};
         int slot_t[2] = {Side::kMasks, Side::kMasks};
@@ -4198,7 +4212,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             else sd->scratch_det_ints = (int64_t)R * det_stride;
         }
         if (pc && !sd->scratch_cnt && hipMalloc((void **)&sd->scratch_cnt, sizeof(int32_t) * 64) != hipSuccess) { (void)hipGetLastError(); pc = false; }
-        if (pc && packed && sd->scratch_packed_words < packed_capacity) {
+        if (pc && packed && !xio && sd->scratch_packed_words < packed_capacity) {
             if (sd->scratch_packed) (void)hipFree(sd->scratch_packed);
             sd->scratch_packed = nullptr; sd->scratch_packed_words = 0;
             if (hipMalloc((void **)&sd->scratch_packed, sizeof(int64_t) * (size_t)packed_capacity) != hipSuccess) { (void)hipGetLastError(); pc = false; }
@@ -4256,13 +4270,19 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             std::memset((void *)&a, 0, sizeof(a));
             std::memset((void *)&b, 0, sizeof(b));
             const int items = std::min(kPairItems, fused_items(ctx, st->n));
-            rc = launch_compact(ctx, vis_t[0], st->n, R, st->base_index, workspace, det_idx ? sd->scratch_det : nullptr, det_stride,
-                                det_idx ? sd->scratch_cnt : nullptr, packed ? sd->scratch_packed : nullptr, packed_capacity, st->gid0, stream,
-                                no_missiles(), vis_t[0], (st->flags & ZRK_F_UNION_BITS) != 0, nullptr, nullptr, &a, items);
+            // (the lists' send buffers were last sent ZRK_EXCHANGE_SLOTS ticks ago: those collectives must be through)
+            for (int j = 0; j < 2 && rc == 0 && xio; ++j)
+                if (int rcw = zrk_exchange_wait(xio->x, xslot[j], stream)) rc = fail(ctx, rcw, zrk_exchange_last_error(xio->x));
             if (rc == 0)
-                rc = launch_compact(ctx, vis_t[1], st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, packed, packed_capacity,
+                rc = launch_compact(ctx, vis_t[0], st->n, R, st->base_index, workspace, det_idx ? sd->scratch_det : nullptr, det_stride,
+                                    det_idx ? sd->scratch_cnt : nullptr, xio ? list_t[0] : (packed ? sd->scratch_packed : nullptr), list_words,
+                                    st->gid0, stream, no_missiles(), vis_t[0], (st->flags & ZRK_F_UNION_BITS) != 0, nullptr, nullptr, &a, items);
+            if (rc == 0)
+                rc = launch_compact(ctx, vis_t[1], st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, list_t[1], list_words,
                                     st->gid0, stream, no_missiles(), (slot_t[1] < Side::kMasks) ? vis_t[1] : nullptr,
                                     (st->flags & ZRK_F_UNION_BITS) != 0, nullptr, nullptr, &b, items);
+            for (int j = 0; j < 2 && rc == 0 && ev_words && !fused; ++j)     // (no missiles: an empty event list behind each list)
+                if (hipMemsetAsync(list_t[j] + list_words, 0, sizeof(int64_t), s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "memset events");
             if (rc == 0) {
                 a.pair = 1; a.C2 = b.C;
                 int lanes = 1;
@@ -4275,9 +4295,36 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                     a.M.ev_count = sd->scratch_ev + 2 * sd->scratch_ev_rows;
                 }
                 a.M2 = M; a.M2.apply = 0; a.M2.ev_code = M.ev_code2; a.M2.clear_vis = nullptr;
+                if (fused && ev_words) { a.M.ev_wire = list_t[0] + list_words; a.M2.ev_wire = list_t[1] + list_words; }
                 a.rm = fused ? sd->rm[slot_t[1]] : nullptr; a.rm_cap = sd->rm_cap;
                 if (last_launch && ctx->tail_by_event) a.wait_event = sd->last_sweep;
+                uint32_t v_first = 0;
+                if (xio) {
+                    // both collectives hang behind the one compaction launch: a launch behind it raises the exchange's word
+                    zrk_exchange *x = xio->x;
+                    v_first = ++x->seq;
+                    a.raise = x->flag; a.raise_value = ++x->seq;
+                    if (x->one_helper) {
+                        a.post_x = x; a.post_words = xio->words;
+                        a.post_slot = xslot[0]; a.post_send = list_t[0]; a.post_recv = xio->recv[xslot[0]];
+                        a.post2_slot = xslot[1]; a.post2_send = list_t[1]; a.post2_recv = xio->recv[xslot[1]];
+                    }
+                }
                 rc = side_enqueue(ctx, sd, a);
+                if (rc == 0 && xio) {
+                    zrk_exchange *x = xio->x;
+                    if (x->one_helper) { x->via_side = sd; x->side_item_no[xslot[0]] = x->side_item_no[xslot[1]] = sd->head.load(); }
+                    else {
+                        for (int j = 0; j < 2 && rc == 0; ++j) {
+                            const uint32_t v = j ? a.raise_value : v_first;
+                            if (x->poster.joinable()) {
+                                if (int rce = exchange_enqueue(x, zrk_exchange::PostItem{xslot[j], list_t[j], xio->recv[xslot[j]], xio->words, v}))
+                                    rc = fail(ctx, rce, zrk_exchange_last_error(x));
+                            } else if (exchange_post_behind_flag(x, xslot[j], list_t[j], xio->recv[xslot[j]], xio->words, v) != 0)
+                                rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(x));
+                        }
+                    }
+                }
                 side_last = slot_t[1];
                 if (slot_t[1] == Side::kMasks) ctx->ring_clean[st->vis_cur] = false;
             }
@@ -4286,16 +4333,36 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         for (int j = 0; j < nt && rc == 0 && !pc; ++j) {
             SideItem it;
             std::memset((void *)&it, 0, sizeof(it));
-            rc = launch_compact(ctx, vis_t[j], st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, packed, packed_capacity,
+            if (xio) { if (int rcw = zrk_exchange_wait(xio->x, xslot[j], stream)) { rc = fail(ctx, rcw, zrk_exchange_last_error(xio->x)); break; } }
+            rc = launch_compact(ctx, vis_t[j], st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, list_t[j], list_words,
                                 st->gid0, stream, no_missiles(), (slot_t[j] < Side::kMasks) ? vis_t[j] : nullptr,
                                 (st->flags & ZRK_F_UNION_BITS) != 0, nullptr, nullptr, &it);
             if (rc != 0) break;
+            if (ev_words && !fused && hipMemsetAsync(list_t[j] + list_words, 0, sizeof(int64_t), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset events"); break; }
             it.stream = side_stream; it.flag_value = ++sd->seq; it.done_slot = slot_t[j];
             it.M = M; it.M.apply = 0;
             if (fused && j == 1) it.M.ev_code = M.ev_code2;
+            if (fused && ev_words) it.M.ev_wire = list_t[j] + list_words;
             it.M.clear_vis = (fused && nt == 2 && j == 0) ? vis_t[1] : nullptr;
             if (last_launch && ctx->tail_by_event) it.wait_event = sd->last_sweep;
+            if (xio) {
+                zrk_exchange *x = xio->x;
+                it.raise = x->flag; it.raise_value = ++x->seq;
+                if (x->one_helper) {
+                    it.post_x = x; it.post_words = xio->words;
+                    it.post_slot = xslot[j]; it.post_send = list_t[j]; it.post_recv = xio->recv[xslot[j]];
+                }
+            }
             rc = side_enqueue(ctx, sd, it);
+            if (rc == 0 && xio) {
+                zrk_exchange *x = xio->x;
+                if (x->one_helper) { x->via_side = sd; x->side_item_no[xslot[j]] = sd->head.load(); }
+                else if (x->poster.joinable()) {
+                    if (int rce = exchange_enqueue(x, zrk_exchange::PostItem{xslot[j], list_t[j], xio->recv[xslot[j]], xio->words, it.raise_value}))
+                        rc = fail(ctx, rce, zrk_exchange_last_error(x));
+                } else if (exchange_post_behind_flag(x, xslot[j], list_t[j], xio->recv[xslot[j]], xio->words, it.raise_value) != 0)
+                    rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(x));
+            }
             side_last = slot_t[j];
             if (slot_t[j] == Side::kMasks) ctx->ring_clean[st->vis_cur] = false;
         }
