@@ -2650,6 +2650,7 @@ struct Side {
     bool masks_dirty = false;       // a call failed half-way: clear them before the next use
     uint64_t mask_pos = 0;
     hipEvent_t done[kMasks + 1] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t done_of[kMasks + 1] = {nullptr};   // the event that says a slot's compaction is over (a pair item records ONE for its two)
     hipEvent_t last_sweep = nullptr;   // recorded behind the last sweep of a call (SideItem::wait_event)
     uint32_t *bar = nullptr;           // DEVICE: the barrier of a pair launch's missile workgroups (arrivals, gave-up word)
     uint32_t bar_epoch = 0;            // arrivals asked for so far
@@ -3753,11 +3754,9 @@ int side_issue(Side *sd, const SideItem &it)
     if (it.raise) hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, it.stream, it.raise, it.raise_value);
     if (hipGetLastError() != hipSuccess) { sd->err = "side stream: compaction launch failed"; return ZRK_E_HIP; }
     if (hipEventRecord(sd->done[it.done_slot], it.stream) != hipSuccess) { sd->err = "side stream: hipEventRecord failed"; return ZRK_E_HIP; }
+    sd->done_of[it.done_slot] = sd->done[it.done_slot];
     sd->posted[it.done_slot] = true;
-    if (it.pair) {
-        if (hipEventRecord(sd->done[it.done_slot2], it.stream) != hipSuccess) { sd->err = "side stream: hipEventRecord failed"; return ZRK_E_HIP; }
-        sd->posted[it.done_slot2] = true;
-    }
+    if (it.pair) { sd->done_of[it.done_slot2] = sd->done[it.done_slot]; sd->posted[it.done_slot2] = true; }
     g_trace.mark("side: compaction issued");
     if (it.post_x && exchange_post_behind_flag(it.post_x, it.post_slot, it.post_send, it.post_recv, it.post_words, it.raise_value) != 0) {
         sd->err = std::string("side stream: ") + it.post_x->err;
@@ -3812,6 +3811,15 @@ Side *side_of(zrk_ctx *ctx)
             const uint32_t words = (uint32_t)((std::max(ctx->cus, first + n) + 31) / 32);
             made = hipExtStreamCreateWithCUMask(&sd->stream, words, mask) == hipSuccess;
             if (made) sd->cu_count = n; else (void)hipGetLastError();
+        }
+    }
+    if (!made) {
+        // ZRK_SIDE_PRIORITY=high|low: the side stream's place among the device's queues
+        if (const char *v = std::getenv("ZRK_SIDE_PRIORITY")) {
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
+                made = hipStreamCreateWithPriority(&sd->stream, hipStreamNonBlocking, v[0] == 'h' ? hi : lo) == hipSuccess;
+            if (!made) (void)hipGetLastError();
         }
     }
     bool ok = (made || hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking) == hipSuccess) &&
@@ -3877,7 +3885,7 @@ int side_wait(zrk_ctx *ctx, Side *sd, int slot, hipStream_t compute)
     if (int rc = side_drain(ctx, sd, sd->item_no[slot])) return rc;
     if (!sd->posted[slot]) return 0;
     hipError_t q = hipErrorNotReady;
-    if (!spin_until([&] { q = hipEventQuery(sd->done[slot]); return q != hipErrorNotReady; }))
+    if (!spin_until([&] { q = hipEventQuery(sd->done_of[slot]); return q != hipErrorNotReady; }))
         return fail(ctx, ZRK_E_STATE, "side stream: a compaction launched ticks ago is not through within the host wait limit (ZRK_HOST_WAIT_MS)");
     return q == hipSuccess ? 0 : fail(ctx, ZRK_E_HIP, "side stream: hipEventQuery failed");
 }
@@ -4577,7 +4585,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (xio) xio->x->via_side = nullptr;                 // (everything it carried has been issued, or has failed with it)
         if (rc != 0) { sd->masks_dirty = true; sd->pend_rows = 0; }  // (marks: allocated and cleared anew)
         if (rc == 0 && side_last >= 0 && sd->posted[side_last]) {
-            if (hipStreamWaitEvent(s, sd->done[side_last], 0) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipStreamWaitEvent");
+            if (hipStreamWaitEvent(s, sd->done_of[side_last], 0) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipStreamWaitEvent");
             else { sd->joined_upto = sd->head.load(); sd->joined_stream = s; }
         }
     }
