@@ -257,6 +257,55 @@ int zrk_ccp_link(zrk_ctx *ctx, const double *det_pos /* DEVICE [D][3] */, const 
                  void *scratch /* DEVICE, zrk_ccp_scratch_bytes(D, T) */, void *stream);
 int64_t zrk_ccp_scratch_bytes(int64_t D, int64_t T);
 
+/*
+ * The command post's detection loop of one tick on the device: replaces the body of CombatControlPoint.step,
+ * modules/CCP.py:406-429 -- for every detection, in FoundObjectsMessage order, link_object (:171-219), then new_target /
+ * old_target / old_rocket (:322-366) with try_to_launch_missile (:287-320) -- with the result of that sequential loop.
+ * Nothing is read back: the detections are rows of the entity table (`seq`, each row once: the reference skips ids it has
+ * processed in the tick, :414; their number in DEVICE memory), positions come from the table (obj.pos = pos[cur],
+ * obj.prev_pos = pos[cur ^ 1], None where start_time == now), the dictionaries live in device arrays.
+ *   Tracks: target tracks [0, counts[0]) and missile tracks [0, counts[1]) in the dictionaries' insertion order.  A track is
+ * keyed by the row whose id created it (`*_key`, fixed: add_target on an existing key replaces the entry in place, :88-93)
+ * and holds the row it last matched (`*_obj`: TargetCCP.target / MissileCCP.missile, the live handle whose prev_pos
+ * link_object reads); key_tt[row] = the target track keyed by that row, or -1.
+ *   Launchers in dictionary order (at most 64): try_to_launch_missile takes the nearest one with launched < capacity.
+ *   Output per detection d (= seq[d]): verdict 0 new / 1 old target / 2 old missile, the matched track's index within its
+ * array (-1), the launcher the request goes to (-1); count[0] = detections, count[1] = launch requests; status 0 ok,
+ * 1 the order-dependent part did not settle in `rounds` rounds (2-3 in practice; nothing was applied wrongly -- call again
+ * is not supported: give it more), 2 a target track's handle has no prev_pos (the reference raises there), 3 track
+ * capacity exhausted.  The order-dependent part is resolved in rounds that end themselves on a device flag.
+ */
+typedef struct {
+    int64_t capacity;               /* tracks that fit each array */
+    int32_t *tt_key, *tt_obj;       /* DEVICE [capacity] */
+    double *tt_upd;                 /* DEVICE [capacity]  TargetCCP.upd_time [s] */
+    uint8_t *tt_follow;             /* DEVICE [capacity]  TargetCCP.following */
+    int32_t *tm_key, *tm_obj;       /* DEVICE [capacity] */
+    double *tm_upd;                 /* DEVICE [capacity] */
+    int32_t *counts;                /* DEVICE [2]: target tracks, missile tracks */
+    int32_t *key_tt;                /* DEVICE [ents->capacity] */
+} zrk_ccp_tracks;
+typedef struct {
+    int32_t L, _pad;
+    const double *pos;              /* DEVICE [L][3]  missile_launcher_coords */
+    const int32_t *capacity;        /* DEVICE [L]     missile_launcher_capacity */
+    int32_t *launched;              /* DEVICE [L]     missile_launcher_launched, in/out */
+} zrk_ccp_launchers;
+typedef struct {
+    int32_t *obj, *verdict, *match, *launcher;   /* DEVICE [dmax] */
+    int32_t *count;                 /* DEVICE [2] */
+    int32_t *status;                /* DEVICE [1] */
+} zrk_ccp_out;
+int zrk_ccp_step(zrk_ctx *ctx, const zrk_entities *ents, int cur, const double *speed_mod /* DEVICE [cap]: obj.speed_mod */,
+                 const int32_t *seq /* DEVICE [dmax] */, const int32_t *seq_count /* DEVICE [1] */, int64_t dmax,
+                 const zrk_ccp_tracks *tracks /* HOST */, const zrk_ccp_launchers *launchers /* HOST */,
+                 const zrk_ccp_out *out /* HOST */, double now_s, double slack_s, int rounds,
+                 void *scratch /* DEVICE, zrk_ccp_step_scratch_bytes(dmax, tracks->capacity) */, void *stream);
+int64_t zrk_ccp_step_scratch_bytes(int64_t dmax, int64_t track_capacity);
+/* check_if_missiles_launched -> add_missile (modules/CCP.py:160-169, :102-108): the missile in table row `row` enters the
+ * missile dictionary (or replaces the entry of its key), updated "now". */
+int zrk_ccp_add_missile(zrk_ctx *ctx, const zrk_ccp_tracks *tracks /* HOST */, int32_t row, double now_s, void *stream);
+
 /* Static scan parameters of one radar (modules/Radar.py:13-42): what
  * move_to_next_sector_circular reads besides the current angles. */
 typedef struct {

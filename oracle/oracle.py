@@ -155,6 +155,49 @@ def ccp_link(det_pos, det_speed, trk_ref, trk_upd, now_s, slack_s):
     return match[:D]
 
 
+class CcpState:
+    """The command post's dictionaries as arrays (zo_ccp_step): target tracks and missile tracks in dict order."""
+
+    def __init__(self, cap, launcher_pos, capacity):
+        self.cap = int(cap)
+        self.tt_key = np.full(self.cap, -1, np.int32); self.tt_obj = np.full(self.cap, -1, np.int32)
+        self.tt_upd = np.zeros(self.cap); self.tt_follow = np.zeros(self.cap, np.uint8)
+        self.tm_key = np.full(self.cap, -1, np.int32); self.tm_obj = np.full(self.cap, -1, np.int32); self.tm_upd = np.zeros(self.cap)
+        self.n_tt = np.zeros(1, np.int64); self.n_tm = np.zeros(1, np.int64)
+        self.key_tt = np.full(self.cap, -1, np.int32)
+        self.l_pos = np.ascontiguousarray(launcher_pos, np.float64).reshape(-1, 3)
+        self.l_cap = np.ascontiguousarray(capacity, np.int32)
+        self.l_launched = np.zeros(len(self.l_cap), np.int32)
+
+    def add_missile(self, row, now_s):
+        i64p = C.POINTER(C.c_int64)
+        lib().zo_ccp_add_missile(C.c_int32(int(row)), C.c_double(float(now_s)), i32ptr(self.tm_key), i32ptr(self.tm_obj), dptr(self.tm_upd),
+                                 self.n_tm.ctypes.data_as(i64p))
+
+    def step(self, seq, pos, prev, prev_none, speed, now_s, slack_s):
+        """seq: rows in FoundObjectsMessage order (duplicates allowed); pos / prev (cap, 3).  Returns (rows, verdicts, matched
+        track index, launcher index) of the processed detections, in order."""
+        i64p = C.POINTER(C.c_int64)
+        seq = np.ascontiguousarray(seq, np.int32)
+        D = len(seq)
+        P = np.ascontiguousarray(np.asarray(pos, np.float64).T).reshape(-1)
+        Q = np.ascontiguousarray(np.asarray(prev, np.float64).T).reshape(-1)
+        none = np.ascontiguousarray(prev_none, np.uint8); speed = np.ascontiguousarray(speed, np.float64)
+        out = [np.zeros(max(D, 1), np.int32) for _ in range(4)]
+        scratch = np.zeros(self.cap, np.uint8)
+        L = lib()
+        L.zo_ccp_step.restype = C.c_int64
+        n = L.zo_ccp_step(C.c_int64(D), i32ptr(seq if D else np.zeros(1, np.int32)), C.c_int64(self.cap), dptr(P), dptr(Q), u8ptr(none),
+                          dptr(speed), C.c_double(now_s), C.c_double(slack_s), i32ptr(self.tt_key), i32ptr(self.tt_obj), dptr(self.tt_upd),
+                          u8ptr(self.tt_follow), self.n_tt.ctypes.data_as(i64p), i32ptr(self.tm_key), i32ptr(self.tm_obj),
+                          dptr(self.tm_upd), self.n_tm.ctypes.data_as(i64p), i32ptr(self.key_tt), C.c_int64(len(self.l_cap)),
+                          dptr(self.l_pos.reshape(-1)), i32ptr(self.l_cap), i32ptr(self.l_launched), u8ptr(scratch),
+                          i32ptr(out[0]), i32ptr(out[1]), i32ptr(out[2]), i32ptr(out[3]))
+        if n < 0:
+            raise RuntimeError(f"the reference would raise at sequence element {-1 - n}: a target track whose handle has prev_pos None")
+        return tuple(o[:n].copy() for o in out)
+
+
 def philox_noise(seed, tick, ordinal, entity):
     """Noise triple of the `ordinal`-th detection of `entity` in `tick` (throughput mode)."""
     out = np.zeros(3)

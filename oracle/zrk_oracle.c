@@ -476,3 +476,107 @@ ZO_API void zo_ccp_link(int64_t D, const double *det_pos, const double *det_spee
         if (m >= 0) upd_scratch[m] = now_s;
     }
 }
+
+/* ------------------------------------------------------------------------- *
+ * One tick of the command post's detection loop, literally:
+ * CombatControlPoint.step (modules/CCP.py:406-429) over the FoundObjectsMessage
+ * sequence -- skip ids already processed in this tick (:414), link_object
+ * (:171-219), then new_target / old_target / old_rocket (:322-366) with
+ * try_to_launch_missile (:287-320) -- on arrays.
+ *
+ * Objects are rows of a table (pos = obj.pos as the command post sees it, prev =
+ * obj.prev_pos, prev_none[i] != 0 where the reference holds None, speed =
+ * obj.speed_mod).  Tracks live in two arrays in dict order: target tracks
+ * [0, *n_tt) and missile tracks [0, *n_tm); a track is keyed by the row whose id
+ * created it (tt_key / tm_key, never changes: add_target on an existing key
+ * replaces the entry IN PLACE, dict order kept, :92) and holds the row it last
+ * matched (tt_obj: TargetCCP.target, the live handle whose prev_pos link_object
+ * reads).  key_tt[row] = target track keyed by that row or -1.
+ * Launchers in dict order: position, capacity, launched (in/out).
+ *
+ * Per processed detection (in order) out_obj / out_verdict (0 new, 1 old target,
+ * 2 old missile) / out_match (track index within its array, -1) / out_launcher
+ * (launcher index the request went to, -1).  Returns their number, or -1 - d if the
+ * reference would have raised at sequence element d (a target track whose
+ * handle has prev_pos None: `None - array`, :197).
+ * The launcher distance is (np.sum(diff ** 2)) ** 0.5 (:297): pow(.., 0.5).
+ * ------------------------------------------------------------------------- */
+ZO_API int64_t zo_ccp_step(int64_t D, const int32_t *seq, int64_t cap, const double *pos, const double *prev,
+                           const uint8_t *prev_none, const double *speed, double now_s, double slack_s,
+                           int32_t *tt_key, int32_t *tt_obj, double *tt_upd, uint8_t *tt_follow, int64_t *n_tt,
+                           const int32_t *tm_key, int32_t *tm_obj, double *tm_upd, int64_t *n_tm, int32_t *key_tt,
+                           int64_t L, const double *l_pos, const int32_t *l_capacity, int32_t *l_launched,
+                           uint8_t *processed /* [cap] scratch, zeroed here */,
+                           int32_t *out_obj, int32_t *out_verdict, int32_t *out_match, int32_t *out_launcher)
+{
+    int64_t n_out = 0;
+    memset(processed, 0, (size_t)cap);
+    for (int64_t d = 0; d < D; ++d) {
+        int32_t o = seq[d];
+        if (processed[o]) continue;                               /* :414 */
+        processed[o] = 1;
+        double px = pos[o], py = pos[cap + o], pz = pos[2 * cap + o], v = speed[o];
+        double best = INFINITY;
+        int verdict = 0;
+        int64_t m = -1;
+        for (int64_t t = 0; t < *n_tt; ++t) {                     /* :193-204 */
+            if (tt_upd[t] == now_s) continue;
+            int32_t h = tt_obj[t];
+            if (prev_none[h]) return -1 - d;                      /* target.prev_pos is None: the reference raises */
+            double dist = zo_norm3(prev[h] - px, prev[cap + h] - py, prev[2 * cap + h] - pz);
+            double age = now_s - tt_upd[t];
+            double lo = v * (age - slack_s), hi = v * (age + slack_s);
+            if (!(lo > 0.0)) lo = 0.0;
+            if (!(hi > 0.0)) hi = 0.0;
+            if (dist < best && lo <= dist && dist <= hi) { best = dist; verdict = 1; m = t; }
+        }
+        for (int64_t t = 0; t < *n_tm; ++t) {                     /* :207-218 */
+            if (tm_upd[t] == now_s) continue;
+            int32_t h = tm_obj[t];
+            const double *ref = prev_none[h] ? pos : prev;        /* :211-213 */
+            double dist = zo_norm3(ref[h] - px, ref[cap + h] - py, ref[2 * cap + h] - pz);
+            double age = now_s - tm_upd[t];
+            double lo = v * (age - slack_s), hi = v * (age + slack_s);
+            if (!(lo > 0.0)) lo = 0.0;
+            if (!(hi > 0.0)) hi = 0.0;
+            if (dist < best && lo <= dist && dist <= hi) { best = dist; verdict = 2; m = t; }
+        }
+        int launcher = -1;
+        int wants = verdict == 0 || (verdict == 1 && !tt_follow[m]);   /* :330, :342-343 */
+        if (wants) {                                              /* try_to_launch_missile, :291-299 */
+            double mind = INFINITY;
+            for (int64_t l = 0; l < L; ++l) {
+                if (l_launched[l] < l_capacity[l]) {
+                    double ax = l_pos[3 * l] - px, ay = l_pos[3 * l + 1] - py, az = l_pos[3 * l + 2] - pz;
+                    double dist = pow((ax * ax + ay * ay) + az * az, 0.5);
+                    if (dist < mind) { mind = dist; launcher = (int)l; }
+                }
+            }
+            if (launcher >= 0) l_launched[launcher] += 1;
+        }
+        if (verdict == 0) {                                       /* new_target -> add_target, :322-332, :88-93 */
+            int64_t t = key_tt[o];
+            if (t < 0) { t = (*n_tt)++; tt_key[t] = o; key_tt[o] = (int32_t)t; }
+            tt_obj[t] = o; tt_upd[t] = now_s; tt_follow[t] = launcher >= 0;
+        } else if (verdict == 1) {                                /* old_target, :334-361 */
+            if (!tt_follow[m]) tt_follow[m] = launcher >= 0;
+            tt_obj[m] = o; tt_upd[m] = now_s;
+        } else {                                                  /* old_rocket, :363-366 (the dict key, tm_key[m], stays) */
+            (void)tm_key;
+            tm_obj[m] = o; tm_upd[m] = now_s;
+        }
+        out_obj[n_out] = o; out_verdict[n_out] = verdict; out_match[n_out] = (int32_t)m; out_launcher[n_out] = launcher;
+        ++n_out;
+    }
+    return n_out;
+}
+
+/* check_if_missiles_launched -> add_missile (modules/CCP.py:160-169, :102-108): a missile of our own enters the
+ * missile dict (keyed by its row; an existing key is replaced in place), updated "now". */
+ZO_API void zo_ccp_add_missile(int32_t row, double now_s, int32_t *tm_key, int32_t *tm_obj, double *tm_upd, int64_t *n_tm)
+{
+    int64_t t = -1;
+    for (int64_t k = 0; k < *n_tm; ++k) if (tm_key[k] == row) t = k;
+    if (t < 0) { t = (*n_tm)++; tm_key[t] = row; }
+    tm_obj[t] = row; tm_upd[t] = now_s;
+}

@@ -1,0 +1,131 @@
+"""zrk_ccp_step -- the command post's detection loop of one tick on the device -- against the
+oracle's literal loop (oracle/zrk_oracle.c::zo_ccp_step, itself pinned on the reference's own decisions:
+tests/test_oracle_golden.py, tests/golden/ccp_step.npz), and on that fixture directly."""
+import ctypes as C
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx():
+    from zrk_modulation_amd._lib import Context
+    return Context(0)
+
+
+class Table:
+    """A bare entity table on the device: only what zrk_ccp_step reads (positions of this tick and the one before,
+    start_time -- prev_pos is None where it equals `now` --, speed_mod)."""
+
+    def __init__(self, cap):
+        from zrk_modulation_amd import _lib
+        self.cap = cap
+        self.pos = [torch.zeros(3, cap, dtype=torch.float64, device="cuda:0") for _ in range(2)]
+        self.t0 = torch.full((cap,), -1.0, dtype=torch.float64, device="cuda:0")
+        self.speed = torch.zeros(cap, dtype=torch.float64, device="cuda:0")
+        e = self.ents = _lib.ZrkEntities()
+        e.capacity = cap
+        e.start_time = self.t0.data_ptr()
+        e.pos[0], e.pos[1] = self.pos[0].data_ptr(), self.pos[1].data_ptr()
+
+    def set_tick(self, pos, prev, prev_none, speed, now_s):
+        self.pos[0].copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(pos).T)))
+        self.pos[1].copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(prev).T)))
+        self.t0.copy_(torch.from_numpy(np.where(prev_none, now_s, -1.0)))
+        self.speed.copy_(torch.from_numpy(np.ascontiguousarray(speed, np.float64)))
+
+
+def _first_occurrences(seq):
+    _, first = np.unique(seq, return_index=True)
+    return np.asarray(seq)[np.sort(first)].astype(np.int32)
+
+
+def test_device_command_post_reproduces_the_reference_fixture():
+    """The 36 ticks the reference's CombatControlPoint decided (ccp_step.npz): the device, fed the same air picture, names
+    the same verdict, the same matched key and the same launcher for every processed detection, tick after tick (its
+    dictionaries carry over on the device)."""
+    from zrk_modulation_amd.association import DeviceCommandPost
+    fx = np.load(Path(__file__).parent / "golden" / "ccp_step.npz")
+    meta = json.loads(str(fx["meta"]))
+    N = len(fx["obj_id"])
+    tab = Table(N)
+    post = DeviceCommandPost(_ctx(), "cuda:0", N, N, meta["launcher_pos"], np.zeros(len(meta["capacity"]), np.int32), dmax=N)
+    dt = meta["dt_ms"] / 1000
+    slack = meta["slack_steps"] * dt
+    launches = 0
+    for k in range(len(fx["seq_off"]) - 1):
+        now = k * meta["dt_ms"] / 1000
+        if k == 1:
+            post.l_cap.copy_(torch.tensor(meta["capacity"], dtype=torch.int32))
+        for mi, _ in fx["new_missile"][fx["new_missile_off"][k]:fx["new_missile_off"][k + 1]]:
+            post.add_missile(int(mi), now)
+        tab.set_tick(fx["pos"][k], fx["prev"][k], fx["prev_none"][k], fx["speed"], now)
+        seq = _first_occurrences(fx["seq_obj"][fx["seq_off"][k]:fx["seq_off"][k + 1]])      # (the reference skips processed ids, :414)
+        d_seq = torch.from_numpy(seq).cuda()
+        d_cnt = torch.tensor([len(seq)], dtype=torch.int32, device="cuda:0")
+        post.step(tab.ents, 0, tab.speed, d_seq, d_cnt, now, slack)
+        rows, verdict, match, launcher = post.results()
+        a, b = fx["out_off"][k], fx["out_off"][k + 1]
+        assert np.array_equal(rows, fx["out_obj"][a:b]) and np.array_equal(verdict, fx["out_verdict"][a:b]), f"tick {k}: verdicts differ"
+        tt_key, tm_key = post.tt_key.cpu().numpy(), post.tm_key.cpu().numpy()
+        key = np.where(verdict == 1, tt_key[np.maximum(match, 0)], np.where(verdict == 2, tm_key[np.maximum(match, 0)], -1))
+        assert np.array_equal(key, fx["out_match"][a:b]), f"tick {k}: matched keys differ"
+        lid = np.array([meta["launcher_ids"][l] if l >= 0 else -1 for l in launcher])
+        assert np.array_equal(lid, fx["out_launcher"][a:b]), f"tick {k}: launchers differ"
+        launches += int((launcher >= 0).sum())
+    assert launches == sum(meta["capacity"])
+
+
+@pytest.mark.parametrize("seed,n,D,L,cap_per,ticks", [(1, 3000, 1200, 3, 40, 6), (2, 100_000, 10_000, 5, 700, 3), (3, 500, 500, 1, 3, 6)])
+def test_device_command_post_equals_the_oracle_over_ticks(seed, n, D, L, cap_per, ticks):
+    """Random air pictures over several ticks (the dictionaries carry over, new targets keep appearing, tracks are matched,
+    lost and found again under another key, launchers run dry in detection order): the device against the oracle's literal
+    loop.  The largest case: 10 000 detections a tick against 100 000 tracks."""
+    from oracle import oracle as O
+    from zrk_modulation_amd.association import DeviceCommandPost
+    g = np.random.Generator(np.random.PCG64(seed))
+    p0 = g.uniform(-6e4, 6e4, (n, 3)) * [1, 1, 0.1]
+    vel = g.normal(0, 250, (n, 3)) * [1, 1, 0.2]
+    speed = np.linalg.norm(vel, axis=1)
+    lpos = g.uniform(-2e4, 2e4, (L, 3)) * [1, 1, 0]
+    caps = np.full(L, cap_per, np.int32)
+    tab = Table(n)
+    post = DeviceCommandPost(_ctx(), "cuda:0", n, n, lpos, caps, dmax=n)
+    ora = O.CcpState(n, lpos, caps)
+    dt, slack_steps = 0.5, 4
+    # the first tick sees everything (the dictionaries fill up), the later ones a random subset, some of it moved so far
+    # that its old track is out of gate (a new target whose id is a key already: replaced in place)
+    pos = p0.copy()
+    total = np.zeros(3, np.int64)
+    launches = 0
+    for k in range(ticks):
+        now = k * dt
+        prev = pos.copy()
+        pos = p0 + vel * now + g.normal(0, 5, (n, 3))
+        if k >= 2:
+            jump = g.choice(n, max(1, n // 50), replace=False)
+            pos[jump] += g.normal(0, 3000, (len(jump), 3))
+        none = np.zeros(n, bool) if k else np.ones(n, bool)
+        seq = (np.arange(n) if k == 0 else g.permutation(n)[:D]).astype(np.int32)
+        tab.set_tick(pos, prev, none, speed, now)
+        post.step(tab.ents, 0, tab.speed, torch.from_numpy(seq).cuda(), torch.tensor([len(seq)], dtype=torch.int32, device="cuda:0"), now,
+                  slack_steps * dt)
+        got = post.results()
+        want = ora.step(seq, pos, prev, none, speed, now, slack_steps * dt)
+        for name, a, b in zip(("rows", "verdicts", "matches", "launchers"), got, want):
+            assert np.array_equal(a, b), f"tick {k}: {name} differ in {int((a != b).sum())} of {len(a)} places"
+        for v in range(3):
+            total[v] += int((want[1] == v).sum())
+        launches += int((want[3] >= 0).sum())
+        # the dictionaries themselves
+        ntt = int(ora.n_tt[0])
+        assert post.counts.cpu().tolist() == [ntt, int(ora.n_tm[0])]
+        for name in ("tt_key", "tt_obj", "tt_follow"):
+            assert np.array_equal(getattr(post, name)[:ntt].cpu().numpy(), getattr(ora, name)[:ntt]), f"tick {k}: {name}"
+        assert np.array_equal(post.tt_upd[:ntt].cpu().numpy(), ora.tt_upd[:ntt])
+        assert np.array_equal(post.l_launched.cpu().numpy(), ora.l_launched)
+    assert total[0] >= n and total[1] > D // 2 and launches == min(L * cap_per, int(total[0] + total[1]))

@@ -111,3 +111,41 @@ def test_multithreaded_airenv_step_equals_the_literal_loop():
                     S["alive"][ts] = 0
         total += len(out[0])
     assert total > 100
+
+
+def test_oracle_command_post_step_equals_the_reference():
+    """oracle/zrk_oracle.c::zo_ccp_step is CombatControlPoint.step's detection loop (modules/CCP.py:406-429: link_object,
+    new_target / old_target / old_rocket, try_to_launch_missile): pinned against the decisions of the reference's own
+    class, recorded over 36 ticks of a tight swarm with two radars, three launchers and missiles entering the air
+    (tests/golden/gen_ccp_golden.py -> ccp_step.npz): every processed detection's verdict, matched key and launcher."""
+    import json
+    from pathlib import Path
+    fx = np.load(Path(__file__).parent / "golden" / "ccp_step.npz")
+    meta = json.loads(str(fx["meta"]))
+    N = len(fx["obj_id"])
+    st = O.CcpState(N, meta["launcher_pos"], np.zeros(len(meta["capacity"]), np.int32))
+    dt = meta["dt_ms"] / 1000
+    slack = meta["slack_steps"] * dt
+    ticks = len(fx["seq_off"]) - 1
+    seen = np.zeros(3, np.int64)
+    launches = 0
+    for k in range(ticks):
+        now = k * meta["dt_ms"] / 1000
+        if k == 1:                                   # MissileCountResponse arrives in tick 1
+            st.l_cap[:] = meta["capacity"]
+        for mi, _tgt in fx["new_missile"][fx["new_missile_off"][k]:fx["new_missile_off"][k + 1]]:
+            st.add_missile(int(mi), now)
+        seq = fx["seq_obj"][fx["seq_off"][k]:fx["seq_off"][k + 1]]
+        rows, verdict, match, launcher = st.step(seq, fx["pos"][k], fx["prev"][k], fx["prev_none"][k], fx["speed"], now, slack)
+        a, b = fx["out_off"][k], fx["out_off"][k + 1]
+        assert np.array_equal(rows, fx["out_obj"][a:b]), f"tick {k}: processed objects differ"
+        assert np.array_equal(verdict, fx["out_verdict"][a:b]), f"tick {k}: verdicts differ"
+        # the reference names the matched dict KEY, the oracle the track: compare through the key arrays
+        key = np.where(verdict == 1, st.tt_key[np.maximum(match, 0)], np.where(verdict == 2, st.tm_key[np.maximum(match, 0)], -1))
+        assert np.array_equal(key, fx["out_match"][a:b]), f"tick {k}: matched keys differ"
+        lid = np.array([meta["launcher_ids"][l] if l >= 0 else -1 for l in launcher])
+        assert np.array_equal(lid, fx["out_launcher"][a:b]), f"tick {k}: launchers differ"
+        for v in range(3):
+            seen[v] += int((verdict == v).sum())
+        launches += int((launcher >= 0).sum())
+    assert seen.min() > 100 and launches == sum(meta["capacity"])

@@ -26,6 +26,21 @@ class HotPathUnavailable(RuntimeError):
     pass
 
 
+class ZrkCcpTracks(C.Structure):
+    _fields_ = [("capacity", C.c_int64), ("tt_key", C.c_void_p), ("tt_obj", C.c_void_p), ("tt_upd", C.c_void_p),
+                ("tt_follow", C.c_void_p), ("tm_key", C.c_void_p), ("tm_obj", C.c_void_p), ("tm_upd", C.c_void_p),
+                ("counts", C.c_void_p), ("key_tt", C.c_void_p)]
+
+
+class ZrkCcpLaunchers(C.Structure):
+    _fields_ = [("L", C.c_int32), ("_pad", C.c_int32), ("pos", C.c_void_p), ("capacity", C.c_void_p), ("launched", C.c_void_p)]
+
+
+class ZrkCcpOut(C.Structure):
+    _fields_ = [("obj", C.c_void_p), ("verdict", C.c_void_p), ("match", C.c_void_p), ("launcher", C.c_void_p),
+                ("count", C.c_void_p), ("status", C.c_void_p)]
+
+
 class ZrkEntities(C.Structure):
     _fields_ = [
         ("capacity", C.c_int64),
@@ -212,6 +227,10 @@ _PROTOTYPES = {
     "zrk_selftest_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64, C.c_void_p,
                                      C.c_int64, C.c_void_p]),
     "zrk_selftest_host_wait": (C.c_int, [C.c_int, C.c_int]),
+    "zrk_ccp_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+    "zrk_ccp_step_scratch_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
+    "zrk_ccp_add_missile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
     "zrk_read_sweep_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "zrk_last_run_ticks_per_launch": (C.c_int, [C.c_void_p]),
 }

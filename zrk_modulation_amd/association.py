@@ -38,3 +38,67 @@ def link_all(ctx, device, det_pos, det_speed, trk_ref, trk_upd, now_s, slack_s):
     ctx.check(ctx.lib.zrk_ccp_link(ctx.handle, d_pos.data_ptr(), d_speed.data_ptr(), D, d_ref.data_ptr(), d_upd.data_ptr(), T,
                                    float(now_s), float(slack_s), match.data_ptr(), scratch.data_ptr(), stream), "zrk_ccp_link")
     return match.cpu().numpy()
+
+
+class DeviceCommandPost:
+    """The command post's dictionaries and one tick of its detection loop on the device (include/zrk_hot.h: zrk_ccp_step):
+    what CombatControlPoint.step does per detection -- link_object, new_target / old_target / old_rocket,
+    try_to_launch_missile (reference modules/CCP.py:171-219, :287-366, :406-429) -- for all detections of a tick, with the
+    result of the reference's sequential loop and without a read-back.  Tracks and launchers live in device arrays; the
+    detections are rows of the entity table."""
+
+    def __init__(self, ctx, device, rows_capacity, track_capacity, launcher_pos, launcher_capacity, dmax, rounds=12):
+        self.ctx, self.dev = ctx, torch.device(device)
+        dev = self.dev
+        i32, f64, u8 = torch.int32, torch.float64, torch.uint8
+        self.tcap, self.dmax, self.rounds = int(track_capacity), int(dmax), int(rounds)
+        z = lambda n, dt, fill=0: torch.full((max(int(n), 1),), fill, dtype=dt, device=dev)     # noqa: E731
+        self.tt_key, self.tt_obj, self.tt_upd, self.tt_follow = z(self.tcap, i32, -1), z(self.tcap, i32, -1), z(self.tcap, f64), z(self.tcap, u8)
+        self.tm_key, self.tm_obj, self.tm_upd = z(self.tcap, i32, -1), z(self.tcap, i32, -1), z(self.tcap, f64)
+        self.counts = z(2, i32)
+        self.key_tt = z(rows_capacity, i32, -1)
+        lp = np.ascontiguousarray(launcher_pos, np.float64).reshape(-1, 3)
+        self.L = len(lp)
+        self.l_pos = torch.from_numpy(lp).to(dev) if self.L else z(3, f64)
+        self.l_cap = torch.from_numpy(np.ascontiguousarray(launcher_capacity, np.int32)).to(dev) if self.L else z(1, i32)
+        self.l_launched = z(self.L, i32)
+        self.o_obj, self.o_verdict, self.o_match, self.o_launcher = (z(self.dmax, i32, -1) for _ in range(4))
+        self.o_count, self.o_status = z(2, i32), z(1, i32)
+        self.scratch = torch.zeros(int(ctx.lib.zrk_ccp_step_scratch_bytes(self.dmax, self.tcap)), dtype=u8, device=dev)
+        t = self.tracks = _lib.ZrkCcpTracks()
+        t.capacity = self.tcap
+        t.tt_key, t.tt_obj, t.tt_upd, t.tt_follow = (x.data_ptr() for x in (self.tt_key, self.tt_obj, self.tt_upd, self.tt_follow))
+        t.tm_key, t.tm_obj, t.tm_upd = (x.data_ptr() for x in (self.tm_key, self.tm_obj, self.tm_upd))
+        t.counts, t.key_tt = self.counts.data_ptr(), self.key_tt.data_ptr()
+        l = self.launchers = _lib.ZrkCcpLaunchers()
+        l.L, l.pos, l.capacity, l.launched = self.L, self.l_pos.data_ptr(), self.l_cap.data_ptr(), self.l_launched.data_ptr()
+        o = self.out = _lib.ZrkCcpOut()
+        o.obj, o.verdict, o.match, o.launcher = (x.data_ptr() for x in (self.o_obj, self.o_verdict, self.o_match, self.o_launcher))
+        o.count, o.status = self.o_count.data_ptr(), self.o_status.data_ptr()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def add_missile(self, row, now_s):
+        self.ctx.check(self.ctx.lib.zrk_ccp_add_missile(self.ctx.handle, C.byref(self.tracks), int(row), float(now_s), self._stream()),
+                       "zrk_ccp_add_missile")
+
+    def step(self, ents, cur, speed_mod, seq, seq_count, now_s, slack_s):
+        """ents: a ctypes ZrkEntities; speed_mod: float64 tensor [capacity]; seq: int32 tensor of rows in processing order;
+        seq_count: int32 tensor [1] on the device.  Enqueues the tick; results stay on the device (`results()` reads them)."""
+        self.ctx.check(self.ctx.lib.zrk_ccp_step(self.ctx.handle, C.byref(ents), int(cur), speed_mod.data_ptr(), seq.data_ptr(),
+                                                 seq_count.data_ptr(), min(self.dmax, seq.numel()), C.byref(self.tracks),
+                                                 C.byref(self.launchers), C.byref(self.out), float(now_s), float(slack_s), self.rounds,
+                                                 self.scratch.data_ptr(), self._stream()), "zrk_ccp_step")
+
+    def results(self):
+        """(rows, verdicts, matched track index, launcher index) of the last tick's detections; raises if the device says the
+        tick did not go through (zrk_hot.h: status)."""
+        status = int(self.o_status.item())
+        if status:
+            raise _lib.ZrkError(f"zrk_ccp_step: status {status} ("
+                                + {1: "the order-dependent part did not settle within the round limit",
+                                   2: "a target track's handle has no prev_pos: the reference raises there",
+                                   3: "track capacity exhausted"}.get(status, "?") + ")")
+        n = int(self.o_count[0].item())
+        return tuple(x[:n].cpu().numpy() for x in (self.o_obj, self.o_verdict, self.o_match, self.o_launcher))

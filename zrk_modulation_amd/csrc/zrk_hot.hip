@@ -2369,10 +2369,14 @@ __global__ __launch_bounds__(256) void k_ccp_candidates(const double *__restrict
                                                         int64_t D, const double *__restrict__ trk_ref,
                                                         const double *__restrict__ trk_upd, int64_t T, double now_s,
                                                         double slack_s, const uint8_t *__restrict__ taken,
-                                                        const uint8_t *__restrict__ only, CcpCand *__restrict__ out)
+                                                        const uint8_t *__restrict__ only, CcpCand *__restrict__ out,
+                                                        const int32_t *__restrict__ dev_sizes = nullptr /* {D, T} on the device */,
+                                                        const int32_t *__restrict__ gate = nullptr /* run only if *gate != 0 */)
 {
     __shared__ double s_ref[3][kCcpTile];
     __shared__ double s_upd[kCcpTile];
+    if (gate && *gate == 0) return;
+    if (dev_sizes) { D = D < dev_sizes[0] ? D : dev_sizes[0]; T = dev_sizes[1]; }
     const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool mine = d < D && (!only || only[d]);
     double px = 0.0, py = 0.0, pz = 0.0, sp = 0.0;
@@ -2423,11 +2427,20 @@ __global__ __launch_bounds__(256) void k_ccp_candidates(const double *__restrict
 // that nobody has been given yet and registers, for every such candidate still in its list, the smallest index of an
 // unresolved detection interested in it.  Phase 1: a detection whose named track has nobody earlier interested in it
 // takes it for good -- no earlier detection can ever claim it, and nothing nearer in its own list is free.
+// `kill` (may be NULL): the target track KEYED by the detection's own row, which a NEW_TARGET verdict replaces in place
+// (add_target on an existing key, modules/CCP.py:88-93: updated "now", hence gone for every later detection of the tick) --
+// an unresolved detection is "interested" in that track too, and takes it out when it resolves as new.
+// `dcount` (may be NULL): the number of detections lives on the device (zrk_ccp_step); counters[3] != 0: all resolved,
+// the launch has nothing to do.
 __global__ void k_ccp_round(int phase, int64_t D, const CcpCand *__restrict__ cand, uint8_t *taken, int32_t *interest,
-                            int32_t *match, uint8_t *state /* 0 unresolved, 1 resolved, 2 needs a re-scan */, int32_t *counters)
+                            int32_t *match, uint8_t *state /* 0 unresolved, 1 resolved, 2 needs a re-scan */, int32_t *counters,
+                            const int32_t *__restrict__ kill = nullptr, const int32_t *__restrict__ dcount = nullptr)
 {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dcount && (counters[3] != 0 || d >= *dcount)) return;
     if (d >= D || state[d] == 1) return;
+    const int32_t kx = kill ? kill[d] : -1;
+    if (phase == 0 && kx >= 0 && !taken[kx]) atomicMin(&interest[kx], (int32_t)d);
     if (state[d] == 2) {                         // waiting for its re-scan: still holds everybody behind it
         if (phase == 0) atomicMin(&counters[2], (int32_t)d);
         return;
@@ -2449,7 +2462,7 @@ __global__ void k_ccp_round(int phase, int64_t D, const CcpCand *__restrict__ ca
     if ((int32_t)d > counters[2]) { atomicAdd(&counters[0], 1); return; }
     if (first < 0) {
         if (c.total > c.n) { state[d] = 2; atomicAdd(&counters[1], 1); }      // the kept prefix is used up: look again
-        else { match[d] = -1; state[d] = 1; }                                 // NEW_TARGET
+        else { match[d] = -1; state[d] = 1; if (kx >= 0) taken[kx] = 1; }     // NEW_TARGET (its key's old track is replaced)
         return;
     }
     if (interest[first] == (int32_t)d) { match[d] = first; state[d] = 1; taken[first] = 1; }
@@ -2465,12 +2478,230 @@ __global__ void k_ccp_rescan_prepare(int64_t D, uint8_t *only, uint8_t *state)
     if (again) state[d] = 0;
 }
 
-__global__ void k_ccp_reset_interest(int64_t D, const CcpCand *__restrict__ cand, const uint8_t *__restrict__ state, int32_t *interest)
+__global__ void k_ccp_reset_interest(int64_t D, const CcpCand *__restrict__ cand, const uint8_t *__restrict__ state, int32_t *interest,
+                                     const int32_t *__restrict__ kill = nullptr, const int32_t *__restrict__ dcount = nullptr,
+                                     const int32_t *__restrict__ counters = nullptr)
 {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dcount && (counters[3] != 0 || d >= *dcount)) return;
     if (d >= D || state[d] == 1) return;
     const CcpCand &c = cand[d];
     for (int k = 0; k < c.n; ++k) interest[c.idx[k]] = 0x7FFFFFFF;
+    if (kill && kill[d] >= 0) interest[kill[d]] = 0x7FFFFFFF;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The command post's detection loop of one tick on the device: CombatControlPoint.step,
+// modules/CCP.py:406-429 -- link_object for every detection (:171-219), new_target / old_target / old_rocket (:322-366)
+// with try_to_launch_missile (:287-320) -- with the result of the reference's sequential loop, without a read-back:
+// the detections are rows of the entity table, the tracks live in device arrays in the dictionaries' order, the
+// order-dependent part runs a bounded number of rounds that end themselves on a device flag.
+// ---------------------------------------------------------------------------------------------
+struct CcpStepArgs {
+    const double *pos_cur, *pos_prev, *t0;        // entity table: obj.pos, obj.prev_pos, start_time (prev_pos is None where t0 == now)
+    const double *speed;                          // obj.speed_mod per row
+    int64_t cap;
+    const int32_t *seq, *seq_count;               // rows in processing order (each row once), their number (DEVICE)
+    int64_t dmax;
+    zrk_ccp_tracks trk;
+    zrk_ccp_launchers lch;
+    zrk_ccp_out out;
+    double now_s, slack_s;
+    // scratch
+    double *det_pos, *det_speed, *trk_ref, *trk_upd;
+    int32_t *kill, *sizes /* {D, T, Tt} */, *want, *new_rank, *winner, *counters;
+};
+
+// sizes, per-detection attributes, per-track references (targets then missiles, the order link_object scans them in)
+__global__ void k_ccp_gather(const CcpStepArgs A)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int D = *A.seq_count;
+    D = D < (int)A.dmax ? D : (int)A.dmax;
+    const int Tt = A.trk.counts[0], Tm = A.trk.counts[1];
+    if (g == 0) { A.sizes[0] = D; A.sizes[1] = Tt + Tm; A.sizes[2] = Tt; A.out.count[0] = D; }
+    if (g < D) {
+        const int32_t row = A.seq[g];
+        A.det_pos[3 * g] = A.pos_cur[row]; A.det_pos[3 * g + 1] = A.pos_cur[A.cap + row]; A.det_pos[3 * g + 2] = A.pos_cur[2 * A.cap + row];
+        A.det_speed[g] = A.speed[row];
+        A.kill[g] = A.trk.key_tt[row];
+        A.out.obj[g] = row;
+    }
+    if (g < Tt + Tm) {
+        const bool missile = g >= Tt;
+        const int32_t h = missile ? A.trk.tm_obj[g - Tt] : A.trk.tt_obj[g];
+        const double upd = missile ? A.trk.tm_upd[g - Tt] : A.trk.tt_upd[g];
+        const bool none = A.t0[h] == A.now_s;                        // AirObject.py:41: prev_pos is None in the object's first tick
+        // a missile track falls back to pos (:211-213); for a target track the reference raises (None - array): status 2
+        if (none && !missile && upd != A.now_s) atomicMax(A.out.status, 2);
+        const double *ref = (none && missile) ? A.pos_cur : A.pos_prev;
+        A.trk_ref[3 * g] = ref[h]; A.trk_ref[3 * g + 1] = ref[A.cap + h]; A.trk_ref[3 * g + 2] = ref[2 * A.cap + h];
+        A.trk_upd[g] = upd;
+        A.winner[g] = -1;
+    }
+}
+
+__global__ void k_ccp_round_begin(int32_t *counters)
+{
+    if (counters[3] != 0) return;
+    counters[0] = 0; counters[1] = 0; counters[2] = 0x7FFFFFFF; counters[4] = 0;
+}
+
+// the round is over: everybody resolved -> done; some lists ran out although more was in gate -> the re-scan below runs
+__global__ void k_ccp_round_end(int64_t dmax, const int32_t *__restrict__ sizes, uint8_t *only, uint8_t *state, int32_t *counters)
+{
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (counters[3] != 0) return;
+    const bool rescan = counters[1] > 0;
+    if (d < dmax && d < sizes[0]) {
+        const bool again = rescan && state[d] == 2;
+        only[d] = again ? 1 : 0;
+        if (again) state[d] = 0;
+    }
+}
+
+__global__ void k_ccp_round_flags(int32_t *counters)
+{
+    if (counters[3] != 0) return;
+    if (counters[0] == 0 && counters[1] == 0) counters[3] = 1;
+    counters[4] = counters[1] > 0 ? 1 : 0;
+}
+
+// One workgroup: which detections ask for a missile (new targets, old targets nobody follows yet: :330, :342-343), in
+// order; the rank of every new target without a track of its key among such (the slot its new track takes).
+__global__ __launch_bounds__(1024) void k_ccp_scan(const CcpStepArgs A, const int32_t *__restrict__ match)
+{
+    __shared__ int s_w[16], s_n[16];
+    __shared__ int s_cw, s_cn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = A.sizes[0], Tt = A.sizes[2];
+    if (tid == 0) { s_cw = 0; s_cn = 0; }
+    __syncthreads();
+    for (int base = 0; base < D; base += 1024) {
+        const int d = base + tid;
+        bool want = false, fresh = false;
+        if (d < D) {
+            const int m = match[d];
+            const int verdict = m < 0 ? 0 : (m < Tt ? 1 : 2);
+            A.out.verdict[d] = verdict;
+            A.out.match[d] = m < 0 ? -1 : (m < Tt ? m : m - Tt);
+            A.out.launcher[d] = -1;
+            want = verdict == 0 || (verdict == 1 && !A.trk.tt_follow[m]);
+            fresh = verdict == 0 && A.kill[d] < 0;
+        }
+        const unsigned long long bw = __ballot(want), bn = __ballot(fresh);
+        if (lane == 0) { s_w[wave] = (int)__popcll(bw); s_n[wave] = (int)__popcll(bn); }
+        __syncthreads();
+        int ow = s_cw, on = s_cn, tw = 0, tn = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) { ow += s_w[w]; on += s_n[w]; } tw += s_w[w]; tn += s_n[w]; }
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        if (want) A.want[1 + ow + (int)__popcll(bw & below)] = d;
+        if (d < D) A.new_rank[d] = on + (int)__popcll(bn & below);
+        __syncthreads();
+        if (tid == 0) { s_cw += tw; s_cn += tn; }
+        __syncthreads();
+    }
+    if (tid == 0) { A.want[0] = s_cw; A.sizes[3] = s_cn; }
+}
+
+// try_to_launch_missile for the asking detections, in order (modules/CCP.py:287-320): the nearest launcher that still has
+// a missile, strictly nearer wins, earlier launcher among equals; its count goes up.  One wave, lane l = launcher l: the
+// loop is sequential in the launchers' counts and runs at most as long as there are missiles left.
+// (dist: sqrt of the sum of squares; the reference's `(...) ** 0.5` is pow(x, 0.5), which may differ from sqrt in the last
+// bit -- it only ever decides between two launchers whose distances agree to 1 ulp.)
+__global__ __launch_bounds__(64) void k_ccp_launch(const CcpStepArgs A)
+{
+    const int lane = threadIdx.x, L = A.lch.L;
+    const bool mine = lane < L;
+    const double lx = mine ? A.lch.pos[3 * lane] : 0.0, ly = mine ? A.lch.pos[3 * lane + 1] : 0.0, lz = mine ? A.lch.pos[3 * lane + 2] : 0.0;
+    const int capacity = mine ? A.lch.capacity[lane] : 0;
+    int launched = mine ? A.lch.launched[lane] : 0;
+    const int n = A.want[0];
+    int launches = 0;
+    for (int q = 0; q < n; ++q) {
+        if (!__ballot(mine && launched < capacity)) break;         // nobody has a missile left: every later request fails
+        const int d = A.want[1 + q];
+        const double ax = lx - A.det_pos[3 * d], ay = ly - A.det_pos[3 * d + 1], az = lz - A.det_pos[3 * d + 2];
+        double dist = (mine && launched < capacity) ? sqrt((ax * ax + ay * ay) + az * az) : __builtin_inf();
+        if (dist != dist) dist = __builtin_inf();                  // (NaN never compares less: such a launcher is never chosen)
+        // minimum over the lanes, the lowest lane among equals
+        double best = dist;
+        int who = lane;
+#pragma unroll
+        for (int off = 32; off; off >>= 1) {
+            const double ob = __shfl_xor(best, off);
+            const int ow = __shfl_xor(who, off);
+            if (ob < best || (ob == best && ow < who)) { best = ob; who = ow; }
+        }
+        if (best < __builtin_inf()) {
+            if (lane == who) launched += 1;
+            if (lane == 0) A.out.launcher[d] = who;
+            ++launches;
+        }
+    }
+    if (mine) A.lch.launched[lane] = launched;
+    if (lane == 0) A.out.count[1] = launches;
+}
+
+// The dictionaries after the tick.  Every detection writes one track: the one it matched, the one its key names (a new
+// target whose id is a key already: replaced in place, :88-93), or a new one behind the others in detection order.  Two
+// detections may write the same target track (matched early in the tick, replaced later): the later one stands.
+__global__ void k_ccp_apply(const CcpStepArgs A, int phase)
+{
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int D = A.sizes[0], Tt = A.sizes[2];
+    if (d >= D) return;
+    const int verdict = A.out.verdict[d];
+    const int32_t row = A.out.obj[d];
+    if (verdict == 2) {                                             // old_rocket, :363-366
+        if (phase == 1) { const int t = A.out.match[d]; A.trk.tm_obj[t] = row; A.trk.tm_upd[t] = A.now_s; }
+        return;
+    }
+    const int w = verdict == 1 ? A.out.match[d] : (A.kill[d] >= 0 ? A.kill[d] : Tt + A.new_rank[d]);
+    if (w >= A.trk.capacity) { atomicMax(A.out.status, 3); return; }
+    if (phase == 0) { if (w < Tt) atomicMax(&A.winner[w], (int32_t)d); return; }
+    if (w < Tt && A.winner[w] != (int32_t)d) return;
+    const bool launched = A.out.launcher[d] >= 0;
+    if (verdict == 0) {                                             // new_target -> add_target, :322-332
+        if (w >= Tt) { A.trk.tt_key[w] = row; A.trk.key_tt[row] = w; }
+        A.trk.tt_follow[w] = launched ? 1 : 0;
+    } else if (!A.trk.tt_follow[w]) {                               // old_target, :334-361
+        A.trk.tt_follow[w] = launched ? 1 : 0;
+    }
+    A.trk.tt_obj[w] = row; A.trk.tt_upd[w] = A.now_s;
+}
+
+__global__ void k_ccp_count_new(const CcpStepArgs A)
+{
+    A.trk.counts[0] = A.sizes[2] + A.sizes[3];                      // the new targets' tracks stand behind the old ones
+}
+
+// the rounds are over: not everybody resolved within the bound -> status 1 (the caller gives it more rounds)
+__global__ void k_ccp_finish(const int32_t *counters, int32_t *status)
+{
+    if (counters[3] == 0) atomicMax(status, 1);
+}
+
+// check_if_missiles_launched -> add_missile (modules/CCP.py:160-169, :102-108): a missile of our own enters the missile
+// dictionary, keyed by its row (an existing key is replaced in place), updated "now".
+__global__ void k_ccp_add_missile(const zrk_ccp_tracks trk, int32_t row, double now_s)
+{
+    __shared__ int s_hit;
+    if (threadIdx.x == 0) s_hit = -1;
+    __syncthreads();
+    const int n = trk.counts[1];
+    for (int k = threadIdx.x; k < n; k += blockDim.x) if (trk.tm_key[k] == row) atomicMax(&s_hit, k);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = s_hit;
+        if (t < 0) {
+            t = n;
+            if (t >= trk.capacity) return;
+            trk.tm_key[t] = row; trk.counts[1] = n + 1;
+        }
+        trk.tm_obj[t] = row; trk.tm_upd[t] = now_s;
+    }
 }
 
 __global__ void k_selftest_math(int op, const double *a, const double *b, double *y, int64_t n)
@@ -3327,6 +3558,82 @@ ZRK_API int zrk_ccp_link(zrk_ctx *ctx, const double *det_pos, const double *det_
         }
     }
     return check_launch(ctx, "zrk_ccp_link");
+}
+
+ZRK_API int64_t zrk_ccp_step_scratch_bytes(int64_t dmax, int64_t track_capacity)
+{
+    if (dmax < 0 || track_capacity < 0) return ZRK_E_INVALID;
+    const int64_t T = 2 * track_capacity;
+    return zrk_ccp_scratch_bytes(dmax, T) + align256(24 * dmax) + align256(8 * dmax) + align256(24 * T) + align256(8 * T) +
+           align256(4 * dmax) + 256 + align256(4 * (dmax + 1)) + align256(4 * dmax) + align256(4 * T) + align256(4 * dmax) + 256;
+}
+
+ZRK_API int zrk_ccp_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const double *speed_mod, const int32_t *seq,
+                         const int32_t *seq_count, int64_t dmax, const zrk_ccp_tracks *trk, const zrk_ccp_launchers *lch,
+                         const zrk_ccp_out *out, double now_s, double slack_s, int rounds, void *scratch, void *stream)
+{
+    if (!ctx || !e || !speed_mod || !seq || !seq_count || !trk || !lch || !out || !scratch || (cur != 0 && cur != 1))
+        return fail(ctx, ZRK_E_INVALID, "zrk_ccp_step: null argument");
+    if (dmax < 0 || trk->capacity < 0 || lch->L < 0 || lch->L > 64 || rounds < 1)
+        return fail(ctx, ZRK_E_INVALID, "zrk_ccp_step: size out of range (at most 64 launchers)");
+    if (dmax == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t T = 2 * trk->capacity;
+    // the association's scratch first (as zrk_ccp_link lays it out), then this step's own
+    char *p = (char *)scratch;
+    CcpCand *cand = (CcpCand *)p;            p += align256(dmax * (int64_t)sizeof(CcpCand));
+    uint8_t *taken = (uint8_t *)p;           p += align256(T);
+    int32_t *interest = (int32_t *)p;        p += align256(4 * T);
+    uint8_t *state = (uint8_t *)p;           p += align256(dmax);
+    uint8_t *only = (uint8_t *)p;            p += align256(dmax);
+    int32_t *counters = (int32_t *)p;        p += 256;
+    CcpStepArgs A;
+    A.pos_cur = e->pos[cur]; A.pos_prev = e->pos[cur ^ 1]; A.t0 = e->start_time; A.speed = speed_mod; A.cap = e->capacity;
+    A.seq = seq; A.seq_count = seq_count; A.dmax = dmax; A.trk = *trk; A.lch = *lch; A.out = *out;
+    A.now_s = now_s; A.slack_s = slack_s;
+    A.det_pos = (double *)p;                 p += align256(24 * dmax);
+    A.det_speed = (double *)p;               p += align256(8 * dmax);
+    A.trk_ref = (double *)p;                 p += align256(24 * T);
+    A.trk_upd = (double *)p;                 p += align256(8 * T);
+    A.kill = (int32_t *)p;                   p += align256(4 * dmax);
+    A.sizes = (int32_t *)p;                  p += 256;
+    A.want = (int32_t *)p;                   p += align256(4 * (dmax + 1));
+    A.new_rank = (int32_t *)p;               p += align256(4 * dmax);
+    A.winner = (int32_t *)p;                 p += align256(4 * T);
+    A.counters = counters;
+    int32_t *match = (int32_t *)p;           // (behind everything: zrk_ccp_step_scratch_bytes leaves 4 * dmax + 256 for it)
+    if (hipMemsetAsync(taken, 0, (size_t)align256(T), s) != hipSuccess || hipMemsetAsync(state, 0, (size_t)align256(dmax), s) != hipSuccess ||
+        hipMemsetAsync(interest, 0x7F, (size_t)align256(4 * T), s) != hipSuccess || hipMemsetAsync(counters, 0, 256, s) != hipSuccess ||
+        hipMemsetAsync(out->status, 0, sizeof(int32_t), s) != hipSuccess)
+        return fail(ctx, ZRK_E_HIP, "zrk_ccp_step: memset");
+    const int gd = nblocks(dmax, 256), gt = nblocks(std::max<int64_t>(dmax, T), 256);
+    hipLaunchKernelGGL(k_ccp_gather, dim3(gt), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_ccp_candidates, dim3(gd), dim3(256), 0, s, A.det_pos, A.det_speed, dmax, A.trk_ref, A.trk_upd, T, now_s, slack_s,
+                       (const uint8_t *)nullptr, (const uint8_t *)nullptr, cand, (const int32_t *)A.sizes, (const int32_t *)nullptr);
+    for (int r = 0; r < rounds; ++r) {               // (each launch looks at the `done` word first: the rounds end themselves)
+        hipLaunchKernelGGL(k_ccp_round_begin, dim3(1), dim3(1), 0, s, counters);
+        hipLaunchKernelGGL(k_ccp_round, dim3(gd), dim3(256), 0, s, 0, dmax, cand, taken, interest, match, state, counters, A.kill, A.sizes);
+        hipLaunchKernelGGL(k_ccp_round, dim3(gd), dim3(256), 0, s, 1, dmax, cand, taken, interest, match, state, counters, A.kill, A.sizes);
+        hipLaunchKernelGGL(k_ccp_reset_interest, dim3(gd), dim3(256), 0, s, dmax, cand, state, interest, A.kill, A.sizes, counters);
+        hipLaunchKernelGGL(k_ccp_round_end, dim3(gd), dim3(256), 0, s, dmax, A.sizes, only, state, counters);
+        hipLaunchKernelGGL(k_ccp_round_flags, dim3(1), dim3(1), 0, s, counters);
+        hipLaunchKernelGGL(k_ccp_candidates, dim3(gd), dim3(256), 0, s, A.det_pos, A.det_speed, dmax, A.trk_ref, A.trk_upd, T, now_s, slack_s,
+                           (const uint8_t *)taken, (const uint8_t *)only, cand, (const int32_t *)A.sizes, (const int32_t *)(counters + 4));
+    }
+    hipLaunchKernelGGL(k_ccp_finish, dim3(1), dim3(1), 0, s, counters, out->status);
+    hipLaunchKernelGGL(k_ccp_scan, dim3(1), dim3(1024), 0, s, A, (const int32_t *)match);
+    hipLaunchKernelGGL(k_ccp_launch, dim3(1), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(k_ccp_apply, dim3(gd), dim3(256), 0, s, A, 0);
+    hipLaunchKernelGGL(k_ccp_apply, dim3(gd), dim3(256), 0, s, A, 1);
+    hipLaunchKernelGGL(k_ccp_count_new, dim3(1), dim3(1), 0, s, A);
+    return check_launch(ctx, "zrk_ccp_step");
+}
+
+ZRK_API int zrk_ccp_add_missile(zrk_ctx *ctx, const zrk_ccp_tracks *trk, int32_t row, double now_s, void *stream)
+{
+    if (!ctx || !trk) return fail(ctx, ZRK_E_INVALID, "zrk_ccp_add_missile: null argument");
+    hipLaunchKernelGGL(k_ccp_add_missile, dim3(1), dim3(64), 0, (hipStream_t)stream, *trk, row, now_s);
+    return check_launch(ctx, "k_ccp_add_missile");
 }
 
 // What every bounded host wait of the library does when its condition never comes: `what` 0 the spin helper itself, 1 a
