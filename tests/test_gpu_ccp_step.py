@@ -53,7 +53,9 @@ def test_device_command_post_reproduces_the_reference_fixture():
     meta = json.loads(str(fx["meta"]))
     N = len(fx["obj_id"])
     tab = Table(N)
-    post = DeviceCommandPost(_ctx(), "cuda:0", N, N, meta["launcher_pos"], np.zeros(len(meta["capacity"]), np.int32), dmax=N)
+    # (a tight swarm under the reference's hundred-step gates: every track is in every detection's gate, detections displace
+    # one another down long chains, and each link of a chain costs a round -- the bound is the caller's to choose)
+    post = DeviceCommandPost(_ctx(), "cuda:0", N, N, meta["launcher_pos"], np.zeros(len(meta["capacity"]), np.int32), dmax=N, rounds=1024)
     dt = meta["dt_ms"] / 1000
     slack = meta["slack_steps"] * dt
     launches = 0

@@ -2352,7 +2352,7 @@ __global__ __launch_bounds__(1024) void k_launch_append(const zrk_launch_req *__
 // pairwise part (every detection against every track) is independent per detection and runs LDS-tiled below; the
 // order-dependent part only ever chooses among a detection's few in-gate candidates and is resolved in rounds.
 // ---------------------------------------------------------------------------------------------
-constexpr int kCcpK = 8;                       // in-gate candidates kept per detection (nearest first)
+constexpr int kCcpK = 16;                      // in-gate candidates kept per detection (nearest first)
 constexpr int kCcpTile = 1024;                 // tracks staged in LDS per step
 
 struct CcpCand {
@@ -2442,21 +2442,27 @@ __global__ void k_ccp_round(int phase, int64_t D, const CcpCand *__restrict__ ca
     const int32_t kx = kill ? kill[d] : -1;
     if (phase == 0 && kx >= 0 && !taken[kx]) atomicMin(&interest[kx], (int32_t)d);
     if (state[d] == 2) {                         // waiting for its re-scan: still holds everybody behind it
-        if (phase == 0) atomicMin(&counters[2], (int32_t)d);
+        if (phase == 1) atomicMin(&counters[2], (int32_t)d);
         return;
     }
     const CcpCand &c = cand[d];
     int first = -1;
+    bool safe = false;                           // some free candidate of its list that nobody earlier is interested in
     for (int k = 0; k < c.n; ++k) {
         const int t = c.idx[k];
         if (taken[t]) continue;
         if (first < 0) first = t;
         if (phase == 0) atomicMin(&interest[t], (int32_t)d);
+        else if (interest[t] == (int32_t)d) safe = true;
     }
-    // a detection whose kept list is only a prefix of what is in its gate may yet turn to tracks it has not named:
-    // nobody behind it takes anything for good before it is settled
-    if (phase == 0) {
-        if (c.total > c.n) atomicMin(&counters[2], (int32_t)d);
+    if (phase == 0) return;
+    if (phase == 1) {
+        // A detection whose kept list is only a prefix of what is in its gate may yet turn to tracks it has not named -- but
+        // only if every free candidate it kept can still be taken from it by somebody earlier.  With one that nobody earlier
+        // wants it ends inside its list whatever happens; without, nobody behind it takes anything for good before it is
+        // settled.  (The reference's gates are a hundred steps wide, modules/constants.py:31: in a dense scene EVERY list is a
+        // prefix, and nearly every detection's nearest free track is its own, uncontested.)
+        if (c.total > c.n && !safe) atomicMin(&counters[2], (int32_t)d);
         return;
     }
     if ((int32_t)d > counters[2]) { atomicAdd(&counters[0], 1); return; }
@@ -3541,9 +3547,11 @@ ZRK_API int zrk_ccp_link(zrk_ctx *ctx, const double *det_pos, const double *det_
     for (int round = 0; round < 1000000; ++round) {
         if (hipMemsetAsync(counters, 0, 8, s) != hipSuccess || hipMemsetAsync(counters + 2, 0x7F, 4, s) != hipSuccess)
             return fail(ctx, ZRK_E_HIP, "zrk_ccp_link: memset");
-        hipLaunchKernelGGL(k_ccp_round, dim3(gd), dim3(256), 0, s, 0, D, cand, taken, interest, match, state, counters);
-        hipLaunchKernelGGL(k_ccp_round, dim3(gd), dim3(256), 0, s, 1, D, cand, taken, interest, match, state, counters);
-        hipLaunchKernelGGL(k_ccp_reset_interest, dim3(gd), dim3(256), 0, s, D, cand, state, interest);
+        for (int phase = 0; phase < 3; ++phase)
+            hipLaunchKernelGGL(k_ccp_round, dim3(gd), dim3(256), 0, s, phase, D, cand, taken, interest, match, state, counters,
+                               (const int32_t *)nullptr, (const int32_t *)nullptr);
+        hipLaunchKernelGGL(k_ccp_reset_interest, dim3(gd), dim3(256), 0, s, D, cand, state, interest, (const int32_t *)nullptr,
+                           (const int32_t *)nullptr, (const int32_t *)nullptr);
         int32_t h[2] = {0, 0};
         if (hipMemcpyAsync(h, counters, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
             return fail(ctx, ZRK_E_HIP, "zrk_ccp_link: reading the round's counters");
@@ -3612,8 +3620,9 @@ ZRK_API int zrk_ccp_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const dou
                        (const uint8_t *)nullptr, (const uint8_t *)nullptr, cand, (const int32_t *)A.sizes, (const int32_t *)nullptr);
     for (int r = 0; r < rounds; ++r) {               // (each launch looks at the `done` word first: the rounds end themselves)
         hipLaunchKernelGGL(k_ccp_round_begin, dim3(1), dim3(1), 0, s, counters);
-        hipLaunchKernelGGL(k_ccp_round, dim3(gd), dim3(256), 0, s, 0, dmax, cand, taken, interest, match, state, counters, A.kill, A.sizes);
-        hipLaunchKernelGGL(k_ccp_round, dim3(gd), dim3(256), 0, s, 1, dmax, cand, taken, interest, match, state, counters, A.kill, A.sizes);
+        for (int phase = 0; phase < 3; ++phase)
+            hipLaunchKernelGGL(k_ccp_round, dim3(gd), dim3(256), 0, s, phase, dmax, cand, taken, interest, match, state, counters,
+                               (const int32_t *)A.kill, (const int32_t *)A.sizes);
         hipLaunchKernelGGL(k_ccp_reset_interest, dim3(gd), dim3(256), 0, s, dmax, cand, state, interest, A.kill, A.sizes, counters);
         hipLaunchKernelGGL(k_ccp_round_end, dim3(gd), dim3(256), 0, s, dmax, A.sizes, only, state, counters);
         hipLaunchKernelGGL(k_ccp_round_flags, dim3(1), dim3(1), 0, s, counters);
