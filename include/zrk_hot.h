@@ -284,6 +284,10 @@ typedef struct {
     double *tm_upd;                 /* DEVICE [capacity] */
     int32_t *counts;                /* DEVICE [2]: target tracks, missile tracks */
     int32_t *key_tt;                /* DEVICE [ents->capacity] */
+    /* DEVICE [capacity][3] or NULL: where set (first component not NaN), the position link_object compares with instead of
+     * the handle's row in pos[cur ^ 1].  For tracks whose object has left the air: the reference's handle keeps the
+     * prev_pos of its last step, the table keeps only the object's last position (in both buffers). */
+    const double *tt_ref_fixed, *tm_ref_fixed;
 } zrk_ccp_tracks;
 typedef struct {
     int32_t L, _pad;

@@ -29,7 +29,7 @@ class HotPathUnavailable(RuntimeError):
 class ZrkCcpTracks(C.Structure):
     _fields_ = [("capacity", C.c_int64), ("tt_key", C.c_void_p), ("tt_obj", C.c_void_p), ("tt_upd", C.c_void_p),
                 ("tt_follow", C.c_void_p), ("tm_key", C.c_void_p), ("tm_obj", C.c_void_p), ("tm_upd", C.c_void_p),
-                ("counts", C.c_void_p), ("key_tt", C.c_void_p)]
+                ("counts", C.c_void_p), ("key_tt", C.c_void_p), ("tt_ref_fixed", C.c_void_p), ("tm_ref_fixed", C.c_void_p)]
 
 
 class ZrkCcpLaunchers(C.Structure):

@@ -70,6 +70,10 @@ class DeviceCommandPost:
         t.tt_key, t.tt_obj, t.tt_upd, t.tt_follow = (x.data_ptr() for x in (self.tt_key, self.tt_obj, self.tt_upd, self.tt_follow))
         t.tm_key, t.tm_obj, t.tm_upd = (x.data_ptr() for x in (self.tm_key, self.tm_obj, self.tm_upd))
         t.counts, t.key_tt = self.counts.data_ptr(), self.key_tt.data_ptr()
+        # what link_object compares with for tracks whose object has left the air (NaN: read the table)
+        self.tt_ref_fixed = torch.full((max(self.tcap, 1), 3), float("nan"), dtype=f64, device=dev)
+        self.tm_ref_fixed = torch.full((max(self.tcap, 1), 3), float("nan"), dtype=f64, device=dev)
+        t.tt_ref_fixed, t.tm_ref_fixed = self.tt_ref_fixed.data_ptr(), self.tm_ref_fixed.data_ptr()
         l = self.launchers = _lib.ZrkCcpLaunchers()
         l.L, l.pos, l.capacity, l.launched = self.L, self.l_pos.data_ptr(), self.l_cap.data_ptr(), self.l_launched.data_ptr()
         o = self.out = _lib.ZrkCcpOut()

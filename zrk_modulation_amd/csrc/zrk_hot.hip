@@ -2538,11 +2538,19 @@ __global__ void k_ccp_gather(const CcpStepArgs A)
         const bool missile = g >= Tt;
         const int32_t h = missile ? A.trk.tm_obj[g - Tt] : A.trk.tt_obj[g];
         const double upd = missile ? A.trk.tm_upd[g - Tt] : A.trk.tt_upd[g];
-        const bool none = A.t0[h] == A.now_s;                        // AirObject.py:41: prev_pos is None in the object's first tick
-        // a missile track falls back to pos (:211-213); for a target track the reference raises (None - array): status 2
-        if (none && !missile && upd != A.now_s) atomicMax(A.out.status, 2);
-        const double *ref = (none && missile) ? A.pos_cur : A.pos_prev;
-        A.trk_ref[3 * g] = ref[h]; A.trk_ref[3 * g + 1] = ref[A.cap + h]; A.trk_ref[3 * g + 2] = ref[2 * A.cap + h];
+        // (an object that left the air keeps the prev_pos of its last step in the reference; the table keeps only its last
+        // position, in both buffers -- the caller supplies what the handle held: zrk_ccp_tracks::ref_fixed)
+        const double *fixed = missile ? A.trk.tm_ref_fixed : A.trk.tt_ref_fixed;
+        const int t = missile ? (int)(g - Tt) : (int)g;
+        if (fixed && fixed[3 * t] == fixed[3 * t]) {                 // (not NaN: set)
+            A.trk_ref[3 * g] = fixed[3 * t]; A.trk_ref[3 * g + 1] = fixed[3 * t + 1]; A.trk_ref[3 * g + 2] = fixed[3 * t + 2];
+        } else {
+            const bool none = A.t0[h] == A.now_s;                    // AirObject.py:41: prev_pos is None in the object's first tick
+            // a missile track falls back to pos (:211-213); for a target track the reference raises (None - array): status 2
+            if (none && !missile && upd != A.now_s) atomicMax(A.out.status, 2);
+            const double *ref = (none && missile) ? A.pos_cur : A.pos_prev;
+            A.trk_ref[3 * g] = ref[h]; A.trk_ref[3 * g + 1] = ref[A.cap + h]; A.trk_ref[3 * g + 2] = ref[2 * A.cap + h];
+        }
         A.trk_upd[g] = upd;
         A.winner[g] = -1;
     }

@@ -65,6 +65,9 @@ class CombatControlPoint(BaseModel):
         self.missile_launcher_launched = {}
         self.missile_launcher_capacity = {}
         self.initialized = False
+        self.device_ticks = 0           # ticks whose detection loop ran on the device (zrk_ccp_step)
+        self._post = None               # the dictionaries' mirror on the device (association.DeviceCommandPost), made on first use
+        self._post_stale = True         # the host changed a dictionary behind its back: rebuilt from the dictionaries
 
     # bookkeeping -------------------------------------------------------------------------------
     def add_target(self, target_ccp: TargetCCP):
@@ -72,6 +75,7 @@ class CombatControlPoint(BaseModel):
 
     def delete_target(self, target_id):
         self._target_dict.pop(target_id, None)
+        self._post_stale = True
 
     def add_missile(self, missile_ccp: MissileCCP):
         m = missile_ccp.missile
@@ -82,6 +86,7 @@ class CombatControlPoint(BaseModel):
         if not self_detonation:
             self.delete_target(self._missile_dict[missile_id].missile.target.id)
         self._missile_dict.pop(missile_id, None)
+        self._post_stale = True
 
     def _now_s(self):
         return to_seconds(self._manager.time.get_time())
@@ -106,6 +111,7 @@ class CombatControlPoint(BaseModel):
     def check_if_missiles_launched(self):
         for msg in self._manager.give_messages_by_type(MessageType.LAUNCHED_MISSILE):
             self.add_missile(MissileCCP(msg.missile, self._now_s()))
+            self._post_stale = True       # (event rate: the mirror is rebuilt from the dictionaries)
 
     # track association ---------------------------------------------------------------------------
     def _gate(self, detected, ref_pos, ref_time):
@@ -163,6 +169,13 @@ class CombatControlPoint(BaseModel):
         match = link_all(store.ctx, store.device, np.asarray([o.pos for o in objs], np.float64).reshape(-1, 3),
                          np.asarray([o.speed_mod for o in objs], np.float64),
                          np.asarray(refs, np.float64).reshape(-1, 3), np.asarray(upds, np.float64), now_s, slack)
+        # a NEW_TARGET verdict for an id that is a key already replaces that entry on the spot (add_target, reference :88-93):
+        # the old track is then updated "now" and gone for every LATER detection of the tick, which this batched link does
+        # not know -- if a later detection matched it, the tick goes through the sequential loop
+        index_of_key = {k: i for i, k in enumerate(t_keys)}
+        for d, m in enumerate(match):
+            if m < 0 and objs[d].id in index_of_key and (match[d + 1:] == index_of_key[objs[d].id]).any():
+                return None
         out = []
         for m in match:
             if m < 0:
@@ -172,6 +185,124 @@ class CombatControlPoint(BaseModel):
             else:
                 out.append((OLD_ROCKET, m_keys[m - len(t_keys)]))
         return out
+
+    # the detection loop on the device -------------------------------------------------------------
+    def _device_tick(self, found_msgs, dets):
+        """CombatControlPoint.step's detection loop for this tick on the device (zrk_ccp_step: link_object, the launcher
+        choice and the dictionaries' updates with the sequential loop's result); the host then only walks the verdicts to
+        keep its own dictionaries (they hold the handles the messages carry) and to send the messages.  Returns False when
+        the tick has to go through the host loop instead (objects that are not rows of one device table)."""
+        import os
+        import torch
+        from ..association import DeviceCommandPost
+        if os.environ.get("ZRK_CCP_HOST") or not dets:
+            return False
+        store = getattr(found_msgs[0], "device_store", None)
+        if store is None or any(getattr(m, "device_store", None) is not store for m in found_msgs):
+            return False
+        if any(getattr(o, "_store", None) is not store or o._frozen is not None for o, _ in dets):
+            return False
+        now_s = self._now_s()
+        ml_ids = list(self.missile_launcher_coords)
+        if len(ml_ids) > 64:
+            return False
+        # the detections of the tick in processing order, each row once (:414), from the radars' device lists
+        seq_all = torch.cat([m.device_rows for m in found_msgs]).to(torch.int64)
+        pos_in_seq = torch.arange(seq_all.numel(), device=seq_all.device)
+        first = torch.full((store.cap,), seq_all.numel(), dtype=torch.int64, device=seq_all.device)
+        first.scatter_reduce_(0, seq_all, pos_in_seq, "amin")
+        seq = seq_all[first[seq_all] == pos_in_seq].to(torch.int32).contiguous()
+        if seq.numel() != len(dets):
+            return False
+        cnt = torch.tensor([seq.numel()], dtype=torch.int32, device=seq.device)
+        # the mirror of the dictionaries: made, or rebuilt when the host changed them (missiles entering, deletions)
+        cap = max(2 * store.cap, 64)
+        if self._post is None or self._post.dev != store.device or self._post.key_tt.numel() < store.cap or self._post.tcap < cap:
+            self._post = DeviceCommandPost(store.ctx, store.device, store.cap, cap, list(self.missile_launcher_coords.values()),
+                                           [0] * len(ml_ids), dmax=store.cap)
+            self._post_speed = np.zeros(store.cap)
+            self._post_stale = True
+        post = self._post
+        for o, _ in dets:
+            self._post_speed[o._slot] = o.speed_mod
+        if self._post_stale and not self._mirror_dictionaries(post, store, now_s):
+            return False
+        if ml_ids:
+            post.l_cap.copy_(torch.tensor([self.missile_launcher_capacity[k] for k in ml_ids], dtype=torch.int32))
+            post.l_launched.copy_(torch.tensor([self.missile_launcher_launched[k] for k in ml_ids], dtype=torch.int32))
+        speed = torch.from_numpy(self._post_speed).to(store.device)
+        slack = POSSIBLE_TARGET_RADIUS * to_seconds(self._manager.time.get_dt())
+        post.step(store.ents, store.cur, speed, seq, cnt, now_s, slack)
+        try:
+            rows, verdict, match, launcher = post.results()
+        except Exception:
+            self._post_stale = True          # (nothing applied on the host: the host loop takes the tick)
+            return False
+        t_keys, m_keys = list(self._target_dict), list(self._missile_dict)
+        for d, (obj, radar_id) in enumerate(dets):
+            assert int(rows[d]) == obj._slot
+            launched = launcher[d] >= 0
+            if launched:
+                ml = ml_ids[int(launcher[d])]
+                self.missile_launcher_launched[ml] += 1
+                self._manager.add_message(CPPLaunchMissileRequestMessage(
+                    time=self._manager.time.get_time(), sender_id=self.id, receiver_id=ml, target=obj, target_position=obj.pos,
+                    radar_id=radar_id))
+            if verdict[d] == 0:
+                self.add_target(TargetCCP(obj, now_s, bool(launched)))
+            elif verdict[d] == 1:
+                track = self._target_dict[t_keys[int(match[d])]]
+                if not track.following:
+                    track.upd_target_ccp(obj, now_s, bool(launched))
+                else:
+                    track.upd_target_ccp(obj, now_s, track.following)
+                    self.send_update_msg_to_radar(obj, track.missile_id, radar_id)
+            else:
+                self._missile_dict[m_keys[int(match[d])]].upd_missile_ccp(obj, now_s)
+        self.device_ticks += 1
+        return True
+
+    def _mirror_dictionaries(self, post, store, now_s):
+        """The dictionaries as the device arrays of zrk_ccp_step, in dictionary order.  False: some handle is not a row of
+        this table (the host loop then)."""
+        import torch
+        t_tracks, m_tracks = list(self._target_dict.values()), list(self._missile_dict.values())
+        handles = [tr.target for tr in t_tracks] + [tr.missile for tr in m_tracks]
+        if any(getattr(h, "_store", None) is not store for h in handles) or max(len(t_tracks), len(m_tracks)) > post.tcap:
+            return False
+        dev = post.dev
+        i32 = lambda xs: torch.tensor(list(xs), dtype=torch.int32, device=dev)         # noqa: E731
+        nt, nm = len(t_tracks), len(m_tracks)
+        slot_of_id = {h.id: h._slot for h in handles}
+        post.key_tt.fill_(-1)
+        post.tt_ref_fixed.fill_(float("nan")); post.tm_ref_fixed.fill_(float("nan"))
+        if nt:
+            keys = [slot_of_id.get(k, -1) for k in self._target_dict]
+            if min(keys) < 0:
+                return False
+            post.tt_key[:nt] = i32(keys); post.tt_obj[:nt] = i32(tr.target._slot for tr in t_tracks)
+            post.tt_upd[:nt] = torch.tensor([tr.upd_time for tr in t_tracks], dtype=torch.float64, device=dev)
+            post.tt_follow[:nt] = torch.tensor([1 if tr.following else 0 for tr in t_tracks], dtype=torch.uint8, device=dev)
+            post.key_tt[torch.tensor(keys, dtype=torch.int64, device=dev)] = torch.arange(nt, dtype=torch.int32, device=dev)
+        if nm:
+            post.tm_key[:nm] = i32(slot_of_id.get(k, -1) for k in self._missile_dict)
+            post.tm_obj[:nm] = i32(tr.missile._slot for tr in m_tracks)
+            post.tm_upd[:nm] = torch.tensor([tr.upd_time for tr in m_tracks], dtype=torch.float64, device=dev)
+        # tracks whose object has left the air: what the handle still holds as prev_pos (the table has lost it)
+        for k, tr in enumerate(t_tracks):
+            if tr.target._frozen is not None:
+                ref = tr.target.prev_pos
+                if ref is None:
+                    return False
+                post.tt_ref_fixed[k] = torch.tensor(np.asarray(ref, np.float64), device=dev)
+        for k, tr in enumerate(m_tracks):
+            if tr.missile._frozen is not None:
+                ref = tr.missile.prev_pos
+                post.tm_ref_fixed[k] = torch.tensor(np.asarray(tr.missile.pos if ref is None else ref, np.float64), device=dev)
+        post.counts.copy_(torch.tensor([nt, nm], dtype=torch.int32))
+        self._post_stale = False
+        self._post_frozen = {id(h) for h in handles if h._frozen is not None}
+        return True
 
     # outbound ----------------------------------------------------------------------------------
     def send_update_msg_to_radar(self, target, missile_id, radar_id):
@@ -243,7 +374,8 @@ class CombatControlPoint(BaseModel):
                     seen_ids.append(obj.id)
 
         processed, seen, dets = [], set(), []
-        for msg in mgr.give_messages_by_type(MessageType.FOUND_OBJECTS):
+        found_msgs = mgr.give_messages_by_type(MessageType.FOUND_OBJECTS)
+        for msg in found_msgs:
             radar_id = msg.sender_id
             for obj in msg.visible_objects:
                 if obj.id in seen:
@@ -251,8 +383,20 @@ class CombatControlPoint(BaseModel):
                 seen.add(obj.id)
                 processed.append(obj.id)
                 dets.append((obj, radar_id))
-        # every verdict of the tick at once on the device; a verdict depends on earlier ones only through tracks they
-        # took (updated "now", hence skipped), which the device resolution reproduces
+        # handles that have left the air since the mirror was made hold a prev_pos the table has lost: mirror again
+        if self._post is not None and not self._post_stale:
+            frozen = {id(tr.target) for tr in self._target_dict.values() if getattr(tr.target, "_frozen", None) is not None}
+            frozen |= {id(tr.missile) for tr in self._missile_dict.values() if getattr(tr.missile, "_frozen", None) is not None}
+            if frozen != getattr(self, "_post_frozen", set()):
+                self._post_stale = True
+        # the whole loop on the device where the objects are rows of one device table (zrk_ccp_step) ...
+        if self._device_tick(found_msgs, dets):
+            self.send_objects_to_GUI(to_draw, processed)
+            return
+        self._post_stale = True
+        # ... otherwise every verdict of the tick at once on the device (zrk_ccp_link: a verdict depends on earlier ones only
+        # through tracks they took -- updated "now", hence skipped --, which the device resolution reproduces), or the
+        # reference's loop
         verdicts = self._link_all([o for o, _ in dets]) if dets else []
         for k, (obj, radar_id) in enumerate(dets):
             verdict, old_id = verdicts[k] if verdicts is not None else self.link_object(obj)

@@ -133,7 +133,11 @@ class SectorRadar(BaseModel):
             store.noise_apply(det, cnt, np.random.normal(0, RADAR_NOISE_SIGMA, (cnt, 3)))
         visible = [objects._handles[s] for s in slots]
         logger.debug("radar %s sees %d objects", self.id, cnt)
-        mgr.add_message(FoundObjectsMessage(time=now, sender_id=self.id, receiver_id=CCP_ID, visible_objects=visible))
+        found = FoundObjectsMessage(time=now, sender_id=self.id, receiver_id=CCP_ID, visible_objects=visible)
+        # (for a command post that works on the device: the same list as table rows, still in HBM -- the compaction's buffer
+        # is reused by the next radar, hence the copy)
+        found.device_rows, found.device_store = (det[:cnt].clone() if cnt else det[:0]), store
+        mgr.add_message(found)
 
         # relay of target updates to missiles: nobody produces UPDATE_TARGET, kept for shape
         for m in mgr.give_messages_by_type(MessageType.UPDATE_TARGET, step_time=now - dt):
