@@ -55,7 +55,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 SPINUP_MS = 100.0
-PROFILE_TAG = "r02"            # profiles/<tag>_* hold the recorded figures echoed in the line
+PROFILE_TAG = "r03"            # profiles/<tag>_* hold the recorded figures echoed in the line
 
 
 def parse_args():
@@ -65,6 +65,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C3x4", "C4", "C5", "tiny", "tiny4", "tiny5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c4", action="store_true",
+                    help="skip the strong-scaling sub-record (configs[3], one population of 1e7) a default C3 run adds to its line")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--selfcheck-launch", action="store_true",
                     help="rank start-up and rendezvous only (gloo, no GPU): what tests/ use to cover --gpus N on a CPU box")
@@ -329,238 +331,255 @@ def main():
     torch.cuda.set_device(device)
 
     from zrk_modulation_amd import scenario as S
-    ensemble = args.workload in S.ENSEMBLES
-    strong = args.workload in S.STRONG
-    if ensemble:
-        eng, info = build_ensemble(args.workload, rank, world, device)
-    else:
-        eng, info = build_engine(args.workload, rank, world, device)
-    # ZRK_BENCH_FORCE_EXCHANGE=1: the N > 1 control flow (C-side exchange, list sizing, overflow report) on ONE rank, for
-    # boxes with one GPU: RCCL runs with a one-rank communicator, nothing crosses a link
-    exchanging = (world > 1 or bool(os.environ.get("ZRK_BENCH_FORCE_EXCHANGE"))) and not ensemble
-    state = {"c_side": exchanging and backend == "nccl"}     # may fall back to the Python exchange at set-up
-    xchg = {"x": None, "ex": [], "buf": [], "work": [None, None], "tick": 0, "entries": 0, "words": 0}
-    ev_cap = max(64, info["m"]) if exchanging else 0
 
-    def coll_device(t):
-        return t.to(device) if backend == "nccl" else t.cpu()
-
-    def all_reduce(t, op):
-        if world > 1:
-            dist.all_reduce(t, op=op)
-
-    def size_exchange(entries):
-        """Lists for up to `entries` seen objects per rank, in the wire format of zrk_compact_bits (count, n, one
-        bit per slot, 16-bit masks): a quarter of the bytes of (index, mask) pairs."""
-        from zrk_modulation_amd.exchange import DetectionExchange, RcclExchange, union_bits_words
-        n_slots = coll_device(torch.tensor([int(eng.store.cap)], dtype=torch.int64))
-        all_reduce(n_slots, dist.ReduceOp.MAX)
-        words = union_bits_words(int(n_slots.item()), info["R"], entries)
-        offsets = [g * info["stride"] for g in range(world)]
-        made = False
-        if state["c_side"] and xchg["x"] is not None:
-            torch.cuda.synchronize(device)
-            xchg["x"].resize(words)                      # same communicator, new buffers
-            made = True
-        elif state["c_side"]:
-            try:
-                xchg["x"] = RcclExchange(words, device, info["R"], offsets=offsets, ev_capacity=ev_cap)
-                made = True
-            except Exception as exc:                     # the library's own communicator could not be set up here
-                print(f"[bench rank {rank}] C-side exchange unavailable ({exc}); falling back to torch.distributed", file=sys.stderr)
-        if state["c_side"]:
-            ok = coll_device(torch.tensor([1 if made else 0], dtype=torch.int64))
-            all_reduce(ok, dist.ReduceOp.MIN)               # every rank takes the same path
-            if int(ok.item()) == 0:
-                if xchg["x"] is not None:
-                    xchg["x"].close()
-                    xchg["x"] = None
-                state["c_side"] = False
-        if not state["c_side"]:
-            xchg["ex"] = [DetectionExchange(words, device, fmt="bits", offsets=offsets, R=info["R"]) for _ in range(2)]
-            xchg["buf"] = [torch.zeros(words, dtype=torch.int64, device=device) for _ in range(2)]
-            xchg["work"] = [None, None]
-        xchg["entries"], xchg["words"] = int(entries), int(words)
-
-    def drain_exchange():
-        if state["c_side"] and xchg["x"] is not None:
-            xchg["x"].sync()
-        for k, w in enumerate(xchg["work"]):
-            if w is not None:
-                w.wait()
-                xchg["work"][k] = None
-
-    def max_count():
-        if state["c_side"]:
-            return max(max(xchg["x"].counts(k)) for k in range(xchg["x"].slots))
-        return max(max(e.counts()) for e in xchg["ex"])
-
-    if exchanging:
-        size_exchange(eng.store.cap)     # (may settle for the Python exchange: decided before anything depends on it)
-
-    # every 10th tick's sweep is timed when the run is short (the last tick of each window of ten: two samples in the
-    # driver's 20-step run), every 8th otherwise: a timed launch costs the stream 5-13 us of idle device around it, whether
-    # the events ride on the dispatch or are recorded around it (profiles/r03_timeline_20steps.txt: five samples cost the
-    # 20-step run 3 us per tick); the events are read after the timed region
-    stride = int(os.environ.get("ZRK_BENCH_STRIDE", 0)) or (10 if args.steps <= 64 else 8)
-    if exchanging and not state["c_side"]:
-        stride = 64                      # ticks driven one call at a time: reading the events drains the stream
-    deferred = not (exchanging and not state["c_side"])
-
-    def run_ticks(k, sweep_ms=None, every=None):
-        every = every or stride
-        ps = (-every if deferred else every) if sweep_ms is not None else 1
-        if not exchanging:
-            eng.run(k, sweep_ms=None if deferred else sweep_ms, prof_stride=ps)
-            return
-        if state["c_side"]:
-            eng.run(k, sweep_ms=None if deferred else sweep_ms, prof_stride=ps, exchange=xchg["x"])
-            return
-        for j in range(k):               # rehearsal path: the exchange goes through torch.distributed, tick by tick
-            b = xchg["tick"] & 1
-            if xchg["work"][b] is not None:
-                xchg["work"][b].wait()
-            eng.packed = xchg["buf"][b]
-            eng.loop.flags |= 8          # ZRK_F_UNION_BITS
-            one = np.zeros(1, np.float32) if (sweep_ms is not None and j % stride == 0) else None
-            eng.run(1, sweep_ms=one, prof_stride=1)
-            xchg["work"][b] = xchg["ex"][b].all_gather(eng.packed, async_op=True)
-            xchg["tick"] += 1
-            if one is not None:
-                sweep_ms[j // stride] = one[0]
-
-    def barrier():
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(device)
-
-    def spin_up():
-        """~100 ms of an unrelated kernel (the noise self-test) so that the clocks are up when the timed steps start, as
-        they are inside any run longer than a few milliseconds (see the docstring)."""
-        buf = torch.zeros(3 << 20, dtype=torch.float64, device=device)
-        st0 = eng.store
-        t_spin = time.perf_counter()
-        while (time.perf_counter() - t_spin) * 1e3 < SPINUP_MS:
-            for _ in range(8):
-                st0.ctx.check(st0.lib.zrk_selftest_noise(st0.ctx.handle, 1, 1, 3, 0, buf.data_ptr(), 1 << 20, None), "spin-up")
-            torch.cuda.synchronize(device)
-
-    # the warm-up steps go through the same code as the timed ones, sweep timing included: the library creates its timing
-    # events on first use, and a first hipExtLaunchKernel is slow -- neither belongs into the timed region
-    # (every warm-up sweep is timed, so that the timed region's events exist already)
-    warm_ms = np.zeros(args.warmup, np.float32) if (args.warmup > 0 and deferred) else None
-    run_ticks(args.warmup, warm_ms, every=1)
-    if warm_ms is not None and deferred:
-        eng.read_sweep_ms(len(warm_ms))
-    overflow = False
-    if exchanging and args.warmup > 0:
-        # size the fixed lists from what the warm-up saw (1.25x the largest per-rank count: the count follows the
-        # sectors round their scan period, which a full warm-up covers; an overflow is reported)
-        drain_exchange()
-        seen = coll_device(torch.tensor([max_count()], dtype=torch.int64))
-        all_reduce(seen, dist.ReduceOp.MAX)
-        size_exchange(int(seen.item() * 1.25) + 1024)
-    barrier()
-    live0 = eng.alive_count()
-    sweep_ms = np.zeros((args.steps + stride - 1) // stride, np.float32)
-    spin_up()
-    barrier()
-    t0 = time.perf_counter()
-    run_ticks(args.steps, sweep_ms)
-    t_issued = time.perf_counter()
-    if exchanging:
-        drain_exchange()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    sweep_ticks = np.ones(len(sweep_ms), np.int32)
-    if deferred:
-        sweep_ms[:] = eng.read_sweep_ms(len(sweep_ms))
-        if hasattr(eng, "read_sweep_ticks"):
-            sweep_ticks[:] = eng.read_sweep_ticks(len(sweep_ms))
-    live1 = eng.alive_count()
-    eng.store.compact_status()           # outside the timing: a compaction that did not run to completion raises here
-    if exchanging:
-        overflow = xchg["x"].overflowed() if state["c_side"] else any(e.overflowed() for e in xchg["ex"])
-
-    elapsed_rank0 = elapsed
-    el = coll_device(torch.tensor([elapsed], dtype=torch.float64))
-    units = coll_device(torch.tensor([float(min(live0, live1)) * args.steps], dtype=torch.float64))
-    all_reduce(el, dist.ReduceOp.MAX)
-    all_reduce(units, dist.ReduceOp.SUM)
-    elapsed = float(el.item()); total_units = float(units.item())
-
-    if rank == 0:
-        n_slots = eng.store.n_uploaded
-        live_avg = 0.5 * (live0 + live1)
-        alg_bytes = 85.0 * live_avg + 1.0 * (n_slots - live_avg)
-        # a launch of the overlapped loop sweeps two consecutive ticks in one pass (zrk_hot.h: zrk_read_sweep_ticks): the
-        # samples are launches; only those of the prevailing kind are averaged (an odd tick at a call's end is a launch of one)
-        tpl = int(np.bincount(sweep_ticks[sweep_ms > 0]).argmax()) if (sweep_ms > 0).any() else 1
-        good = sweep_ms[(sweep_ms > 0) & (sweep_ticks == tpl)]
-        sweep_avg_ms = float(good.mean()) if len(good) else float("nan")
-        alg_bytes_tick = alg_bytes
-        alg_bytes = alg_bytes_tick * tpl                   # algorithmic bytes per LAUNCH: 85 B per live entity and tick swept
-        achieved = alg_bytes / (sweep_avg_ms * 1e-3) / 1e9
+    def measure(workload, steps, warmup, cpu_base):
+        """One workload, set up, warmed up and timed as the docstring says; rank 0 gets the line's dictionary."""
+        from zrk_modulation_amd import scenario as S
+        ensemble = workload in S.ENSEMBLES
+        strong = workload in S.STRONG
         if ensemble:
-            what = (f"{args.workload}: {info['scenarios']} independent scenarios x {info['per_scenario']} AirObjects, "
-                    f"{info['R']} SectorRadars and {info['m'] // info['scenarios']} missiles each, per GPU, one batched table")
+            eng, info = build_ensemble(workload, rank, world, device)
         else:
-            what = (f"{args.workload}: {info['n']} AirObjects, {info['R']} SectorRadars, "
-                    f"{info['launched']}/{info['m']} missiles in flight per GPU")
-            if strong:
-                what += f" (rank 0's shard of ONE population of {info['n_total']})"
-        what += ", dt=10 ms, Philox measurement noise, "
+            eng, info = build_engine(workload, rank, world, device)
+        # ZRK_BENCH_FORCE_EXCHANGE=1: the N > 1 control flow (C-side exchange, list sizing, overflow report) on ONE rank, for
+        # boxes with one GPU: RCCL runs with a one-rank communicator, nothing crosses a link
+        exchanging = (world > 1 or bool(os.environ.get("ZRK_BENCH_FORCE_EXCHANGE"))) and not ensemble
+        state = {"c_side": exchanging and backend == "nccl"}     # may fall back to the Python exchange at set-up
+        xchg = {"x": None, "ex": [], "buf": [], "work": [None, None], "tick": 0, "entries": 0, "words": 0}
+        ev_cap = max(64, info["m"]) if exchanging else 0
+
+        def coll_device(t):
+            return t.to(device) if backend == "nccl" else t.cpu()
+
+        def all_reduce(t, op):
+            if world > 1:
+                dist.all_reduce(t, op=op)
+
+        def size_exchange(entries):
+            """Lists for up to `entries` seen objects per rank, in the wire format of zrk_compact_bits (count, n, one
+            bit per slot, 16-bit masks): a quarter of the bytes of (index, mask) pairs."""
+            from zrk_modulation_amd.exchange import DetectionExchange, RcclExchange, union_bits_words
+            n_slots = coll_device(torch.tensor([int(eng.store.cap)], dtype=torch.int64))
+            all_reduce(n_slots, dist.ReduceOp.MAX)
+            words = union_bits_words(int(n_slots.item()), info["R"], entries)
+            offsets = [g * info["stride"] for g in range(world)]
+            made = False
+            if state["c_side"] and xchg["x"] is not None:
+                torch.cuda.synchronize(device)
+                xchg["x"].resize(words)                      # same communicator, new buffers
+                made = True
+            elif state["c_side"]:
+                try:
+                    xchg["x"] = RcclExchange(words, device, info["R"], offsets=offsets, ev_capacity=ev_cap)
+                    made = True
+                except Exception as exc:                     # the library's own communicator could not be set up here
+                    print(f"[bench rank {rank}] C-side exchange unavailable ({exc}); falling back to torch.distributed", file=sys.stderr)
+            if state["c_side"]:
+                ok = coll_device(torch.tensor([1 if made else 0], dtype=torch.int64))
+                all_reduce(ok, dist.ReduceOp.MIN)               # every rank takes the same path
+                if int(ok.item()) == 0:
+                    if xchg["x"] is not None:
+                        xchg["x"].close()
+                        xchg["x"] = None
+                    state["c_side"] = False
+            if not state["c_side"]:
+                xchg["ex"] = [DetectionExchange(words, device, fmt="bits", offsets=offsets, R=info["R"]) for _ in range(2)]
+                xchg["buf"] = [torch.zeros(words, dtype=torch.int64, device=device) for _ in range(2)]
+                xchg["work"] = [None, None]
+            xchg["entries"], xchg["words"] = int(entries), int(words)
+
+        def drain_exchange():
+            if state["c_side"] and xchg["x"] is not None:
+                xchg["x"].sync()
+            for k, w in enumerate(xchg["work"]):
+                if w is not None:
+                    w.wait()
+                    xchg["work"][k] = None
+
+        def max_count():
+            if state["c_side"]:
+                return max(max(xchg["x"].counts(k)) for k in range(xchg["x"].slots))
+            return max(max(e.counts()) for e in xchg["ex"])
+
         if exchanging:
-            what += ("union compaction in the bitmap wire format + per-tick RCCL all-gather of the detection list and the "
-                     "detonation events, " + ("issued from the C side, overlapped with the next sweep" if state["c_side"]
-                                              else "through torch.distributed (rehearsal backend)"))
-        else:
-            what += "per-radar compaction"
-        overlapped = eng.store.lib.zrk_last_run_overlapped(eng.store.ctx.handle) == 1     # (of the timed call)
-        loop_mode = ("two launches per tick on one stream" if not overlapped else
-                     "overlapped: tick t's compaction on a side stream beside tick t+1's sweep" if tpl == 1 else
-                     "overlapped, two ticks per sweep launch: the trajectory columns are read once for ticks t and t+1, their "
-                     "compactions run on a side stream beside the next launch")
-        out = {
-            "metric": "entity-timesteps/sec (targets+missiles)", "value": total_units / elapsed,
-            "unit": "entity-timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": what, "entities_per_gpu": n_slots, "live_per_gpu": int(live1),
-                       "parallelism": f"shard{world}" if not ensemble else f"replicas{world}",
-                       "loop": loop_mode},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "traffic_recorded": recorded(f"traffic_bytes_{args.workload}") if world == 1 else None,
-                         "kernel": "k_tick_sweep", "avg_kernel_us": sweep_avg_ms * 1e3, "samples": int(len(good)),
-                         "algorithmic_bytes_per_launch": alg_bytes, "ticks_per_launch": tpl,
-                         "profiled_kernel_us_recorded": recorded(f"sweep_us_{args.workload}") if world == 1 else None,
-                         "profiled_kernel_us_alone_recorded": recorded(f"sweep_us_{args.workload}_plain_loop") if world == 1 else None,
-                         "recorded_from": f"profiles/{PROFILE_TAG}_recorded.json (rocprofv3 passes of this command, committed)",
-                         # the same algorithmic bytes over the whole tick (this rank's): what the loop around the kernel leaves of it
-                         "whole_tick": {"achieved": alg_bytes_tick / (elapsed / args.steps) / 1e9,
-                                        "frac": alg_bytes_tick / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}},
-            "setup": {"clock_spinup_ms": SPINUP_MS, "sweep_timing_stride": stride,
-                      # of the timed region: until the one zrk_run_ticks call returned (everything issued, the side stream's
-                      # work handed over), and the synchronisation behind it
-                      "call_returned_after_us": (t_issued - t0) * 1e6, "sync_us": (elapsed_rank0 - (t_issued - t0)) * 1e6},
-        }
+            size_exchange(eng.store.cap)     # (may settle for the Python exchange: decided before anything depends on it)
+
+        # every 10th tick's sweep is timed when the run is short (the last tick of each window of ten: two samples in the
+        # driver's 20-step run), every 8th otherwise: a timed launch costs the stream 5-13 us of idle device around it, whether
+        # the events ride on the dispatch or are recorded around it (profiles/r03_timeline_20steps.txt: five samples cost the
+        # 20-step run 3 us per tick); the events are read after the timed region
+        stride = int(os.environ.get("ZRK_BENCH_STRIDE", 0)) or (10 if steps <= 64 else 8)
+        if exchanging and not state["c_side"]:
+            stride = 64                      # ticks driven one call at a time: reading the events drains the stream
+        deferred = not (exchanging and not state["c_side"])
+
+        def run_ticks(k, sweep_ms=None, every=None):
+            every = every or stride
+            ps = (-every if deferred else every) if sweep_ms is not None else 1
+            if not exchanging:
+                eng.run(k, sweep_ms=None if deferred else sweep_ms, prof_stride=ps)
+                return
+            if state["c_side"]:
+                eng.run(k, sweep_ms=None if deferred else sweep_ms, prof_stride=ps, exchange=xchg["x"])
+                return
+            for j in range(k):               # rehearsal path: the exchange goes through torch.distributed, tick by tick
+                b = xchg["tick"] & 1
+                if xchg["work"][b] is not None:
+                    xchg["work"][b].wait()
+                eng.packed = xchg["buf"][b]
+                eng.loop.flags |= 8          # ZRK_F_UNION_BITS
+                one = np.zeros(1, np.float32) if (sweep_ms is not None and j % stride == 0) else None
+                eng.run(1, sweep_ms=one, prof_stride=1)
+                xchg["work"][b] = xchg["ex"][b].all_gather(eng.packed, async_op=True)
+                xchg["tick"] += 1
+                if one is not None:
+                    sweep_ms[j // stride] = one[0]
+
+        def barrier():
+            torch.cuda.synchronize(device)
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize(device)
+
+        def spin_up():
+            """~100 ms of an unrelated kernel (the noise self-test) so that the clocks are up when the timed steps start, as
+            they are inside any run longer than a few milliseconds (see the docstring)."""
+            buf = torch.zeros(3 << 20, dtype=torch.float64, device=device)
+            st0 = eng.store
+            t_spin = time.perf_counter()
+            while (time.perf_counter() - t_spin) * 1e3 < SPINUP_MS:
+                for _ in range(8):
+                    st0.ctx.check(st0.lib.zrk_selftest_noise(st0.ctx.handle, 1, 1, 3, 0, buf.data_ptr(), 1 << 20, None), "spin-up")
+                torch.cuda.synchronize(device)
+
+        # the warm-up steps go through the same code as the timed ones, sweep timing included: the library creates its timing
+        # events on first use, and a first hipExtLaunchKernel is slow -- neither belongs into the timed region
+        # (every warm-up sweep is timed, so that the timed region's events exist already)
+        warm_ms = np.zeros(warmup, np.float32) if (warmup > 0 and deferred) else None
+        run_ticks(warmup, warm_ms, every=1)
+        if warm_ms is not None and deferred:
+            eng.read_sweep_ms(len(warm_ms))
+        overflow = False
+        if exchanging and warmup > 0:
+            # size the fixed lists from what the warm-up saw (1.25x the largest per-rank count: the count follows the
+            # sectors round their scan period, which a full warm-up covers; an overflow is reported)
+            drain_exchange()
+            seen = coll_device(torch.tensor([max_count()], dtype=torch.int64))
+            all_reduce(seen, dist.ReduceOp.MAX)
+            size_exchange(int(seen.item() * 1.25) + 1024)
+        barrier()
+        live0 = eng.alive_count()
+        sweep_ms = np.zeros((steps + stride - 1) // stride, np.float32)
+        spin_up()
+        barrier()
+        t0 = time.perf_counter()
+        run_ticks(steps, sweep_ms)
+        t_issued = time.perf_counter()
         if exchanging:
-            out["config"]["exchange"] = "rccl, C side" if state["c_side"] else f"torch.distributed {backend}"
-            out["config"]["exchange_entries_per_rank"] = xchg["entries"]
-            out["config"]["exchange_bytes_per_rank"] = 8 * (xchg["words"] + (1 + ev_cap if state["c_side"] else 0))
-            out["config"]["exchange_overflow"] = bool(overflow)
-        if world == 1 and not args.no_cpu_baseline and not ensemble:
-            out["cpu_baseline"] = cpu_baseline(info, eng, args.cpu_budget)
-        elif world == 1 and not args.no_cpu_baseline and ensemble:
-            out["cpu_baseline"] = cpu_baseline_ensemble(eng, args.cpu_budget, usable_cores(), cpu_model())
-        else:
-            out["cpu_baseline"] = None
+            drain_exchange()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        sweep_ticks = np.ones(len(sweep_ms), np.int32)
+        if deferred:
+            sweep_ms[:] = eng.read_sweep_ms(len(sweep_ms))
+            if hasattr(eng, "read_sweep_ticks"):
+                sweep_ticks[:] = eng.read_sweep_ticks(len(sweep_ms))
+        live1 = eng.alive_count()
+        eng.store.compact_status()           # outside the timing: a compaction that did not run to completion raises here
+        if exchanging:
+            overflow = xchg["x"].overflowed() if state["c_side"] else any(e.overflowed() for e in xchg["ex"])
+
+        elapsed_rank0 = elapsed
+        el = coll_device(torch.tensor([elapsed], dtype=torch.float64))
+        units = coll_device(torch.tensor([float(min(live0, live1)) * steps], dtype=torch.float64))
+        all_reduce(el, dist.ReduceOp.MAX)
+        all_reduce(units, dist.ReduceOp.SUM)
+        elapsed = float(el.item()); total_units = float(units.item())
+
+        if rank == 0:
+            n_slots = eng.store.n_uploaded
+            live_avg = 0.5 * (live0 + live1)
+            alg_bytes = 85.0 * live_avg + 1.0 * (n_slots - live_avg)
+            # a launch of the overlapped loop sweeps two consecutive ticks in one pass (zrk_hot.h: zrk_read_sweep_ticks): the
+            # samples are launches; only those of the prevailing kind are averaged (an odd tick at a call's end is a launch of one)
+            tpl = int(np.bincount(sweep_ticks[sweep_ms > 0]).argmax()) if (sweep_ms > 0).any() else 1
+            good = sweep_ms[(sweep_ms > 0) & (sweep_ticks == tpl)]
+            sweep_avg_ms = float(good.mean()) if len(good) else float("nan")
+            alg_bytes_tick = alg_bytes
+            alg_bytes = alg_bytes_tick * tpl                   # algorithmic bytes per LAUNCH: 85 B per live entity and tick swept
+            achieved = alg_bytes / (sweep_avg_ms * 1e-3) / 1e9
+            if ensemble:
+                what = (f"{workload}: {info['scenarios']} independent scenarios x {info['per_scenario']} AirObjects, "
+                        f"{info['R']} SectorRadars and {info['m'] // info['scenarios']} missiles each, per GPU, one batched table")
+            else:
+                what = (f"{workload}: {info['n']} AirObjects, {info['R']} SectorRadars, "
+                        f"{info['launched']}/{info['m']} missiles in flight per GPU")
+                if strong:
+                    what += f" (rank 0's shard of ONE population of {info['n_total']})"
+            what += ", dt=10 ms, Philox measurement noise, "
+            if exchanging:
+                what += ("union compaction in the bitmap wire format + per-tick RCCL all-gather of the detection list and the "
+                         "detonation events, " + ("issued from the C side, overlapped with the next sweep" if state["c_side"]
+                                                  else "through torch.distributed (rehearsal backend)"))
+            else:
+                what += "per-radar compaction"
+            overlapped = eng.store.lib.zrk_last_run_overlapped(eng.store.ctx.handle) == 1     # (of the timed call)
+            loop_mode = ("two launches per tick on one stream" if not overlapped else
+                         "overlapped: tick t's compaction on a side stream beside tick t+1's sweep" if tpl == 1 else
+                         "overlapped, two ticks per sweep launch: the trajectory columns are read once for ticks t and t+1, their "
+                         "compactions run on a side stream beside the next launch")
+            out = {
+                "metric": "entity-timesteps/sec (targets+missiles)", "value": total_units / elapsed,
+                "unit": "entity-timesteps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+                "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+                "scaling": "strong" if strong else "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": what, "entities_per_gpu": n_slots, "live_per_gpu": int(live1),
+                           "parallelism": f"shard{world}" if not ensemble else f"replicas{world}",
+                           "loop": loop_mode},
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                             "traffic_recorded": recorded(f"traffic_bytes_{workload}") if world == 1 else None,
+                             "kernel": "k_tick_sweep", "avg_kernel_us": sweep_avg_ms * 1e3, "samples": int(len(good)),
+                             "algorithmic_bytes_per_launch": alg_bytes, "ticks_per_launch": tpl,
+                             "profiled_kernel_us_recorded": recorded(f"sweep_us_{workload}") if world == 1 else None,
+                             "profiled_kernel_us_alone_recorded": recorded(f"sweep_us_{workload}_plain_loop") if world == 1 else None,
+                             "recorded_from": f"profiles/{PROFILE_TAG}_recorded.json (rocprofv3 passes of this command, committed)",
+                             # the same algorithmic bytes over the whole tick (this rank's): what the loop around the kernel leaves of it
+                             "whole_tick": {"achieved": alg_bytes_tick / (elapsed / steps) / 1e9,
+                                            "frac": alg_bytes_tick / (elapsed / steps) / 1e9 / HBM_PEAK_GBS}},
+                "setup": {"clock_spinup_ms": SPINUP_MS, "sweep_timing_stride": stride,
+                          # of the timed region: until the one zrk_run_ticks call returned (everything issued, the side stream's
+                          # work handed over), and the synchronisation behind it
+                          "call_returned_after_us": (t_issued - t0) * 1e6, "sync_us": (elapsed_rank0 - (t_issued - t0)) * 1e6},
+            }
+            if exchanging:
+                out["config"]["exchange"] = "rccl, C side" if state["c_side"] else f"torch.distributed {backend}"
+                out["config"]["exchange_entries_per_rank"] = xchg["entries"]
+                out["config"]["exchange_bytes_per_rank"] = 8 * (xchg["words"] + (1 + ev_cap if state["c_side"] else 0))
+                out["config"]["exchange_overflow"] = bool(overflow)
+            if world == 1 and cpu_base and not ensemble:
+                out["cpu_baseline"] = cpu_baseline(info, eng, args.cpu_budget)
+            elif world == 1 and cpu_base and ensemble:
+                out["cpu_baseline"] = cpu_baseline_ensemble(eng, args.cpu_budget, usable_cores(), cpu_model())
+            else:
+                out["cpu_baseline"] = None
+        if xchg["x"] is not None:
+            xchg["x"].close()
+        return out if rank == 0 else None
+
+    out = measure(args.workload, args.steps, args.warmup, not args.no_cpu_baseline)
+    # The scaling curve north_star names is on the ONE-population 1e7-target scenario (configs[3], strong scaling): the
+    # default run (C3 per GPU, weak scaling -- the roofline configuration) measures it as well, behind the main timing, so
+    # that `python bench.py --gpus N` for N = 1, 2, 4, 8 yields both curves (--no-c4 skips it).
+    if args.workload == "C3" and not args.no_c4 and not os.environ.get("ZRK_BENCH_FORCE_EXCHANGE"):
+        sub = measure("C4", min(args.steps, 60), min(max(args.warmup, 4), 12), False)
+        if rank == 0:
+            out["c4_strong"] = {k: sub[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling")}
+            out["c4_strong"]["config"] = sub["config"]
+            out["c4_strong"]["roofline"] = {k: sub["roofline"][k] for k in ("achieved", "frac", "avg_kernel_us", "ticks_per_launch", "samples")}
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    if xchg["x"] is not None:
-        xchg["x"].close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
