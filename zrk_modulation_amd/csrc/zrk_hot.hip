@@ -1650,6 +1650,42 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_side(const CompactArgs C
     compact_block<kCompBlock>(S, C, by_ticket);
 }
 
+// The ordered event list of a tick from the per-row codes, by ONE workgroup of any size (each thread owns a run of
+// consecutive rows and walks it twice: count, then emit).  The side stream's variant: no tombstones (removals are marks).
+__device__ __forceinline__ void missile_events_any(int *s_wave /* [16] */, const MissileArgs &M)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, T = (int)blockDim.x, waves = T >> 6;
+    const int64_t per = (M.m + T - 1) / T;
+    const int64_t row0 = (int64_t)tid * per, row1 = (row0 + per < M.m) ? row0 + per : M.m;
+    int cnt = 0;
+    for (int64_t row = row0; row < row1; ++row) cnt += M.ev_code[row] != 0;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int base = incl - cnt, total = 0;
+    for (int w = 0; w < waves; ++w) { if (w < wave) base += s_wave[w]; total += s_wave[w]; }
+    if (tid == 0) {
+        *M.ev_count = total;
+        if (M.ev_wire) M.ev_wire[0] = total;
+    }
+    if (cnt == 0) return;
+    for (int64_t row = row0; row < row1; ++row) {
+        const uint8_t code = M.ev_code[row];
+        if (!code) continue;
+        const int32_t ms = M.m_slot[row], ts = (code == 1) ? M.m_tgt[row] : -1;
+        M.ev_missile[base] = ms; M.ev_target[base] = ts;
+        if (M.ev_wire && base < M.ev_wire_cap)                // MissileDetonateMessage (modules/Missile.py:138-146) for the other ranks
+            M.ev_wire[1 + base] = (int64_t)(((uint64_t)(M.gid0 + (M.lidx ? M.lidx[ms] : ms)) << 32) |
+                                            (ts >= 0 ? (uint64_t)(uint32_t)(M.gid0 + (M.lidx ? M.lidx[ts] : ts)) : 0xFFFFFFFFull));
+        ++base;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The two compactions of a PAIR launch's ticks in ONE launch (side stream): every workgroup squeezes the same slots of
 // both ticks' mask buffers, publishes ONE record with both ticks' R + 1 counts and waits ONCE for its predecessors -- the
@@ -1659,22 +1695,28 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_side(const CompactArgs C
 // det_idx / det_cnt / packed only.  `rm`: list indices of the rows the first tick's missile phase removed (rm[0] = how
 // many), whose bits the sweep's second tick set all the same (SweepParams::t2): taken out of the second tick's masks here.
 // ---------------------------------------------------------------------------------------------
-constexpr int kPairItems = kFusedMaxItems / 2;
+// Workgroup size: THREADS threads over kPairSlots list slots (kPairSlots / THREADS per thread and tick).  Beside a sweep
+// that fills the register files (seven waves of 72 registers per SIMD), a workgroup of 1024 threads -- four waves on every
+// SIMD of one compute unit at once -- finds room only when four sweep workgroups of that unit have retired and none was
+// put in their place; smaller workgroups take the room one retiring sweep workgroup leaves.
+constexpr int kPairSlots = 4096;
+constexpr int kPairItems = kFusedMaxItems / 2;                       // (per thread at 1024 threads)
 constexpr int kPairAggStride = 2 * kAggStride;
 
 struct CompactSharedPair {
-    int wcnt[2][kPairItems * (kCompBlock / 64)];
+    int wcnt[2][64];                                                  // (item, wave) counts: kPairSlots / 64 of them
     int cnt[2][ZRK_MAX_RADARS + 1];
     int pre[2 * (ZRK_MAX_RADARS + 1)];
     int ticket, found[2];
-    unsigned short idx[2][kPairItems * kCompBlock];
-    uint32_t msk[2][kPairItems * kCompBlock];
+    unsigned short idx[2][kPairSlots];
+    uint32_t msk[2][kPairSlots];
 };
 
+template <int THREADS>
 __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const CompactArgs &C0, const CompactArgs &C1, const int32_t *rm,
                                                    int rm_cap)
 {
-    constexpr int THREADS = kCompBlock, WAVES = kCompBlock / 64;
+    constexpr int WAVES = THREADS / 64, kItems = kPairSlots / THREADS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) S.ticket = atomicAdd(&C0.ctl[0], 1);
     if (tid < 2 * (ZRK_MAX_RADARS + 1)) S.pre[tid] = 0;
@@ -1690,12 +1732,12 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
     // the rows the first tick removed (few, mostly none): their list indices
     int rmn = rm ? __hip_atomic_load(rm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     rmn = rmn < rm_cap ? rmn : rm_cap;
-    uint32_t mk[2][kPairItems];
+    uint32_t mk[2][kItems];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const CompactArgs &C = s ? C1 : C0;
 #pragma unroll
-        for (int it = 0; it < kPairItems; ++it) {    // every load in flight before anything looks at one
+        for (int it = 0; it < kItems; ++it) {    // every load in flight before anything looks at one
             const int64_t i = blk0 + (int64_t)it * THREADS + tid;
             mk[s][it] = (it < items && i < C.n) ? C.vis[i] : 0u;
         }
@@ -1704,7 +1746,7 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
     for (int s = 0; s < 2; ++s) {
         const CompactArgs &C = s ? C1 : C0;
 #pragma unroll
-        for (int it = 0; it < kPairItems; ++it) {
+        for (int it = 0; it < kItems; ++it) {
             if (it < items) {
                 const int64_t i = blk0 + (int64_t)it * THREADS + tid;
                 // (the loop's own mask buffers are cleared by the compaction that reads them: only the detections are not zero)
@@ -1715,7 +1757,7 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
     for (int q = 0; q < rmn; ++q) {                  // (wave-uniform trip count; every thread compares its own slots)
         const int64_t off = (int64_t)rm[1 + q] - blk0;
 #pragma unroll
-        for (int it = 0; it < kPairItems; ++it)
+        for (int it = 0; it < kItems; ++it)
             if (off == (int64_t)it * THREADS + tid) {
                 mk[1][it] = 0u;
                 const_cast<uint32_t *>(C1.vis)[blk0 + off] = 0u;     // (the call's last tick: the caller reads this buffer)
@@ -1725,7 +1767,7 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
     for (int s = 0; s < 2; ++s) {
         const CompactArgs &C = s ? C1 : C0;
 #pragma unroll
-        for (int it = 0; it < kPairItems; ++it) {
+        for (int it = 0; it < kItems; ++it) {
             if (it < items) {
                 const unsigned long long bu = __ballot(mk[s][it] != 0u);
                 if (lane == 0) {
@@ -1755,7 +1797,7 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
-        for (int it = 0; it < kPairItems; ++it) {
+        for (int it = 0; it < kItems; ++it) {
             if (it < items) {
                 const unsigned long long bu = __ballot(mk[s][it] != 0u);
                 if (mk[s][it] != 0u) {
@@ -1886,19 +1928,20 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
     }
 }
 
-__global__ __launch_bounds__(kCompBlock) void k_compact_pair(const CompactArgs C0, const CompactArgs C1, const MissileArgs M0,
-                                                             const MissileArgs M1, const int32_t *rm, int rm_cap)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_compact_pair(const CompactArgs C0, const CompactArgs C1, const MissileArgs M0,
+                                                          const MissileArgs M1, const int32_t *rm, int rm_cap)
 {
-    __shared__ int s_wave[kCompBlock / 64];
+    __shared__ int s_wave[16];
     __shared__ CompactSharedPair S;
     if ((int)blockIdx.x >= C0.nb) {                  // two extra workgroups: the ticks' ordered event lists
         if (M0.m > 0) {
-            if ((int)blockIdx.x == C0.nb) missile_finish_entry(s_wave, M0);
-            else missile_finish_entry(s_wave, M1);
+            if ((int)blockIdx.x == C0.nb) missile_events_any(s_wave, M0);
+            else missile_events_any(s_wave, M1);
         }
         return;
     }
-    compact_block_pair(S, C0, C1, rm, rm_cap);
+    compact_block_pair<THREADS>(S, C0, C1, rm, rm_cap);
 }
 
 // Overlapped loop of an ENSEMBLE: what the next sweep needs of a tick's second launch -- the tombstones, every
@@ -2856,7 +2899,7 @@ struct SideItem {
     // behind that sweep (an event record costs the compute stream a barrier packet -- harmless where no sweep follows)
     hipEvent_t wait_event;
     // both ticks of a pair launch in one compaction launch (k_compact_pair): C / M are the first tick's, C2 / M2 the second's
-    int pair, done_slot2;
+    int pair, done_slot2, pair_threads, _pad5;
     CompactArgs C2;
     MissileArgs M2;
     const int32_t *rm;
@@ -2974,6 +3017,7 @@ struct zrk_ctx {
     uint32_t rb_cache_flags[2] = {0, 0};
     bool pair_enabled = true;          // ZRK_PAIR=0: one tick per launch in the overlapped loop
     bool pair_compact = true;          // ZRK_PAIR_COMPACT=0: a pair's two compactions as two launches
+    int pair_threads = 1024;           // ZRK_PAIR_THREADS=256|512|1024: workgroup size of k_compact_pair
     int last_ticks_per_launch = 1;     // of the last zrk_run_ticks* call
     std::vector<int> tev_alias, tev_ticks;   // per timing sample: which event pair holds it, and the ticks its launch swept
     bool tail_by_event = true;         // ZRK_TAIL_EVENT=0: the last compaction of a call is released by a launch that raises the host word
@@ -3064,6 +3108,7 @@ ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
     { const char *v = std::getenv("ZRK_TAIL_EVENT"); c->tail_by_event = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_PAIR"); c->pair_enabled = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_PAIR_COMPACT"); c->pair_compact = !(v && v[0] == '0'); }
+    { const char *v = std::getenv("ZRK_PAIR_THREADS"); const int t = v ? std::atoi(v) : 1024; c->pair_threads = (t == 256 || t == 512) ? t : 1024; }
     if (const char *v = std::getenv("ZRK_COMPACT_ITEMS")) c->env_items = std::max(1, std::atoi(v));
     if (const char *v = std::getenv("ZRK_COMPACT_ORDER")) c->env_order = std::strcmp(v, "block") != 0;
     c->fused_max_blocks = kFusedMaxBlocks;
@@ -4069,9 +4114,15 @@ int side_issue(Side *sd, const SideItem &it)
     }
     if (!it.wait_event && (int32_t)(*sd->hflag - it.flag_value) < 0) { sd->err = "side stream: stopped"; return ZRK_E_STATE; }
     g_trace.mark("side: flag seen");
-    if (it.pair)
-        hipLaunchKernelGGL(k_compact_pair, dim3(it.C.nb + (it.M.m > 0 ? 2 : 0)), dim3(kCompBlock), 0, it.stream, it.C, it.C2, it.M, it.M2,
-                           it.rm, it.rm_cap);
+    if (it.pair) {
+        const dim3 grid(it.C.nb + (it.M.m > 0 ? 2 : 0));
+        if (it.pair_threads == 256)
+            hipLaunchKernelGGL(k_compact_pair<256>, grid, dim3(256), 0, it.stream, it.C, it.C2, it.M, it.M2, it.rm, it.rm_cap);
+        else if (it.pair_threads == 512)
+            hipLaunchKernelGGL(k_compact_pair<512>, grid, dim3(512), 0, it.stream, it.C, it.C2, it.M, it.M2, it.rm, it.rm_cap);
+        else
+            hipLaunchKernelGGL(k_compact_pair<1024>, grid, dim3(1024), 0, it.stream, it.C, it.C2, it.M, it.M2, it.rm, it.rm_cap);
+    }
     else
         hipLaunchKernelGGL(k_compact_side, dim3(it.C.nb + (it.M.m > 0 ? 1 : 0)), dim3(kCompBlock), 0, it.stream, it.C, it.by_ticket, it.M);
     // an exchange's collective (on the exchange's own stream) waits for this word: the list and its events are complete
@@ -4601,7 +4652,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             SideItem a, b;
             std::memset((void *)&a, 0, sizeof(a));
             std::memset((void *)&b, 0, sizeof(b));
-            const int items = std::min(kPairItems, fused_items(ctx, st->n));
+            // (kPairSlots list slots per workgroup whatever its size: the slots per thread follow)
+            const int items = kPairItems;
             // (the lists' send buffers were last sent ZRK_EXCHANGE_SLOTS ticks ago: those collectives must be through)
             for (int j = 0; j < 2 && rc == 0 && xio; ++j)
                 if (int rcw = zrk_exchange_wait(xio->x, xslot[j], stream)) rc = fail(ctx, rcw, zrk_exchange_last_error(xio->x));
@@ -4616,7 +4668,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             for (int j = 0; j < 2 && rc == 0 && ev_words && !fused; ++j)     // (no missiles: an empty event list behind each list)
                 if (hipMemsetAsync(list_t[j] + list_words, 0, sizeof(int64_t), s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "memset events");
             if (rc == 0) {
-                a.pair = 1; a.C2 = b.C;
+                a.pair = 1; a.C2 = b.C; a.pair_threads = ctx->pair_threads;
+                a.C.items = a.C2.items = kPairSlots / ctx->pair_threads;
                 int lanes = 1;
                 while (lanes < 2 * (R + 1)) lanes <<= 1;
                 a.C.lanes = lanes;
