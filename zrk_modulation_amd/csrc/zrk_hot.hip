@@ -1138,6 +1138,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) voi
         // is swept here all the same -- its thread cannot know; see SweepParams::t2 for who puts that right.)
         uint32_t mask2 = 0u;
         if (c2.cand) sweep_rows<PHILOX>(P.tick + 1, P.gid0, rbp2, seed, c2, li, live, x2, y2, z2, mask2, wave);
+        ZRK_WAVE_PROBE(wave, 4, wall_clock64());              // (pair: slot 4 is the end of the second tick's radar loop)
         if (live) { P.pos_prev[i] = x2; P.pos_prev[cap + i] = y2; P.pos_prev[2 * cap + i] = z2; }
         if (i < P.n && (mask2 || !(P.flags & kSparseVis2))) P.vis2[li] = mask2;
     }
