@@ -271,9 +271,10 @@ int64_t zrk_ccp_scratch_bytes(int64_t D, int64_t T);
  *   Launchers in dictionary order (at most 64): try_to_launch_missile takes the nearest one with launched < capacity.
  *   Output per detection d (= seq[d]): verdict 0 new / 1 old target / 2 old missile, the matched track's index within its
  * array (-1), the launcher the request goes to (-1); count[0] = detections, count[1] = launch requests; status 0 ok,
- * 1 the order-dependent part did not settle in `rounds` rounds (2-3 in practice; nothing was applied wrongly -- call again
- * is not supported: give it more), 2 a target track's handle has no prev_pos (the reference raises there), 3 track
- * capacity exhausted.  The order-dependent part is resolved in rounds that end themselves on a device flag.
+ * 2 a target track's handle has no prev_pos (the reference raises there), 3 track capacity exhausted (1 is not returned any
+ * more).  The order-dependent part is resolved in at most `rounds` parallel rounds that end themselves on a device flag
+ * (2-3 in practice); what a long chain of detections waiting for each other leaves unresolved after them, one workgroup
+ * settles in detection order, so the step always ends decided.
  */
 typedef struct {
     int64_t capacity;               /* tracks that fit each array */

@@ -79,7 +79,7 @@ def test_command_post_with_device_association_sends_what_the_host_loop_sends(mon
         mgr, _ = create_objects_from_config(cfg, device="cuda:0")
         mgr.run_simulation(1500)
         post = [m for m in mgr.modules if type(m).__name__ == "CombatControlPoint"][0]
-        assert (post.device_ticks == 0) if host else (post.device_ticks >= 10), post.device_ticks
+        assert (post.device_ticks == 0) if host else (post.device_ticks >= 10), (post.device_ticks, post.host_ticks)
         out = []
         for step in sorted(mgr.messages):
             for m in mgr.messages[step]:

@@ -1359,6 +1359,40 @@ __device__ __forceinline__ unsigned long long agg_load(const unsigned long long 
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Sum of counter c over the records [a0, a1) of `ra` and then [b0, b1) of `rb` (either range may be empty), as one run of
+// loads: record q of the run is dealt to the threads p_step apart, kBatch loads in flight per thread, each waited for until
+// it carries this launch's epoch.
+template <int STRIDE>
+__device__ __forceinline__ int sum_epoch_records(const unsigned long long *ra, int a0, int a1, const unsigned long long *rb, int b0, int b1,
+                                                 int c, int p_first, int p_step, uint32_t epoch, bool &timed_out)
+{
+    constexpr int kBatch = 8;
+    const int na = a1 - a0, total = na + (b1 - b0);
+    int acc = 0;
+    for (int q0 = p_first; q0 < total; q0 += p_step * kBatch) {
+        unsigned long long v[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int q = q0 + u * p_step;
+            const unsigned long long *w = q < na ? ra + (int64_t)(a0 + q) * STRIDE + c : rb + (int64_t)(b0 + q - na) * STRIDE + c;
+            v[u] = (q < total) ? agg_load(w) : ((unsigned long long)epoch << 32);
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int q = q0 + u * p_step;
+            const unsigned long long *w = q < na ? ra + (int64_t)(a0 + q) * STRIDE + c : rb + (int64_t)(b0 + q - na) * STRIDE + c;
+            int spins = 0;
+            while ((uint32_t)(v[u] >> 32) != epoch) {
+                if (++spins > kSpinLimit) { timed_out = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+                v[u] = agg_load(w);
+            }
+            acc += (int)(uint32_t)v[u];
+        }
+    }
+    return acc;
+}
+
 struct CompactArgs {
     const uint32_t *vis;           // NULL: nothing to compact
     uint32_t *zero_next;
@@ -1378,6 +1412,10 @@ struct CompactArgs {
     // of scenario s writes to det_idx[(s * R + r) * det_stride ...], counts to det_cnt[s * (R + 1) + r]; 0: one list
     int32_t seg_blocks, zero_own;  // zero_own: zero_next is `vis` itself, all zero but for the detections
     int64_t seg_slots;
+    // two-level sums (0: every workgroup adds up all lower records): the last ticket of every `group` consecutive ones also
+    // publishes the group's totals (behind the records, at agg + kFusedMaxBlocks * kAggStride), and a workgroup adds up the
+    // lower records of its own group and the totals of the groups before it: group + nb / group words instead of nb
+    int32_t group;
 };
 
 template <int THREADS>
@@ -1385,6 +1423,7 @@ struct CompactShared {
     int wcnt[kFusedMaxItems * (THREADS / 64)];
     int cnt[ZRK_MAX_RADARS + 1];
     int pre[ZRK_MAX_RADARS + 1];
+    int grp[ZRK_MAX_RADARS + 1];
     int ticket, found;
     unsigned short idx[kFusedMaxItems * THREADS];  // detected slots of this workgroup, in list order ...
     uint32_t msk[kFusedMaxItems * THREADS];        // ... and their masks
@@ -1397,7 +1436,7 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) S.ticket = by_ticket ? atomicAdd(&C.ctl[0], 1) : (int)blockIdx.x;
-    if (tid <= ZRK_MAX_RADARS) S.pre[tid] = 0;
+    if (tid <= ZRK_MAX_RADARS) S.pre[tid] = S.grp[tid] = 0;
     __syncthreads();
     const int b = S.ticket;
     if (b < 0 || b >= C.nb) {                        // a workspace that was not ours: refuse rather than scribble
@@ -1484,35 +1523,32 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     {
         // lower tickets: record p, counter c is word p * C.lanes + c of a (p, c) grid dealt out to the
-        // threads THREADS apart (C.lanes: a power of two >= C.R+1), kBatch loads in flight per thread
-        constexpr int kBatch = 8;
+        // threads THREADS apart (C.lanes: a power of two >= C.R+1)
         const int c = tid & (C.lanes - 1);
         const int p_first = tid / C.lanes, p_step = THREADS / C.lanes;
-        int acc = 0;
+        const int G = C.group, g = G ? b / G : 0, gs = g * G;
+        const unsigned long long *gagg = C.agg + (int64_t)kFusedMaxBlocks * kAggStride;
         bool timed_out = false;
-        if (c <= C.R) {
-            for (int p0 = first + p_first; p0 < b; p0 += p_step * kBatch) {
-                unsigned long long v[kBatch];
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    const int p = p0 + u * p_step;
-                    v[u] = (p < b) ? agg_load(&C.agg[(int64_t)p * kAggStride + c]) : ((unsigned long long)C.epoch << 32);
-                }
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    const int p = p0 + u * p_step;
-                    int spins = 0;
-                    while ((uint32_t)(v[u] >> 32) != C.epoch) {
-                        if (++spins > kSpinLimit) { timed_out = true; break; }
-                        __builtin_amdgcn_s_sleep(1);
-                        v[u] = agg_load(&C.agg[(int64_t)p * kAggStride + c]);
-                    }
-                    acc += (int)(uint32_t)v[u];
-                }
+        if (G && b - gs == G - 1) {                   // the group's last ticket: its totals first, they wait for nobody before the group
+            if (c <= C.R) {
+                const int in = sum_epoch_records<kAggStride>(C.agg, gs, b, gagg, 0, 0, c, p_first, p_step, C.epoch, timed_out);
+                if (in) { atomicAdd(&S.grp[c], in); atomicAdd(&S.pre[c], in); }
             }
+            __syncthreads();
+            if (tid <= C.R)
+                __hip_atomic_store(const_cast<unsigned long long *>(gagg) + (int64_t)g * kAggStride + tid,
+                                   ((unsigned long long)C.epoch << 32) | (uint32_t)(S.grp[tid] + S.cnt[tid]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (c <= C.R) {
+                const int acc = sum_epoch_records<kAggStride>(C.agg, 0, 0, gagg, 0, g, c, p_first, p_step, C.epoch, timed_out);
+                if (acc) atomicAdd(&S.pre[c], acc);
+            }
+        } else if (c <= C.R) {
+            const int acc = G ? sum_epoch_records<kAggStride>(C.agg, gs, b, gagg, 0, g, c, p_first, p_step, C.epoch, timed_out)
+                              : sum_epoch_records<kAggStride>(C.agg, first, b, gagg, 0, 0, c, p_first, p_step, C.epoch, timed_out);
             if (acc) atomicAdd(&S.pre[c], acc);
-            if (timed_out) atomicExch(&C.ctl[2], 2);
         }
+        if (timed_out) atomicExch(&C.ctl[2], 2);
     }
     __syncthreads();
     ZRK_PROBE(4);
@@ -1708,6 +1744,7 @@ struct CompactSharedPair {
     int wcnt[2][64];                                                  // (item, wave) counts: kPairSlots / 64 of them
     int cnt[2][ZRK_MAX_RADARS + 1];
     int pre[2 * (ZRK_MAX_RADARS + 1)];
+    int grp[2 * (ZRK_MAX_RADARS + 1)];
     int ticket, found[2];
     unsigned short idx[2][kPairSlots];
     uint32_t msk[2][kPairSlots];
@@ -1720,7 +1757,7 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
     constexpr int WAVES = THREADS / 64, kItems = kPairSlots / THREADS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) S.ticket = atomicAdd(&C0.ctl[0], 1);
-    if (tid < 2 * (ZRK_MAX_RADARS + 1)) S.pre[tid] = 0;
+    if (tid < 2 * (ZRK_MAX_RADARS + 1)) S.pre[tid] = S.grp[tid] = 0;
     __syncthreads();
     const int b = S.ticket;
     if (b < 0 || b >= C0.nb) {                       // a workspace that was not ours: refuse rather than scribble
@@ -1837,35 +1874,33 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
                            __HIP_MEMORY_SCOPE_AGENT);
     {
         // lower tickets: record p, counter c is word p * lanes + c of a (p, c) grid dealt out to the threads
-        constexpr int kBatch = 8;
         const int lanes = C0.lanes;                  // a power of two >= nctr
         const int c = tid & (lanes - 1);
         const int p_first = tid / lanes, p_step = THREADS / lanes;
-        int acc = 0;
+        const int G = C0.group, g = G ? b / G : 0, gs = g * G;
+        const unsigned long long *gagg = C0.agg + (int64_t)kFusedMaxBlocks * kAggStride;
+        const uint32_t epoch = C0.epoch;
         bool timed_out = false;
-        if (c < nctr) {
-            for (int p0 = p_first; p0 < b; p0 += p_step * kBatch) {
-                unsigned long long v[kBatch];
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    const int p = p0 + u * p_step;
-                    v[u] = (p < b) ? agg_load(&C0.agg[(int64_t)p * kPairAggStride + c]) : ((unsigned long long)C0.epoch << 32);
-                }
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    const int p = p0 + u * p_step;
-                    int spins = 0;
-                    while ((uint32_t)(v[u] >> 32) != C0.epoch) {
-                        if (++spins > kSpinLimit) { timed_out = true; break; }
-                        __builtin_amdgcn_s_sleep(1);
-                        v[u] = agg_load(&C0.agg[(int64_t)p * kPairAggStride + c]);
-                    }
-                    acc += (int)(uint32_t)v[u];
-                }
+        if (G && b - gs == G - 1) {                   // the group's last ticket: its totals first (see compact_block)
+            if (c < nctr) {
+                const int in = sum_epoch_records<kPairAggStride>(C0.agg, gs, b, gagg, 0, 0, c, p_first, p_step, epoch, timed_out);
+                if (in) { atomicAdd(&S.grp[c], in); atomicAdd(&S.pre[c], in); }
             }
+            __syncthreads();
+            if (tid < nctr)
+                __hip_atomic_store(const_cast<unsigned long long *>(gagg) + (int64_t)g * kPairAggStride + tid,
+                                   ((unsigned long long)epoch << 32) | (uint32_t)(S.grp[tid] + S.cnt[tid / (R + 1)][tid % (R + 1)]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c < nctr) {
+                const int acc = sum_epoch_records<kPairAggStride>(C0.agg, 0, 0, gagg, 0, g, c, p_first, p_step, epoch, timed_out);
+                if (acc) atomicAdd(&S.pre[c], acc);
+            }
+        } else if (c < nctr) {
+            const int acc = G ? sum_epoch_records<kPairAggStride>(C0.agg, gs, b, gagg, 0, g, c, p_first, p_step, epoch, timed_out)
+                              : sum_epoch_records<kPairAggStride>(C0.agg, 0, b, gagg, 0, 0, c, p_first, p_step, epoch, timed_out);
             if (acc) atomicAdd(&S.pre[c], acc);
-            if (timed_out) atomicExch(&C0.ctl[2], 2);
         }
+        if (timed_out) atomicExch(&C0.ctl[2], 2);
     }
     __syncthreads();
 #pragma unroll
@@ -2735,7 +2770,57 @@ __global__ void k_ccp_count_new(const CcpStepArgs A)
     A.trk.counts[0] = A.sizes[2] + A.sizes[3];                      // the new targets' tracks stand behind the old ones
 }
 
-// the rounds are over: not everybody resolved within the bound -> status 1 (the caller gives it more rounds)
+// The rounds are over and somebody is still unresolved (a long chain of detections each waiting for the one before it: every
+// round settles only its head): ONE workgroup walks the unresolved detections in order, as the reference's loop does, with
+// the scan over the tracks spread over its threads -- the strictly nearest free track in the annulus, the earlier track
+// among equals.  What the rounds gave away stays given (nobody earlier could have claimed it).  Bounded and exact, so the
+// step never ends undecided; the rounds are what makes the common case parallel.
+__global__ __launch_bounds__(1024) void k_ccp_tail(const CcpStepArgs A, uint8_t *taken, int32_t *match, uint8_t *state, int32_t *counters)
+{
+    __shared__ double s_dist[16];
+    __shared__ int s_trk[16];
+    if (counters[3] != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = A.sizes[0], T = A.sizes[1];
+    for (int d = 0; d < D; ++d) {
+        if (state[d] == 1) continue;
+        const double px = A.det_pos[3 * d], py = A.det_pos[3 * d + 1], pz = A.det_pos[3 * d + 2], sp = A.det_speed[d];
+        double best = __builtin_inf();
+        int who = 0x7FFFFFFF;
+        for (int t = tid; t < T; t += 1024) {
+            const double upd = A.trk_upd[t];
+            if (upd == A.now_s || taken[t]) continue;
+            const double dx = A.trk_ref[3 * t] - px, dy = A.trk_ref[3 * t + 1] - py, dz = A.trk_ref[3 * t + 2] - pz;
+            const double dist = sqrt(dot3(dx, dy, dz, dx, dy, dz));
+            const double age = A.now_s - upd;
+            double lo = sp * (age - A.slack_s), hi = sp * (age + A.slack_s);
+            lo = (lo > 0.0) ? lo : 0.0; hi = (hi > 0.0) ? hi : 0.0;
+            if (!(lo <= dist && dist <= hi)) continue;
+            if (dist < best) { best = dist; who = t; }
+        }
+#pragma unroll
+        for (int off = 32; off; off >>= 1) {
+            const double ob = __shfl_xor(best, off);
+            const int ow = __shfl_xor(who, off);
+            if (ob < best || (ob == best && ow < who)) { best = ob; who = ow; }
+        }
+        if (lane == 0) { s_dist[wave] = best; s_trk[wave] = who; }
+        __syncthreads();
+        best = s_dist[0]; who = s_trk[0];
+        for (int w = 1; w < 16; ++w)
+            if (s_dist[w] < best || (s_dist[w] == best && s_trk[w] < who)) { best = s_dist[w]; who = s_trk[w]; }
+        if (tid == 0) {
+            const int32_t kx = A.kill[d];
+            if (who != 0x7FFFFFFF) { match[d] = who; taken[who] = 1; }
+            else { match[d] = -1; if (kx >= 0) taken[kx] = 1; }
+            state[d] = 1;
+        }
+        __syncthreads();                             // (the track is gone before anybody scans for the next detection)
+    }
+    if (tid == 0) counters[3] = 1;
+}
+
+// the rounds are over: not everybody resolved -> status 1 (cannot happen behind k_ccp_tail; kept as the check that it ran)
 __global__ void k_ccp_finish(const int32_t *counters, int32_t *status)
 {
     if (counters[3] == 0) atomicMax(status, 1);
@@ -2979,6 +3064,7 @@ struct zrk_ctx {
     bool order_enabled = true;
     int env_items = 0;                 // ZRK_COMPACT_ITEMS (0: automatic), read once: getenv per launch costs microseconds
     int env_order = -1;                // ZRK_COMPACT_ORDER: 0 "block", 1 anything else, -1 automatic
+    int env_group = -1;                // ZRK_COMPACT_GROUP: 0 flat sums, a power of two <= 32 the group size, -1 automatic
     uint32_t diag = 0;                 // ZRK_DIAG: bit 0 no "certainly visible" shortcut, bit 1 no box records
     bool time_on_dispatch = true;      // ZRK_TIME_BY_RECORDS=1: time sweeps between two recorded events instead
     const void *box_ws = nullptr;      // workspace whose box records belong to ...
@@ -3112,6 +3198,10 @@ ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
     { const char *v = std::getenv("ZRK_PAIR_THREADS"); const int t = v ? std::atoi(v) : 1024; c->pair_threads = (t == 256 || t == 512) ? t : 1024; }
     if (const char *v = std::getenv("ZRK_COMPACT_ITEMS")) c->env_items = std::max(1, std::atoi(v));
     if (const char *v = std::getenv("ZRK_COMPACT_ORDER")) c->env_order = std::strcmp(v, "block") != 0;
+    if (const char *v = std::getenv("ZRK_COMPACT_GROUP")) {
+        const long k = std::strtol(v, nullptr, 10);
+        c->env_group = (k == 0 || k == 4 || k == 8 || k == 16 || k == 32) ? (int)k : -1;
+    }
     c->fused_max_blocks = kFusedMaxBlocks;
     if (const char *v = std::getenv("ZRK_COMPACT_FUSED_MAX_BLOCKS")) {     // 0 = always the three-launch path
         const long k = std::strtol(v, nullptr, 10);
@@ -3396,6 +3486,10 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         C.bits = U;
         C.seg_blocks = ens ? (int32_t)(ens->rows_ps / ((int64_t)kCompBlock * items)) : 0;
         C.zero_own = (zero_next == vis_mask) ? 1 : 0;
+        // (one scenario only: a batched ensemble's lists restart per scenario.  The group records live in the half of the
+        // record space that only a pair compaction's wider records reach, and those stop at kFusedMaxBlocks / 2 workgroups.)
+        C.group = (!ens && nbf > 64) ? 32 : 0;
+        if (!ens && ctx->env_group >= 0) C.group = ctx->env_group;
         C.seg_slots = ens ? ens->rows_ps : 0;
         EnsembleArgs E;
         std::memset(&E, 0, sizeof(E));
@@ -3683,6 +3777,7 @@ ZRK_API int zrk_ccp_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const dou
         hipLaunchKernelGGL(k_ccp_candidates, dim3(gd), dim3(256), 0, s, A.det_pos, A.det_speed, dmax, A.trk_ref, A.trk_upd, T, now_s, slack_s,
                            (const uint8_t *)taken, (const uint8_t *)only, cand, (const int32_t *)A.sizes, (const int32_t *)(counters + 4));
     }
+    hipLaunchKernelGGL(k_ccp_tail, dim3(1), dim3(1024), 0, s, A, taken, match, state, counters);
     hipLaunchKernelGGL(k_ccp_finish, dim3(1), dim3(1), 0, s, counters, out->status);
     hipLaunchKernelGGL(k_ccp_scan, dim3(1), dim3(1024), 0, s, A, (const int32_t *)match);
     hipLaunchKernelGGL(k_ccp_launch, dim3(1), dim3(64), 0, s, A);
@@ -4674,6 +4769,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                 int lanes = 1;
                 while (lanes < 2 * (R + 1)) lanes <<= 1;
                 a.C.lanes = lanes;
+                a.C.group = a.C.nb > 32 ? 16 : 0;          // (half as many records per batch of loads as the single compaction)
+                if (ctx->env_group >= 0) a.C.group = ctx->env_group;
                 a.stream = side_stream; a.flag_value = ++sd->seq; a.done_slot = slot_t[0]; a.done_slot2 = slot_t[1];
                 a.M = M; a.M.apply = 0; a.M.clear_vis = nullptr;
                 if (fused) {                               // the first tick's ordered events: a list of the context's own

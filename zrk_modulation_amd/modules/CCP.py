@@ -66,6 +66,7 @@ class CombatControlPoint(BaseModel):
         self.missile_launcher_capacity = {}
         self.initialized = False
         self.device_ticks = 0           # ticks whose detection loop ran on the device (zrk_ccp_step)
+        self.host_ticks = {}            # ... and why the others went through the host loop: reason -> ticks
         self._post = None               # the dictionaries' mirror on the device (association.DeviceCommandPost), made on first use
         self._post_stale = True         # the host changed a dictionary behind its back: rebuilt from the dictionaries
 
@@ -195,17 +196,20 @@ class CombatControlPoint(BaseModel):
         import os
         import torch
         from ..association import DeviceCommandPost
-        if os.environ.get("ZRK_CCP_HOST") or not dets:
+        def host(why):
+            self.host_ticks[why] = self.host_ticks.get(why, 0) + 1
             return False
+        if os.environ.get("ZRK_CCP_HOST") or not dets:
+            return host("forced" if dets else "no detections")
         store = getattr(found_msgs[0], "device_store", None)
         if store is None or any(getattr(m, "device_store", None) is not store for m in found_msgs):
-            return False
+            return host("no device table")
         if any(getattr(o, "_store", None) is not store or o._frozen is not None for o, _ in dets):
-            return False
+            return host("object outside the table")
         now_s = self._now_s()
         ml_ids = list(self.missile_launcher_coords)
         if len(ml_ids) > 64:
-            return False
+            return host("launchers")
         # the detections of the tick in processing order, each row once (:414), from the radars' device lists
         seq_all = torch.cat([m.device_rows for m in found_msgs]).to(torch.int64)
         pos_in_seq = torch.arange(seq_all.numel(), device=seq_all.device)
@@ -213,7 +217,7 @@ class CombatControlPoint(BaseModel):
         first.scatter_reduce_(0, seq_all, pos_in_seq, "amin")
         seq = seq_all[first[seq_all] == pos_in_seq].to(torch.int32).contiguous()
         if seq.numel() != len(dets):
-            return False
+            return host("row lists")
         cnt = torch.tensor([seq.numel()], dtype=torch.int32, device=seq.device)
         # the mirror of the dictionaries: made, or rebuilt when the host changed them (missiles entering, deletions)
         cap = max(2 * store.cap, 64)
@@ -226,7 +230,7 @@ class CombatControlPoint(BaseModel):
         for o, _ in dets:
             self._post_speed[o._slot] = o.speed_mod
         if self._post_stale and not self._mirror_dictionaries(post, store, now_s):
-            return False
+            return host("mirror")
         if ml_ids:
             post.l_cap.copy_(torch.tensor([self.missile_launcher_capacity[k] for k in ml_ids], dtype=torch.int32))
             post.l_launched.copy_(torch.tensor([self.missile_launcher_launched[k] for k in ml_ids], dtype=torch.int32))
@@ -235,9 +239,9 @@ class CombatControlPoint(BaseModel):
         post.step(store.ents, store.cur, speed, seq, cnt, now_s, slack)
         try:
             rows, verdict, match, launcher = post.results()
-        except Exception:
+        except Exception as e:
             self._post_stale = True          # (nothing applied on the host: the host loop takes the tick)
-            return False
+            return host(f"step: {e}")
         t_keys, m_keys = list(self._target_dict), list(self._missile_dict)
         for d, (obj, radar_id) in enumerate(dets):
             assert int(rows[d]) == obj._slot
@@ -273,11 +277,15 @@ class CombatControlPoint(BaseModel):
         dev = post.dev
         i32 = lambda xs: torch.tensor(list(xs), dtype=torch.int32, device=dev)         # noqa: E731
         nt, nm = len(t_tracks), len(m_tracks)
-        slot_of_id = {h.id: h._slot for h in handles}
+        # (a key may name an object no track holds any more -- replaced in place, :88-93 -- or one that has left the air: the
+        # table still knows its row, and rows are never given out twice)
+        def slot_of(obj_id):
+            rows = store.slots_for_id(obj_id)
+            return int(rows[0]) if len(rows) else -1
         post.key_tt.fill_(-1)
         post.tt_ref_fixed.fill_(float("nan")); post.tm_ref_fixed.fill_(float("nan"))
         if nt:
-            keys = [slot_of_id.get(k, -1) for k in self._target_dict]
+            keys = [slot_of(k) for k in self._target_dict]
             if min(keys) < 0:
                 return False
             post.tt_key[:nt] = i32(keys); post.tt_obj[:nt] = i32(tr.target._slot for tr in t_tracks)
@@ -285,7 +293,7 @@ class CombatControlPoint(BaseModel):
             post.tt_follow[:nt] = torch.tensor([1 if tr.following else 0 for tr in t_tracks], dtype=torch.uint8, device=dev)
             post.key_tt[torch.tensor(keys, dtype=torch.int64, device=dev)] = torch.arange(nt, dtype=torch.int32, device=dev)
         if nm:
-            post.tm_key[:nm] = i32(slot_of_id.get(k, -1) for k in self._missile_dict)
+            post.tm_key[:nm] = i32(slot_of(k) for k in self._missile_dict)
             post.tm_obj[:nm] = i32(tr.missile._slot for tr in m_tracks)
             post.tm_upd[:nm] = torch.tensor([tr.upd_time for tr in m_tracks], dtype=torch.float64, device=dev)
         # tracks whose object has left the air: what the handle still holds as prev_pos (the table has lost it)
