@@ -33,8 +33,8 @@ def _same(a, b, what):
 
 
 @pytest.mark.parametrize("n,R,m,noise", [(40_000, 6, 300, "philox"), (40_000, 6, 300, "off"), (3_000, 16, 0, "philox"),
-                                         (700_000, 5, 2_000, "philox")],
-                         ids=["mid", "mid-no-noise", "small-no-missiles", "multi-round-grid"])
+                                         (700_000, 5, 2_000, "philox"), (2_600_000, 4, 1_000, "philox")],
+                         ids=["mid", "mid-no-noise", "small-no-missiles", "multi-round-grid", "pair-compaction-of-635-workgroups"])
 def test_overlapped_loop_leaves_what_the_tick_by_tick_loop_leaves(n, R, m, noise, monkeypatch):
     from tests.test_gpu_engine import _engine
     monkeypatch.setenv("ZRK_OVERLAP_MIN_ROWS", "0")           # (by default only tables of 4e5 rows or more overlap)

@@ -1349,6 +1349,8 @@ __global__ __launch_bounds__(kCompBlock) void k_scatter(const uint32_t *__restri
 constexpr int kFusedMaxItems = 8;                // list slots per thread
 constexpr int kFusedMaxBlocks = 1024;
 constexpr int kAggStride = 40;                   // 64-bit words per workgroup record (>= ZRK_MAX_RADARS + 1)
+constexpr int kGroupOffset = kFusedMaxBlocks * 2 * kAggStride;   // the group records' place behind the widest records (words)
+constexpr int kMinGroup = 4;
 constexpr int kFusedCtlInts = 64;                // ticket, done, error, padding
 constexpr int kSpinLimit = 1 << 22;
 
@@ -1413,7 +1415,7 @@ struct CompactArgs {
     int32_t seg_blocks, zero_own;  // zero_own: zero_next is `vis` itself, all zero but for the detections
     int64_t seg_slots;
     // two-level sums (0: every workgroup adds up all lower records): the last ticket of every `group` consecutive ones also
-    // publishes the group's totals (behind the records, at agg + kFusedMaxBlocks * kAggStride), and a workgroup adds up the
+    // publishes the group's totals (behind the records, at agg + kGroupOffset), and a workgroup adds up the
     // lower records of its own group and the totals of the groups before it: group + nb / group words instead of nb
     int32_t group;
 };
@@ -1527,7 +1529,7 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
         const int c = tid & (C.lanes - 1);
         const int p_first = tid / C.lanes, p_step = THREADS / C.lanes;
         const int G = C.group, g = G ? b / G : 0, gs = g * G;
-        const unsigned long long *gagg = C.agg + (int64_t)kFusedMaxBlocks * kAggStride;
+        const unsigned long long *gagg = C.agg + kGroupOffset;
         bool timed_out = false;
         if (G && b - gs == G - 1) {                   // the group's last ticket: its totals first, they wait for nobody before the group
             if (c <= C.R) {
@@ -1878,7 +1880,7 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
         const int c = tid & (lanes - 1);
         const int p_first = tid / lanes, p_step = THREADS / lanes;
         const int G = C0.group, g = G ? b / G : 0, gs = g * G;
-        const unsigned long long *gagg = C0.agg + (int64_t)kFusedMaxBlocks * kAggStride;
+        const unsigned long long *gagg = C0.agg + kGroupOffset;
         const uint32_t epoch = C0.epoch;
         bool timed_out = false;
         if (G && b - gs == G - 1) {                   // the group's last ticket: its totals first (see compact_block)
@@ -3104,7 +3106,8 @@ struct zrk_ctx {
     uint32_t rb_cache_flags[2] = {0, 0};
     bool pair_enabled = true;          // ZRK_PAIR=0: one tick per launch in the overlapped loop
     bool pair_compact = true;          // ZRK_PAIR_COMPACT=0: a pair's two compactions as two launches
-    int pair_threads = 1024;           // ZRK_PAIR_THREADS=256|512|1024: workgroup size of k_compact_pair
+    int pair_compact_blocks = kFusedMaxBlocks;   // ... beyond this many workgroups too (ZRK_PAIR_COMPACT_BLOCKS, <= kFusedMaxBlocks)
+    int pair_threads = 0;              // ZRK_PAIR_THREADS=256|512|1024: workgroup size of k_compact_pair (0: by the number of workgroups)
     int last_ticks_per_launch = 1;     // of the last zrk_run_ticks* call
     std::vector<int> tev_alias, tev_ticks;   // per timing sample: which event pair holds it, and the ticks its launch swept
     bool tail_by_event = true;         // ZRK_TAIL_EVENT=0: the last compaction of a call is released by a launch that raises the host word
@@ -3137,7 +3140,8 @@ struct Workspace {
 };
 
 constexpr int64_t kFusedBytes = kFusedCtlInts * (int64_t)sizeof(int32_t) +
-                                (int64_t)kFusedMaxBlocks * kPairAggStride * (int64_t)sizeof(unsigned long long);
+                                ((int64_t)kFusedMaxBlocks * kPairAggStride + (int64_t)(kFusedMaxBlocks / kMinGroup) * kPairAggStride) *
+                                    (int64_t)sizeof(unsigned long long);
 
 inline int64_t order_ints(int64_t n) { return ((n + ZRK_BLOCK - 1) / ZRK_BLOCK + 64) & ~(int64_t)63; }
 inline int64_t box_ints(int64_t n) { return ((((n + ZRK_BLOCK - 1) / ZRK_BLOCK + 4) * (int64_t)(sizeof(WaveBox) / 4)) + 63) & ~(int64_t)63; }
@@ -3195,12 +3199,14 @@ ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
     { const char *v = std::getenv("ZRK_TAIL_EVENT"); c->tail_by_event = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_PAIR"); c->pair_enabled = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_PAIR_COMPACT"); c->pair_compact = !(v && v[0] == '0'); }
-    { const char *v = std::getenv("ZRK_PAIR_THREADS"); const int t = v ? std::atoi(v) : 1024; c->pair_threads = (t == 256 || t == 512) ? t : 1024; }
+    if (const char *v = std::getenv("ZRK_PAIR_COMPACT_BLOCKS"))
+        c->pair_compact_blocks = (int)std::min<long>(std::max<long>(std::strtol(v, nullptr, 10), 0), kFusedMaxBlocks);
+    { const char *v = std::getenv("ZRK_PAIR_THREADS"); const int t = v ? std::atoi(v) : 0; c->pair_threads = (t == 256 || t == 512 || t == 1024) ? t : 0; }
     if (const char *v = std::getenv("ZRK_COMPACT_ITEMS")) c->env_items = std::max(1, std::atoi(v));
     if (const char *v = std::getenv("ZRK_COMPACT_ORDER")) c->env_order = std::strcmp(v, "block") != 0;
     if (const char *v = std::getenv("ZRK_COMPACT_GROUP")) {
         const long k = std::strtol(v, nullptr, 10);
-        c->env_group = (k == 0 || k == 4 || k == 8 || k == 16 || k == 32) ? (int)k : -1;
+        c->env_group = (k == 0 || k == kMinGroup || k == 8 || k == 16 || k == 32) ? (int)k : -1;
     }
     c->fused_max_blocks = kFusedMaxBlocks;
     if (const char *v = std::getenv("ZRK_COMPACT_FUSED_MAX_BLOCKS")) {     // 0 = always the three-launch path
@@ -3486,8 +3492,7 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         C.bits = U;
         C.seg_blocks = ens ? (int32_t)(ens->rows_ps / ((int64_t)kCompBlock * items)) : 0;
         C.zero_own = (zero_next == vis_mask) ? 1 : 0;
-        // (one scenario only: a batched ensemble's lists restart per scenario.  The group records live in the half of the
-        // record space that only a pair compaction's wider records reach, and those stop at kFusedMaxBlocks / 2 workgroups.)
+        // (one scenario only: a batched ensemble's lists restart per scenario)
         C.group = (!ens && nbf > 64) ? 32 : 0;
         if (!ens && ctx->env_group >= 0) C.group = ctx->env_group;
         C.seg_slots = ens ? ens->rows_ps : 0;
@@ -4683,7 +4688,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         // the two compactions of the pair as ONE launch, where the table allows it (k_compact_pair)
         // (up to 512 workgroups: beyond, beside a sweep of that size, two launches of half as many fatter workgroups are faster
         // -- 89 against 94 us per tick at 4e6 rows)
-        bool pc = nt == 2 && ctx->pair_compact && st->n <= (int64_t)kPairItems * kCompBlock * (kFusedMaxBlocks / 2);
+        bool pc = nt == 2 && ctx->pair_compact && st->n <= (int64_t)kPairItems * kCompBlock * ctx->pair_compact_blocks;
         if (pc && det_idx && sd->scratch_det_ints < (int64_t)R * det_stride) {
             if (sd->scratch_det) (void)hipFree(sd->scratch_det);
             sd->scratch_det = nullptr; sd->scratch_det_ints = 0;
@@ -4764,12 +4769,14 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             for (int j = 0; j < 2 && rc == 0 && ev_words && !fused; ++j)     // (no missiles: an empty event list behind each list)
                 if (hipMemsetAsync(list_t[j] + list_words, 0, sizeof(int64_t), s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "memset events");
             if (rc == 0) {
-                a.pair = 1; a.C2 = b.C; a.pair_threads = ctx->pair_threads;
-                a.C.items = a.C2.items = kPairSlots / ctx->pair_threads;
+                // (workgroups of 1024 threads up to 512 of them; beyond, beside a sweep that keeps every compute unit full for
+                // longer, half-size ones find room sooner: C3x4 83 against 119 us/tick, C3 the other way round, 22.7 against 20.9)
+                a.pair = 1; a.C2 = b.C; a.pair_threads = ctx->pair_threads ? ctx->pair_threads : (a.C.nb > kFusedMaxBlocks / 2 ? 512 : 1024);
+                a.C.items = a.C2.items = kPairSlots / a.pair_threads;
                 int lanes = 1;
                 while (lanes < 2 * (R + 1)) lanes <<= 1;
                 a.C.lanes = lanes;
-                a.C.group = a.C.nb > 32 ? 16 : 0;          // (half as many records per batch of loads as the single compaction)
+                a.C.group = a.C.nb > 512 ? 32 : (a.C.nb > 32 ? 16 : 0);   // (half as many records per batch of loads as the single compaction)
                 if (ctx->env_group >= 0) a.C.group = ctx->env_group;
                 a.stream = side_stream; a.flag_value = ++sd->seq; a.done_slot = slot_t[0]; a.done_slot2 = slot_t[1];
                 a.M = M; a.M.apply = 0; a.M.clear_vis = nullptr;
