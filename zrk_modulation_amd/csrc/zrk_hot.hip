@@ -1675,13 +1675,31 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_fused(const CompactArgs 
     compact_block<kCompBlock>(S, C, by_ticket);
 }
 
+// The side stream's compactions tell the HOST which of them are over through a word in pinned memory: the first thread of
+// a compaction writes the number of the item BEFORE it -- launches of one stream run one after the other, so when this one
+// runs that one is over, its stores written back.  The loop's back-pressure (a mask buffer is free again when the
+// compaction that read it is over) then costs the side stream no packet of its own -- an event record behind every launch
+// held the next launch back by 2.8 us (tools/backtoback_probe.hip) -- and the waiting host thread no call into the runtime.
+// (Workgroups that count themselves out and a last one that tells the host would need an agent-scope release each, i.e. a
+// write-back of their XCD's L2 under the running sweep: measured, 75 instead of 21 us per tick.)
+struct DoneWord {
+    uint32_t *word;                // pinned host memory as the device addresses it; NULL: nobody asks
+    uint32_t value;
+};
+
+__device__ __forceinline__ void previous_launch_is_over(const DoneWord &dw)
+{
+    if (dw.word && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(dw.word, dw.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // The same for the overlapped loop's side stream: lists and (M.apply == 0) the ordered event list only.  An entry of its
 // own because of its arguments: the 9 KB of radar records that the entry above carries (unused there) made every launch
 // cost the side stream's thread 6-8 us, which is what bounded the loop.
-__global__ __launch_bounds__(kCompBlock) void k_compact_side(const CompactArgs C, int by_ticket, const MissileArgs M)
+__global__ __launch_bounds__(kCompBlock) void k_compact_side(const CompactArgs C, int by_ticket, const MissileArgs M, const DoneWord dw)
 {
     __shared__ int s_wave[kCompBlock / 64];
     __shared__ CompactShared<kCompBlock> S;
+    previous_launch_is_over(dw);
     if ((int)blockIdx.x >= C.nb) {
         if (M.m > 0 && (int)blockIdx.x == C.nb) missile_finish_entry(s_wave, M);
         return;
@@ -1968,10 +1986,11 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_compact_pair(const CompactArgs C0, const CompactArgs C1, const MissileArgs M0,
-                                                          const MissileArgs M1, const int32_t *rm, int rm_cap)
+                                                          const MissileArgs M1, const int32_t *rm, int rm_cap, const DoneWord dw)
 {
     __shared__ int s_wave[16];
     __shared__ CompactSharedPair S;
+    previous_launch_is_over(dw);
     if ((int)blockIdx.x >= C0.nb) {                  // two extra workgroups: the ticks' ordered event lists
         if (M0.m > 0) {
             if ((int)blockIdx.x == C0.nb) missile_events_any(s_wave, M0);
@@ -2980,7 +2999,12 @@ struct SideItem {
     // its own behind the compaction writes
     uint32_t *raise;
     uint32_t raise_value;
-    int done_slot;                  // done[done_slot] is recorded last
+    int done_slot;                  // the ring slot whose buffers this compaction reads (done[done_slot] is recorded last)
+    // the item's number (set by side_enqueue): its compaction's first thread writes done_value - 1 to the side stream's pinned
+    // word (DoneWord: the launch before it is over); record_event: an event behind the launch (the call's last items, which
+    // no launch follows: the compute stream takes the side stream in through it)
+    uint32_t done_value;
+    int record_event;
     // one helper thread per rank (few host cores per rank): this thread also issues the tick's collective, right behind
     // the launch that raises the word it waits for (otherwise the exchange's own thread does)
     // the LAST tick of a call has no next sweep to raise the word: its compaction waits, on the device, for an event recorded
@@ -3010,6 +3034,9 @@ struct Side {
     // cost the side stream 5 us a tick (a lone wave is slow to find a slot on a device full of sweep waves)
     volatile uint32_t *hflag = nullptr;
     uint32_t *hflag_dev = nullptr;  // the same word as the device addresses it
+    // ... and the word in which a compaction says that the one before it is over (item numbers, in launch order), 64 bytes on
+    volatile uint32_t *hdone = nullptr;
+    uint32_t *hdone_dev = nullptr;
     uint32_t seq = 0;
     // mask buffers of its own for all ticks of a call but the last (whose masks the caller may read): each is all zero
     // except between the sweep that writes it and the compaction that reads and clears it; slot kMasks stands for the
@@ -4215,24 +4242,30 @@ int side_issue(Side *sd, const SideItem &it)
     }
     if (!it.wait_event && (int32_t)(*sd->hflag - it.flag_value) < 0) { sd->err = "side stream: stopped"; return ZRK_E_STATE; }
     g_trace.mark("side: flag seen");
+    const DoneWord dw{sd->hdone_dev, it.done_value - 1u};
     if (it.pair) {
         const dim3 grid(it.C.nb + (it.M.m > 0 ? 2 : 0));
         if (it.pair_threads == 256)
-            hipLaunchKernelGGL(k_compact_pair<256>, grid, dim3(256), 0, it.stream, it.C, it.C2, it.M, it.M2, it.rm, it.rm_cap);
+            hipLaunchKernelGGL(k_compact_pair<256>, grid, dim3(256), 0, it.stream, it.C, it.C2, it.M, it.M2, it.rm, it.rm_cap, dw);
         else if (it.pair_threads == 512)
-            hipLaunchKernelGGL(k_compact_pair<512>, grid, dim3(512), 0, it.stream, it.C, it.C2, it.M, it.M2, it.rm, it.rm_cap);
+            hipLaunchKernelGGL(k_compact_pair<512>, grid, dim3(512), 0, it.stream, it.C, it.C2, it.M, it.M2, it.rm, it.rm_cap, dw);
         else
-            hipLaunchKernelGGL(k_compact_pair<1024>, grid, dim3(1024), 0, it.stream, it.C, it.C2, it.M, it.M2, it.rm, it.rm_cap);
+            hipLaunchKernelGGL(k_compact_pair<1024>, grid, dim3(1024), 0, it.stream, it.C, it.C2, it.M, it.M2, it.rm, it.rm_cap, dw);
     }
     else
-        hipLaunchKernelGGL(k_compact_side, dim3(it.C.nb + (it.M.m > 0 ? 1 : 0)), dim3(kCompBlock), 0, it.stream, it.C, it.by_ticket, it.M);
+        hipLaunchKernelGGL(k_compact_side, dim3(it.C.nb + (it.M.m > 0 ? 1 : 0)), dim3(kCompBlock), 0, it.stream, it.C, it.by_ticket, it.M, dw);
     // an exchange's collective (on the exchange's own stream) waits for this word: the list and its events are complete
     if (it.raise) hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, it.stream, it.raise, it.raise_value);
     if (hipGetLastError() != hipSuccess) { sd->err = "side stream: compaction launch failed"; return ZRK_E_HIP; }
-    if (hipEventRecord(sd->done[it.done_slot], it.stream) != hipSuccess) { sd->err = "side stream: hipEventRecord failed"; return ZRK_E_HIP; }
-    sd->done_of[it.done_slot] = sd->done[it.done_slot];
-    sd->posted[it.done_slot] = true;
-    if (it.pair) { sd->done_of[it.done_slot2] = sd->done[it.done_slot]; sd->posted[it.done_slot2] = true; }
+    if (it.record_event) {
+        if (hipEventRecord(sd->done[it.done_slot], it.stream) != hipSuccess) { sd->err = "side stream: hipEventRecord failed"; return ZRK_E_HIP; }
+        sd->done_of[it.done_slot] = sd->done[it.done_slot];
+        sd->posted[it.done_slot] = true;
+        if (it.pair) { sd->done_of[it.done_slot2] = sd->done[it.done_slot]; sd->posted[it.done_slot2] = true; }
+    } else {
+        sd->posted[it.done_slot] = false;
+        if (it.pair) sd->posted[it.done_slot2] = false;
+    }
     g_trace.mark("side: compaction issued");
     if (it.post_x && exchange_post_behind_flag(it.post_x, it.post_slot, it.post_send, it.post_recv, it.post_words, it.raise_value) != 0) {
         sd->err = std::string("side stream: ") + it.post_x->err;
@@ -4301,9 +4334,9 @@ Side *side_of(zrk_ctx *ctx)
     bool ok = (made || hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking) == hipSuccess) &&
               hipEventCreateWithFlags(&sd->last_sweep, hipEventDisableTiming) == hipSuccess &&
               hipMalloc((void **)&sd->bar, 64) == hipSuccess && hipMemset(sd->bar, 0, 64) == hipSuccess &&
-              hipHostMalloc((void **)&sd->hflag, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+              hipHostMalloc((void **)&sd->hflag, 128, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
               hipHostGetDevicePointer((void **)&sd->hflag_dev, (void *)sd->hflag, 0) == hipSuccess;
-    if (ok) *sd->hflag = 0u;
+    if (ok) { *sd->hflag = 0u; sd->hdone = sd->hflag + 16; sd->hdone_dev = sd->hflag_dev + 16; *sd->hdone = 0u; }
     for (int k = 0; k <= Side::kMasks && ok; ++k) ok = hipEventCreateWithFlags(&sd->done[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
@@ -4326,6 +4359,7 @@ int side_enqueue(zrk_ctx *ctx, Side *sd, const SideItem &it)
     if (!spin_until([&] { return h - sd->tail.load(std::memory_order_acquire) < Side::kRing; }))
         return fail(ctx, ZRK_E_STATE, "side stream: its thread did not take an item within the host wait limit (ZRK_HOST_WAIT_MS)");
     sd->ring[h % Side::kRing] = it;
+    sd->ring[h % Side::kRing].done_value = (uint32_t)(h + 1);
     sd->head.store(h + 1, std::memory_order_release);
     sd->item_no[it.done_slot] = h + 1;
     if (it.pair) sd->item_no[it.done_slot2] = h + 1;
@@ -4357,13 +4391,23 @@ int side_wait(zrk_ctx *ctx, Side *sd, int slot, hipStream_t compute)
 {
     // (work of earlier calls: the compute stream took the side stream in when that call returned, whatever is launched
     // on it now is behind that -- nothing to ask the runtime, whose first answer after a pause takes 10 us)
+    if (sd->item_no[slot] == 0) return 0;                    // (never used, or started afresh after a failure)
     if (sd->item_no[slot] <= sd->joined_upto && compute == sd->joined_stream) return 0;
+    // the word in which the NEXT compaction of the side stream says that this one is over (the next one is always in the
+    // thread's hands by now -- the ring is several items deep -- and starts without this thread's help)
+    const uint32_t want = (uint32_t)sd->item_no[slot];
+    if ((int32_t)(*sd->hdone - want) >= 0) return 0;
     if (int rc = side_drain(ctx, sd, sd->item_no[slot])) return rc;
-    if (!sd->posted[slot]) return 0;
-    hipError_t q = hipErrorNotReady;
-    if (!spin_until([&] { q = hipEventQuery(sd->done_of[slot]); return q != hipErrorNotReady; }))
+    if (sd->posted[slot]) {                                  // a call's last item: no launch follows it, an event does
+        hipError_t q = hipErrorNotReady;
+        if (!spin_until([&] { q = hipEventQuery(sd->done_of[slot]); return q != hipErrorNotReady; }))
+            return fail(ctx, ZRK_E_STATE, "side stream: a compaction launched ticks ago is not through within the host wait limit (ZRK_HOST_WAIT_MS)");
+        return q == hipSuccess ? 0 : fail(ctx, ZRK_E_HIP, "side stream: hipEventQuery failed");
+    }
+    if (!spin_until([&] { return (int32_t)(*sd->hdone - want) >= 0 || sd->rc.load() != 0; }))
         return fail(ctx, ZRK_E_STATE, "side stream: a compaction launched ticks ago is not through within the host wait limit (ZRK_HOST_WAIT_MS)");
-    return q == hipSuccess ? 0 : fail(ctx, ZRK_E_HIP, "side stream: hipEventQuery failed");
+    if (sd->rc.load() != 0) return fail(ctx, sd->rc.load(), sd->err);
+    return 0;
 }
 
 void side_destroy(Side *sd)
@@ -4788,6 +4832,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                 if (fused && ev_words) { a.M.ev_wire = list_t[0] + list_words; a.M2.ev_wire = list_t[1] + list_words; }
                 a.rm = fused ? sd->rm[slot_t[1]] : nullptr; a.rm_cap = sd->rm_cap;
                 if (last_launch && ctx->tail_by_event) a.wait_event = sd->last_sweep;
+                a.record_event = last_launch ? 1 : 0;
                 uint32_t v_first = 0;
                 if (xio) {
                     // both collectives hang behind the one compaction launch: a launch behind it raises the exchange's word
@@ -4835,6 +4880,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             if (fused && ev_words) it.M.ev_wire = list_t[j] + list_words;
             it.M.clear_vis = (fused && nt == 2 && j == 0) ? vis_t[1] : nullptr;
             if (last_launch && ctx->tail_by_event) it.wait_event = sd->last_sweep;
+            it.record_event = last_launch ? 1 : 0;
             if (xio) {
                 zrk_exchange *x = xio->x;
                 it.raise = x->flag; it.raise_value = ++x->seq;
@@ -4992,6 +5038,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             if (ev_words && !fused && hipMemsetAsync(list + list_words, 0, sizeof(int64_t), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset events"); break; }
             it.stream = side_stream; it.flag_value = v; it.done_slot = side_slot;
             it.M = M; it.M.apply = 0;
+            it.record_event = (k + 1 == K) ? 1 : 0;
             if (k + 1 == K && ctx->tail_by_event) {
                 if (hipEventRecord(sd->last_sweep, s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "hipEventRecord"); break; }
                 it.wait_event = sd->last_sweep;
