@@ -44,13 +44,14 @@ def _first_occurrences(seq):
     return np.asarray(seq)[np.sort(first)].astype(np.int32)
 
 
-@pytest.mark.parametrize("rounds", [1, 3, 12, 1024])
-def test_device_command_post_reproduces_the_reference_fixture(rounds):
+@pytest.mark.parametrize("rounds,grid", [(1, "0"), (3, "0"), (12, "0"), (1024, "0"), (3, "1"), (12, "1")])
+def test_device_command_post_reproduces_the_reference_fixture(rounds, grid, monkeypatch):
     """The 36 ticks the reference's CombatControlPoint decided (ccp_step.npz): the device, fed the same air picture, names
     the same verdict, the same matched key and the same launcher for every processed detection, tick after tick (its
     dictionaries carry over on the device).  Whatever the bound on the parallel rounds: with 1 the workgroup that walks the
     leftovers in order decides nearly everything, with 1024 nothing."""
     from zrk_modulation_amd.association import DeviceCommandPost
+    monkeypatch.setenv("ZRK_CCP_GRID", grid)                      # (the candidate pass: tiled all-pairs, or through the spatial index)
     fx = np.load(Path(__file__).parent / "golden" / "ccp_step.npz")
     meta = json.loads(str(fx["meta"]))
     N = len(fx["obj_id"])
@@ -84,13 +85,15 @@ def test_device_command_post_reproduces_the_reference_fixture(rounds):
     assert launches == sum(meta["capacity"])
 
 
+@pytest.mark.parametrize("grid", ["0", "1"], ids=["all-pairs", "spatial-index"])
 @pytest.mark.parametrize("seed,n,D,L,cap_per,ticks", [(1, 3000, 1200, 3, 40, 6), (2, 100_000, 10_000, 5, 700, 3), (3, 500, 500, 1, 3, 6)])
-def test_device_command_post_equals_the_oracle_over_ticks(seed, n, D, L, cap_per, ticks):
+def test_device_command_post_equals_the_oracle_over_ticks(seed, n, D, L, cap_per, ticks, grid, monkeypatch):
     """Random air pictures over several ticks (the dictionaries carry over, new targets keep appearing, tracks are matched,
     lost and found again under another key, launchers run dry in detection order): the device against the oracle's literal
     loop.  The largest case: 10 000 detections a tick against 100 000 tracks."""
     from oracle import oracle as O
     from zrk_modulation_amd.association import DeviceCommandPost
+    monkeypatch.setenv("ZRK_CCP_GRID", grid)
     g = np.random.Generator(np.random.PCG64(seed))
     p0 = g.uniform(-6e4, 6e4, (n, 3)) * [1, 1, 0.1]
     vel = g.normal(0, 250, (n, 3)) * [1, 1, 0.2]
@@ -133,3 +136,60 @@ def test_device_command_post_equals_the_oracle_over_ticks(seed, n, D, L, cap_per
         assert np.array_equal(post.tt_upd[:ntt].cpu().numpy(), ora.tt_upd[:ntt])
         assert np.array_equal(post.l_launched.cpu().numpy(), ora.l_launched)
     assert total[0] >= n and total[1] > D // 2 and launches == min(L * cap_per, int(total[0] + total[1]))
+
+
+def test_spatial_index_names_the_candidates_the_all_pairs_pass_names(monkeypatch):
+    """3*10^5 tracks, 3*10^4 detections a tick, with everything the index has to get right at once: tracks of very different
+    ages (annuli from metres to the whole scene), tracks and detections at the same point, positions that are not numbers,
+    a detection faster than anything else, speeds of zero.  Two command posts, one per candidate pass, fed the same ticks:
+    same verdicts, matches, launchers and dictionaries -- and the index is what makes 10^5 x 10^6 a matter of milliseconds."""
+    import time
+    from zrk_modulation_amd.association import DeviceCommandPost
+    n, D, L = 300_000, 30_000, 4
+    g = np.random.Generator(np.random.PCG64(77))
+    p0 = g.uniform(-1.5e5, 1.5e5, (n, 3)) * [1, 1, 0.05]
+    vel = g.normal(0, 250, (n, 3)) * [1, 1, 0.2]
+    speed = np.linalg.norm(vel, axis=1)
+    speed[g.choice(n, 50, replace=False)] = 0.0
+    speed[7] = 40_000.0                                           # reaches across hundreds of cells
+    lpos = g.uniform(-2e4, 2e4, (L, 3)) * [1, 1, 0]
+    caps = np.full(L, 2000, np.int32)
+    tab = Table(n)
+    posts = {}
+    for mode in ("0", "1"):
+        posts[mode] = DeviceCommandPost(_ctx(), "cuda:0", n, n, lpos, caps, dmax=n, rounds=8)
+    dt, slack_steps = 0.5, 4
+    pos = p0.copy()
+    spent = {"0": 0.0, "1": 0.0}
+    for k in range(5):
+        now = k * dt
+        prev = pos.copy()
+        pos = p0 + vel * now + g.normal(0, 5, (n, 3))
+        if k >= 1:
+            same = g.choice(n, 200, replace=False)
+            pos[same[:100]] = prev[same[100:]]                    # exactly on another track's reference position
+            pos[g.choice(n, 20, replace=False)] = np.nan
+        none = np.zeros(n, bool) if k else np.ones(n, bool)
+        # every tick a different share of the table is seen: the tracks' ages spread out over the ticks
+        seq = (np.arange(n) if k == 0 else g.permutation(n)[:D]).astype(np.int32)
+        tab.set_tick(pos, prev, none, speed, now)
+        got = {}
+        for mode, post in posts.items():
+            monkeypatch.setenv("ZRK_CCP_GRID", mode)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            post.step(tab.ents, 0, tab.speed, torch.from_numpy(seq).cuda(), torch.tensor([len(seq)], dtype=torch.int32, device="cuda:0"), now,
+                      slack_steps * dt)
+            torch.cuda.synchronize()
+            spent[mode] += time.perf_counter() - t0
+            got[mode] = post.results()
+        for name, a, b in zip(("rows", "verdicts", "matches", "launchers"), got["0"], got["1"]):
+            assert np.array_equal(a, b), f"tick {k}: {name} differ in {int((a != b).sum())} of {len(a)} places"
+        assert posts["0"].counts.cpu().tolist() == posts["1"].counts.cpu().tolist()
+        ntt = int(posts["0"].counts[0])
+        for name in ("tt_key", "tt_obj", "tt_follow", "tt_upd"):
+            assert torch.equal(getattr(posts["0"], name)[:ntt], getattr(posts["1"], name)[:ntt]), f"tick {k}: {name}"
+    v = got["0"][1]
+    assert (v == 1).sum() > D // 2 and (v == 0).sum() > 0
+    print(f"\n5 ticks of the command post at 3e5 tracks: all pairs {spent['0'] * 1e3:.1f} ms, spatial index {spent['1'] * 1e3:.1f} ms")
+    assert spent["1"] < spent["0"]

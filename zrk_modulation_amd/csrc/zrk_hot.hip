@@ -2523,6 +2523,270 @@ __global__ __launch_bounds__(256) void k_ccp_candidates(const double *__restrict
     if (mine) out[d] = c;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The candidate pass with a spatial index (many tracks): the tracks are binned, per tick and on the device, by the size of
+// their annulus and by where they are, and a detection looks only into the bins its annulus can reach -- with the same
+// arithmetic per pair and the same result as the tiled pass above (the kept lists are ordered by (distance, track), which
+// is the order the sequential scan's strict `<` produces).
+//   A track's annulus for a detection of speed v ends at v * (age + slack): tracks fall into classes by a = age + slack,
+// class c holding a <= base * 2^c (base = slack), the last class whatever is left (and what has no finite position): one
+// bin.  Class c has a uniform grid over the tracks' x-y extent with cells at least v_max * base * 2^c wide (v_max: the
+// fastest detection of the tick), so that no detection's reach spans more than 3 x 3 cells of any class -- unless the cell
+// budget caps the grid, which only makes cells larger.  A counting sort by (class, cell) puts the tracks of a cell next to
+// each other (their order within a cell does not matter: the kept lists carry their own order).
+// ---------------------------------------------------------------------------------------------
+constexpr int kGridClasses = 12;
+
+struct CcpGrid {
+    double x0, y0, base;
+    double inv_h[kGridClasses];
+    double reach[kGridClasses];                // base * 2^c: what a = age + slack is at most in class c (the last: unbounded)
+    int32_t nx[kGridClasses], ny[kGridClasses], cell0[kGridClasses + 1];
+};
+
+struct CcpGridArgs {
+    const double *det_pos, *det_speed, *trk_ref, *trk_upd;
+    const int32_t *sizes;                      // {D, T} on the device
+    int64_t dmax, tmax;
+    double now_s, slack_s;
+    double *partial;                           // [blocks][5]: min x, max x, min y, max y, max speed
+    int32_t blocks;
+    CcpGrid *grid;
+    int32_t cells_cap;                         // cells available in all
+    int32_t *count, *start, *key;              // [cells_cap + 1], [cells_cap + 1], [tmax]
+    int32_t *block_sum;                        // [1024]
+    int32_t *sorted_idx;                       // [tmax]
+    double *sorted_ref, *sorted_upd;           // [tmax][3], [tmax]
+};
+
+__device__ __forceinline__ bool finite3(double x, double y, double z)
+{
+    return fabs(x) < __builtin_inf() && fabs(y) < __builtin_inf() && fabs(z) < __builtin_inf();
+}
+
+// extent of the tracks that have a finite position, fastest finite detection: per-block partial results
+__global__ __launch_bounds__(256) void k_ccp_grid_partials(const CcpGridArgs G)
+{
+    __shared__ double s_v[5][256];
+    const int D = (int)(G.sizes[0] < G.dmax ? G.sizes[0] : G.dmax), T = (int)(G.sizes[1] < G.tmax ? G.sizes[1] : G.tmax);
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double v[5] = {__builtin_inf(), -__builtin_inf(), __builtin_inf(), -__builtin_inf(), 0.0};
+    if (g < T) {
+        const double x = G.trk_ref[3 * g], y = G.trk_ref[3 * g + 1], z = G.trk_ref[3 * g + 2];
+        if (finite3(x, y, z)) { v[0] = v[1] = x; v[2] = v[3] = y; }
+    }
+    if (g < D) {
+        const double sp = G.det_speed[g];
+        if (sp > 0.0 && sp < __builtin_inf()) v[4] = sp;
+    }
+    for (int k = 0; k < 5; ++k) s_v[k][threadIdx.x] = v[k];
+    __syncthreads();
+    for (int off = 128; off; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            s_v[0][threadIdx.x] = fmin(s_v[0][threadIdx.x], s_v[0][threadIdx.x + off]);
+            s_v[1][threadIdx.x] = fmax(s_v[1][threadIdx.x], s_v[1][threadIdx.x + off]);
+            s_v[2][threadIdx.x] = fmin(s_v[2][threadIdx.x], s_v[2][threadIdx.x + off]);
+            s_v[3][threadIdx.x] = fmax(s_v[3][threadIdx.x], s_v[3][threadIdx.x + off]);
+            s_v[4][threadIdx.x] = fmax(s_v[4][threadIdx.x], s_v[4][threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 5) G.partial[(int64_t)blockIdx.x * 5 + threadIdx.x] = s_v[threadIdx.x][0];
+}
+
+// one workgroup: the grids of the tick
+__global__ __launch_bounds__(256) void k_ccp_grid_params(const CcpGridArgs G)
+{
+    __shared__ double s_v[5][256];
+    double v[5] = {__builtin_inf(), -__builtin_inf(), __builtin_inf(), -__builtin_inf(), 0.0};
+    for (int b = threadIdx.x; b < G.blocks; b += 256) {
+        const double *q = G.partial + (int64_t)b * 5;
+        v[0] = fmin(v[0], q[0]); v[1] = fmax(v[1], q[1]); v[2] = fmin(v[2], q[2]); v[3] = fmax(v[3], q[3]); v[4] = fmax(v[4], q[4]);
+    }
+    for (int k = 0; k < 5; ++k) s_v[k][threadIdx.x] = v[k];
+    __syncthreads();
+    for (int off = 128; off; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            s_v[0][threadIdx.x] = fmin(s_v[0][threadIdx.x], s_v[0][threadIdx.x + off]);
+            s_v[1][threadIdx.x] = fmax(s_v[1][threadIdx.x], s_v[1][threadIdx.x + off]);
+            s_v[2][threadIdx.x] = fmin(s_v[2][threadIdx.x], s_v[2][threadIdx.x + off]);
+            s_v[3][threadIdx.x] = fmax(s_v[3][threadIdx.x], s_v[3][threadIdx.x + off]);
+            s_v[4][threadIdx.x] = fmax(s_v[4][threadIdx.x], s_v[4][threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    CcpGrid g;
+    const bool any = s_v[0][0] <= s_v[1][0] && s_v[2][0] <= s_v[3][0];
+    g.x0 = any ? s_v[0][0] : 0.0; g.y0 = any ? s_v[2][0] : 0.0;
+    const double ex = any ? s_v[1][0] - s_v[0][0] : 0.0, ey = any ? s_v[3][0] - s_v[2][0] : 0.0;
+    const double vmax = s_v[4][0];
+    g.base = G.slack_s > 1e-9 ? G.slack_s : 1e-9;
+    const int per_class = G.cells_cap / kGridClasses;
+    int axis = 1;
+    while ((axis + 1) * (axis + 1) <= per_class && axis < 2048) ++axis;
+    int cell = 0;
+    double reach = g.base;
+    for (int c = 0; c < kGridClasses; ++c, reach *= 2.0) {
+        g.cell0[c] = cell;
+        g.reach[c] = reach;
+        int nx = 1, ny = 1;
+        double h = vmax * reach;                                  // no detection reaches further than this in class c
+        if (c < kGridClasses - 1 && any) {
+            // (at least the reach, at least what the cell budget allows; a zero reach -- nobody moves -- takes the finest grid)
+            const double hx = fmax(h, ex / axis), hy = fmax(h, ey / axis);
+            h = fmax(hx, hy);
+            if (h > 0.0 && h < __builtin_inf()) {
+                nx = (int)fmin((double)axis, floor(ex / h) + 1.0);
+                ny = (int)fmin((double)axis, floor(ey / h) + 1.0);
+            }
+        }
+        g.nx[c] = nx; g.ny[c] = ny;
+        g.inv_h[c] = (nx > 1 || ny > 1) ? 1.0 / h : 0.0;
+        cell += nx * ny;
+    }
+    g.cell0[kGridClasses] = cell;
+    *G.grid = g;
+}
+
+__device__ __forceinline__ int grid_class(const CcpGrid &g, double a)
+{
+    int c = 0;
+    while (c < kGridClasses - 1 && !(a <= g.reach[c])) ++c;       // (a NaN age lands in the last class)
+    return c;
+}
+
+__device__ __forceinline__ int grid_axis_cell(double v, double v0, double inv_h, int n)
+{
+    const double q = floor((v - v0) * inv_h);
+    return q < 0.0 ? 0 : (q > (double)(n - 1) ? n - 1 : (int)q);  // (NaN: 0)
+}
+
+__global__ __launch_bounds__(256) void k_ccp_grid_count(const CcpGridArgs G)
+{
+    const int T = (int)(G.sizes[1] < G.tmax ? G.sizes[1] : G.tmax);
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const CcpGrid &g = *G.grid;
+    const double x = G.trk_ref[3 * t], y = G.trk_ref[3 * t + 1], z = G.trk_ref[3 * t + 2];
+    int c = kGridClasses - 1;
+    if (finite3(x, y, z)) c = grid_class(g, (G.now_s - G.trk_upd[t]) + G.slack_s);
+    const int ix = grid_axis_cell(x, g.x0, g.inv_h[c], g.nx[c]), iy = grid_axis_cell(y, g.y0, g.inv_h[c], g.ny[c]);
+    const int key = g.cell0[c] + iy * g.nx[c] + ix;
+    G.key[t] = key;
+    atomicAdd(&G.count[key], 1);
+}
+
+// exclusive scan of count[0 .. cells_cap] into start[]: blocks of 4096 cells, their sums, then the offsets
+__global__ __launch_bounds__(1024) void k_ccp_grid_scan(const CcpGridArgs G, int phase)
+{
+    __shared__ int s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = G.cells_cap + 1;
+    if (phase == 1) {                                             // one workgroup: the block sums
+        const int nb = (n + 4095) / 4096;
+        int v = tid < nb ? G.block_sum[tid] : 0;
+        int incl = v;
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wave; ++w) off += s_w[w];
+        if (tid < nb) G.block_sum[tid] = off + incl - v;
+        return;
+    }
+    const int base = (int)blockIdx.x * 4096 + tid * 4;
+    int v[4], sum = 0;
+    for (int k = 0; k < 4; ++k) { v[k] = (base + k < n) ? G.count[base + k] : 0; sum += v[k]; }
+    int incl = sum;
+    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int off = 0, total = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wave) off += s_w[w]; total += s_w[w]; }
+    if (phase == 0) { if (tid == 0) G.block_sum[blockIdx.x] = total; return; }
+    int run = G.block_sum[blockIdx.x] + off + incl - sum;
+    for (int k = 0; k < 4; ++k) { if (base + k < n) G.start[base + k] = run; run += v[k]; }
+}
+
+__global__ __launch_bounds__(256) void k_ccp_grid_scatter(const CcpGridArgs G)
+{
+    const int T = (int)(G.sizes[1] < G.tmax ? G.sizes[1] : G.tmax);
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const int key = G.key[t];
+    const int at = G.start[key] + (atomicAdd(&G.count[key], -1) - 1);     // (the counts run down to zero: cleared for the next tick)
+    G.sorted_idx[at] = (int32_t)t;
+    G.sorted_ref[3 * (int64_t)at] = G.trk_ref[3 * t]; G.sorted_ref[3 * (int64_t)at + 1] = G.trk_ref[3 * t + 1];
+    G.sorted_ref[3 * (int64_t)at + 2] = G.trk_ref[3 * t + 2];
+    G.sorted_upd[at] = G.trk_upd[t];
+}
+
+// One thread per detection, through the bins its annuli can reach.  Same outputs as k_ccp_candidates.
+__global__ __launch_bounds__(256) void k_ccp_candidates_grid(const CcpGridArgs G, const uint8_t *__restrict__ taken,
+                                                             const uint8_t *__restrict__ only, CcpCand *__restrict__ out,
+                                                             const int32_t *__restrict__ gate)
+{
+    if (gate && *gate == 0) return;
+    const int D = (int)(G.sizes[0] < G.dmax ? G.sizes[0] : G.dmax);
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d >= D || (only && !only[d])) return;
+    const CcpGrid &g = *G.grid;
+    const double px = G.det_pos[3 * d], py = G.det_pos[3 * d + 1], pz = G.det_pos[3 * d + 2], sp = G.det_speed[d];
+    const double now_s = G.now_s, slack_s = G.slack_s;
+    CcpCand c;
+    c.n = 0; c.total = 0;
+#pragma unroll
+    for (int k = 0; k < kCcpK; ++k) { c.dist[k] = __builtin_inf(); c.idx[k] = -1; }
+    if (sp == sp) {                                                // (a NaN speed: every gate fails)
+        for (int cl = 0; cl < kGridClasses; ++cl) {
+            const int nx = g.nx[cl], ny = g.ny[cl];
+            int ix0 = 0, ix1 = nx - 1, iy0 = 0, iy1 = ny - 1;
+            if (nx > 1 || ny > 1) {
+                // how far a track of this class can be and still be in gate: v * reach, a little more for the roundings between
+                // the distance's square root and the coordinates
+                double r = sp * g.reach[cl];
+                r = (r > 0.0 ? r * (1.0 + 1e-9) : 0.0) + 1e-9 + 1e-12 * (fabs(px) + fabs(py) + fabs(g.x0) + fabs(g.y0));
+                ix0 = grid_axis_cell(px - r, g.x0, g.inv_h[cl], nx); ix1 = grid_axis_cell(px + r, g.x0, g.inv_h[cl], nx);
+                iy0 = grid_axis_cell(py - r, g.y0, g.inv_h[cl], ny); iy1 = grid_axis_cell(py + r, g.y0, g.inv_h[cl], ny);
+                if (!(px == px) || !(py == py)) { ix0 = 0; ix1 = -1; }       // (no distance from a NaN position is in any gate)
+            }
+            for (int iy = iy0; iy <= iy1; ++iy) {
+                const int row = g.cell0[cl] + iy * nx;
+                const int j0 = G.start[row + ix0], j1 = G.start[row + ix1 + 1];     // (the cells of a row are neighbours in the sort)
+                for (int j = j0; j < j1; ++j) {
+                    const double upd = G.sorted_upd[j];
+                    if (upd == now_s) continue;
+                    const int t = G.sorted_idx[j];
+                    if (taken && taken[t]) continue;
+                    const double dx = G.sorted_ref[3 * (int64_t)j] - px, dy = G.sorted_ref[3 * (int64_t)j + 1] - py,
+                                 dz = G.sorted_ref[3 * (int64_t)j + 2] - pz;
+                    const double dist = sqrt(dot3(dx, dy, dz, dx, dy, dz));
+                    const double age = now_s - upd;
+                    double lo = sp * (age - slack_s), hi = sp * (age + slack_s);
+                    lo = (lo > 0.0) ? lo : 0.0; hi = (hi > 0.0) ? hi : 0.0;
+                    if (!(lo <= dist && dist <= hi)) continue;
+                    c.total += 1;
+                    // keep the kCcpK nearest, the earlier track first among equals
+                    const bool full = c.n >= kCcpK;
+                    if (!full || dist < c.dist[kCcpK - 1] || (dist == c.dist[kCcpK - 1] && t < c.idx[kCcpK - 1])) {
+                        int pos = full ? kCcpK - 1 : c.n;
+#pragma unroll
+                        for (int k = kCcpK - 1; k > 0; --k) {
+                            if (k <= pos && (c.dist[k - 1] > dist || (c.dist[k - 1] == dist && c.idx[k - 1] > t))) {
+                                c.dist[k] = c.dist[k - 1]; c.idx[k] = c.idx[k - 1]; pos = k - 1;
+                            }
+                        }
+                        c.dist[pos] = dist; c.idx[pos] = t;
+                        if (!full) c.n += 1;
+                    }
+                }
+            }
+        }
+    }
+    out[d] = c;
+}
+
 // One round of the order-dependent part.  Phase 0: every unresolved detection names the first candidate of its list
 // that nobody has been given yet and registers, for every such candidate still in its list, the smallest index of an
 // unresolved detection interested in it.  Phase 1: a detection whose named track has nobody earlier interested in it
@@ -3748,12 +4012,25 @@ ZRK_API int zrk_ccp_link(zrk_ctx *ctx, const double *det_pos, const double *det_
     return check_launch(ctx, "zrk_ccp_link");
 }
 
+namespace {
+// the spatial index of the candidate pass (k_ccp_candidates_grid): cells, partial results, the sorted copy of the tracks
+int32_t ccp_grid_cells(int64_t T) { return (int32_t)std::min<int64_t>(std::max<int64_t>(4 * T, 4096), (1 << 22) - 4096); }
+int32_t ccp_grid_blocks(int64_t dmax, int64_t T) { return nblocks(std::max<int64_t>(std::max(dmax, T), 1), 256); }
+int64_t ccp_grid_bytes(int64_t dmax, int64_t T)
+{
+    const int64_t cells = ccp_grid_cells(T);
+    return align256(40 * (int64_t)ccp_grid_blocks(dmax, T)) + align256((int64_t)sizeof(CcpGrid)) + 2 * align256(4 * (cells + 1)) +
+           align256(4 * T) + 4096 + align256(4 * T) + align256(24 * T) + align256(8 * T);
+}
+}  // namespace
+
 ZRK_API int64_t zrk_ccp_step_scratch_bytes(int64_t dmax, int64_t track_capacity)
 {
     if (dmax < 0 || track_capacity < 0) return ZRK_E_INVALID;
     const int64_t T = 2 * track_capacity;
     return zrk_ccp_scratch_bytes(dmax, T) + align256(24 * dmax) + align256(8 * dmax) + align256(24 * T) + align256(8 * T) +
-           align256(4 * dmax) + 256 + align256(4 * (dmax + 1)) + align256(4 * dmax) + align256(4 * T) + align256(4 * dmax) + 256;
+           align256(4 * dmax) + 256 + align256(4 * (dmax + 1)) + align256(4 * dmax) + align256(4 * T) + align256(4 * dmax) + 256 +
+           ccp_grid_bytes(dmax, T);
 }
 
 ZRK_API int zrk_ccp_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const double *speed_mod, const int32_t *seq,
@@ -3789,13 +4066,43 @@ ZRK_API int zrk_ccp_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const dou
     A.new_rank = (int32_t *)p;               p += align256(4 * dmax);
     A.winner = (int32_t *)p;                 p += align256(4 * T);
     A.counters = counters;
-    int32_t *match = (int32_t *)p;           // (behind everything: zrk_ccp_step_scratch_bytes leaves 4 * dmax + 256 for it)
+    int32_t *match = (int32_t *)p;           p += align256(4 * dmax) + 256;
+    // many tracks: the candidate pass goes through a spatial index built on the device each tick (ZRK_CCP_GRID=0 never, 1 always)
+    bool use_grid = T >= 8192;
+    if (const char *v = std::getenv("ZRK_CCP_GRID")) use_grid = v[0] == '1';
+    CcpGridArgs G;
+    std::memset(&G, 0, sizeof(G));
+    G.det_pos = A.det_pos; G.det_speed = A.det_speed; G.trk_ref = A.trk_ref; G.trk_upd = A.trk_upd; G.sizes = A.sizes;
+    G.dmax = dmax; G.tmax = T; G.now_s = now_s; G.slack_s = slack_s;
+    G.blocks = ccp_grid_blocks(dmax, T); G.cells_cap = ccp_grid_cells(T);
+    G.partial = (double *)p;                 p += align256(40 * (int64_t)G.blocks);
+    G.grid = (CcpGrid *)p;                   p += align256((int64_t)sizeof(CcpGrid));
+    G.count = (int32_t *)p;                  p += align256(4 * ((int64_t)G.cells_cap + 1));
+    G.start = (int32_t *)p;                  p += align256(4 * ((int64_t)G.cells_cap + 1));
+    G.key = (int32_t *)p;                    p += align256(4 * T);
+    G.block_sum = (int32_t *)p;              p += 4096;
+    G.sorted_idx = (int32_t *)p;             p += align256(4 * T);
+    G.sorted_ref = (double *)p;              p += align256(24 * T);
+    G.sorted_upd = (double *)p;              p += align256(8 * T);
     if (hipMemsetAsync(taken, 0, (size_t)align256(T), s) != hipSuccess || hipMemsetAsync(state, 0, (size_t)align256(dmax), s) != hipSuccess ||
         hipMemsetAsync(interest, 0x7F, (size_t)align256(4 * T), s) != hipSuccess || hipMemsetAsync(counters, 0, 256, s) != hipSuccess ||
         hipMemsetAsync(out->status, 0, sizeof(int32_t), s) != hipSuccess)
         return fail(ctx, ZRK_E_HIP, "zrk_ccp_step: memset");
     const int gd = nblocks(dmax, 256), gt = nblocks(std::max<int64_t>(dmax, T), 256);
     hipLaunchKernelGGL(k_ccp_gather, dim3(gt), dim3(256), 0, s, A);
+    if (use_grid) {
+        if (hipMemsetAsync(G.count, 0, 4 * ((size_t)G.cells_cap + 1), s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "zrk_ccp_step: memset");
+        const int sb = (G.cells_cap + 1 + 4095) / 4096;
+        hipLaunchKernelGGL(k_ccp_grid_partials, dim3(G.blocks), dim3(256), 0, s, G);
+        hipLaunchKernelGGL(k_ccp_grid_params, dim3(1), dim3(256), 0, s, G);
+        hipLaunchKernelGGL(k_ccp_grid_count, dim3(nblocks(T, 256)), dim3(256), 0, s, G);
+        hipLaunchKernelGGL(k_ccp_grid_scan, dim3(sb), dim3(1024), 0, s, G, 0);
+        hipLaunchKernelGGL(k_ccp_grid_scan, dim3(1), dim3(1024), 0, s, G, 1);
+        hipLaunchKernelGGL(k_ccp_grid_scan, dim3(sb), dim3(1024), 0, s, G, 2);
+        hipLaunchKernelGGL(k_ccp_grid_scatter, dim3(nblocks(T, 256)), dim3(256), 0, s, G);
+        hipLaunchKernelGGL(k_ccp_candidates_grid, dim3(gd), dim3(256), 0, s, G, (const uint8_t *)nullptr, (const uint8_t *)nullptr, cand,
+                           (const int32_t *)nullptr);
+    } else
     hipLaunchKernelGGL(k_ccp_candidates, dim3(gd), dim3(256), 0, s, A.det_pos, A.det_speed, dmax, A.trk_ref, A.trk_upd, T, now_s, slack_s,
                        (const uint8_t *)nullptr, (const uint8_t *)nullptr, cand, (const int32_t *)A.sizes, (const int32_t *)nullptr);
     for (int r = 0; r < rounds; ++r) {               // (each launch looks at the `done` word first: the rounds end themselves)
@@ -3806,6 +4113,10 @@ ZRK_API int zrk_ccp_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const dou
         hipLaunchKernelGGL(k_ccp_reset_interest, dim3(gd), dim3(256), 0, s, dmax, cand, state, interest, A.kill, A.sizes, counters);
         hipLaunchKernelGGL(k_ccp_round_end, dim3(gd), dim3(256), 0, s, dmax, A.sizes, only, state, counters);
         hipLaunchKernelGGL(k_ccp_round_flags, dim3(1), dim3(1), 0, s, counters);
+        if (use_grid)
+            hipLaunchKernelGGL(k_ccp_candidates_grid, dim3(gd), dim3(256), 0, s, G, (const uint8_t *)taken, (const uint8_t *)only, cand,
+                               (const int32_t *)(counters + 4));
+        else
         hipLaunchKernelGGL(k_ccp_candidates, dim3(gd), dim3(256), 0, s, A.det_pos, A.det_speed, dmax, A.trk_ref, A.trk_upd, T, now_s, slack_s,
                            (const uint8_t *)taken, (const uint8_t *)only, cand, (const int32_t *)A.sizes, (const int32_t *)(counters + 4));
     }
@@ -4624,6 +4935,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         }
     }
     ctx->last_overlapped = sd ? 1 : 0;
+    g_trace.mark("run_ticks: side ready");
     hipStream_t side_stream = sd ? sd->stream : nullptr;
     int side_last = -1;
     zrk_exchange *fx = (xio && xio->x->flag) ? xio->x : nullptr;
@@ -4770,6 +5082,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         zrk_scan_advance(radars_b, scan, R);
         PairLaunch pl{st->time_ms + st->dt_ms, radars_b, vis_t[1], mark_b};
         const bool on_dispatch = prof_idx >= 0;
+        if (k == 0) g_trace.mark("run_ticks: first launch prepared");
         const int rc_sweep =
             launch_sweep(ctx, e, st->n, cur_a, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse_t[0] | (nt == 2 ? sparse_t[1] : 0u),
                          st->seed, st->tick, st->gid0, workspace, stream, M, vis_t[0], ordering ? w.order[oph ^ 1] : nullptr,
