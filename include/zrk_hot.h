@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ZRK_ABI_VERSION 6
+#define ZRK_ABI_VERSION 7
 #define ZRK_MAX_RADARS 32           /* one bit per radar in the visibility mask */
 #define ZRK_BLOCK 256               /* table rows per sweep workgroup */
 
@@ -105,7 +105,7 @@ typedef struct {
 } zrk_launch_req;
 
 typedef struct {
-    int32_t rc;                     /* 0 launched; 1..5 = which ValueError of modules/Missile.py:70-94 */
+    int32_t rc;                     /* 0 launched; 1..5 = which ValueError of modules/Missile.py:70-94; 6 no such target row */
     int32_t _pad;
     double velocity[3];             /* V, modules/Missile.py:97-100 */
     double t_hit;
@@ -307,6 +307,20 @@ int zrk_ccp_step(zrk_ctx *ctx, const zrk_entities *ents, int cur, const double *
                  const zrk_ccp_out *out /* HOST */, double now_s, double slack_s, int rounds,
                  void *scratch /* DEVICE, zrk_ccp_step_scratch_bytes(dmax, tracks->capacity) */, void *stream);
 int64_t zrk_ccp_step_scratch_bytes(int64_t dmax, int64_t track_capacity);
+/*
+ * The launch decisions of a zrk_ccp_step as the requests zrk_launch_salvo takes, in request order (the order
+ * try_to_launch_missile was called in, modules/CCP.py:330, :342-343) and without the host:
+ *   replaces: CPPLaunchMissileRequestMessage -> MissileLauncher.step -> launch_missile (modules/CCP.py:310-318,
+ *             modules/MissileLauncher.py:82-101) for all requests of a tick -- request q = {target row of the detection, the chosen
+ *             launcher's position, that launcher's missile parameters missile_params[l] = {velocity_module, detonate_period,
+ *             detonate_radius}}.
+ * req[0 .. k_max) is written in full: the requests first, then requests for no row (target_slot -1; zrk_launch_solve fails
+ * them with rc 6), so zrk_launch_salvo can be called for k_max requests with nothing read back -- k_max bounds the
+ * launches of a tick (the missiles the launchers have left); *count (may be NULL) receives their number.
+ */
+int zrk_ccp_requests(zrk_ctx *ctx, const zrk_ccp_out *out /* HOST */, int64_t dmax, const zrk_ccp_launchers *launchers /* HOST */,
+                     const double *missile_params /* DEVICE [L][3] */, zrk_launch_req *req /* DEVICE [k_max] out */, int64_t k_max,
+                     int32_t *count /* DEVICE [1] out */, void *stream);
 /* check_if_missiles_launched -> add_missile (modules/CCP.py:160-169, :102-108): the missile in table row `row` enters the
  * missile dictionary (or replaces the entry of its key), updated "now". */
 int zrk_ccp_add_missile(zrk_ctx *ctx, const zrk_ccp_tracks *tracks /* HOST */, int32_t row, double now_s, void *stream);

@@ -193,3 +193,68 @@ def test_spatial_index_names_the_candidates_the_all_pairs_pass_names(monkeypatch
     assert (v == 1).sum() > D // 2 and (v == 0).sum() > 0
     print(f"\n5 ticks of the command post at 3e5 tracks: all pairs {spent['0'] * 1e3:.1f} ms, spatial index {spent['1'] * 1e3:.1f} ms")
     assert spent["1"] < spent["0"]
+
+
+def test_launch_requests_feed_the_salvo_without_the_host():
+    """The chain sweep -> lists -> command post -> launch requests -> salvo with nothing read back in between: the requests the
+    device builds from the step's decisions (zrk_ccp_requests) are, byte for byte, the ones a host would build from the step's
+    results, in request order, padded with requests for no row; the salvo launched from them for the padded count leaves the
+    tables a salvo of exactly those requests leaves, the padding's rows dead behind; the loop carries on."""
+    import ctypes as C
+    from zrk_modulation_amd import _lib, scenario as S
+    from zrk_modulation_amd.association import DeviceCommandPost
+    from zrk_modulation_amd.engine import HotPathEngine
+    n, k_max = 60_000, 1500
+    lpos = np.array([[0.0, 0.0, 0.0], [4000.0, -1500.0, 10.0], [-2500.0, 3000.0, 5.0]])
+    caps = np.array([400, 300, 500], np.int32)                    # 1200 missiles in all: fewer than the detections that ask
+    params = np.array([[1000.0, 60.0, 150.0], [900.0, 45.0, 120.0], [1100.0, 30.0, 200.0]])
+    engines, outs = [], []
+    for twin in range(2):
+        ids, sp, vel, t0 = S.synthetic_targets(n, 31)
+        eng = HotPathEngine(device="cuda:0", dt_ms=10, seed=1, noise="off")
+        eng.load(ids, sp, vel, t0, S.synthetic_radars(4), missile_capacity=k_max, sort=False).enable_lists()
+        eng.run(3)
+        engines.append(eng)
+    eng, twin = engines
+    st = eng.store
+    lists = eng.detections()
+    seq = _first_occurrences(np.concatenate(lists))               # FoundObjectsMessage order, every object once (rows: unsorted table)
+    assert len(seq) > 2 * caps.sum()
+    speed = torch.linalg.vector_norm(st.d_vel[:, :st.cap], dim=0).contiguous()
+    post = DeviceCommandPost(st.ctx, "cuda:0", st.cap, st.cap, lpos, caps, dmax=len(seq))
+    now = eng.loop.time_ms / 1000
+    post.step(st.ents, st.cur, speed, torch.from_numpy(seq).cuda(), torch.tensor([len(seq)], dtype=torch.int32, device="cuda:0"), now, 1.0)
+    d_req, d_count = post.requests(params, k_max)
+    rows, verdicts, matches, launchers = post.results()
+    asked = np.nonzero(launchers >= 0)[0]
+    assert len(asked) == caps.sum() and int(d_count.item()) == len(asked)     # every missile handed out, in detection order
+    req_t, res_t = _lib.launch_dtypes()
+    want = np.zeros(k_max, req_t)
+    want["target_slot"] = -1
+    want["target_slot"][:len(asked)] = rows[asked]
+    want["missile_pos"][:len(asked)] = lpos[launchers[asked]]
+    want["speed"][:len(asked)], want["period"][:len(asked)], want["radius"][:len(asked)] = params[launchers[asked]].T
+    got = d_req.cpu().numpy().view(req_t)
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    # the salvo from the device's padded list against a salvo of exactly the requests, on a twin table
+    n0, m0 = st.n_uploaded, st.m
+    count = eng.launch_requests_on_device(d_req, k_max)
+    exact = torch.from_numpy(want[:len(asked)].view(np.uint8).reshape(-1).copy()).cuda()
+    count_twin = twin.launch_requests_on_device(exact, len(asked))
+    c = int(count.item())
+    assert c == int(count_twin.item()) and 0 < c <= len(asked)
+    res = eng._last_device_results.cpu().numpy().view(res_t)
+    assert (res["rc"][len(asked):] == 6).all() and set(np.unique(res["rc"][:len(asked)])) <= {0, 1, 2, 3, 4, 5}
+    a, b = st, twin.store
+    live = slice(n0, n0 + c)
+    for name in ("d_sp", "d_vel"):
+        assert torch.equal(getattr(a, name)[:, live], getattr(b, name)[:, live]), name
+    assert torch.equal(a.d_t0[live], b.d_t0[live]) and a.d_alive[live].all() and b.d_alive[live].all()
+    assert not a.d_alive[n0 + c:n0 + k_max].any()
+    for name in ("dm_slot", "dm_tgt", "dm_period", "dm_status"):
+        assert torch.equal(getattr(a, name)[m0:m0 + c], getattr(b, name)[m0:m0 + c]), name
+    assert not a.dm_status[m0 + c:m0 + k_max].any()
+    eng.run(6)
+    twin.run(6)
+    assert eng.alive_count() == twin.alive_count()
+    assert np.array_equal(eng.store.host_pos("cur")[n0:n0 + c].view(np.uint64), twin.store.host_pos("cur")[n0:n0 + c].view(np.uint64))

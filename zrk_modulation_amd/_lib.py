@@ -14,7 +14,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = CSRC / "libzrk_hot.so"
 
-ZRK_ABI_VERSION = 6
+ZRK_ABI_VERSION = 7
 EXCHANGE_SLOTS = 4          # ZRK_EXCHANGE_SLOTS
 ZRK_MAX_RADARS = 32
 ZRK_BLOCK = 256
@@ -231,6 +231,8 @@ _PROTOTYPES = {
                                C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
     "zrk_ccp_step_scratch_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "zrk_ccp_add_missile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
+    "zrk_ccp_requests": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                   C.c_void_p]),
     "zrk_read_sweep_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "zrk_last_run_ticks_per_launch": (C.c_int, [C.c_void_p]),
 }

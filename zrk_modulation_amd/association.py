@@ -95,6 +95,19 @@ class DeviceCommandPost:
                                                  C.byref(self.launchers), C.byref(self.out), float(now_s), float(slack_s), self.rounds,
                                                  self.scratch.data_ptr(), self._stream()), "zrk_ccp_step")
 
+    def requests(self, missile_params, k_max):
+        """The last tick's launch decisions as a device array of zrk_launch_req in request order, padded to k_max with requests
+        for no row, and their number (int32 tensor [1]) -- what zrk_launch_salvo takes, with nothing read back
+        (include/zrk_hot.h: zrk_ccp_requests).  missile_params: [L][3] velocity_module, detonate_period, detonate_radius."""
+        dev = self.dev
+        par = torch.as_tensor(np.ascontiguousarray(missile_params, np.float64).reshape(-1, 3)).to(dev)
+        assert par.shape[0] == self.L
+        req = torch.zeros(int(k_max) * C.sizeof(_lib.ZrkLaunchReq), dtype=torch.uint8, device=dev)
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.ctx.check(self.ctx.lib.zrk_ccp_requests(self.ctx.handle, C.byref(self.out), self.dmax, C.byref(self.launchers), par.data_ptr(),
+                                                     req.data_ptr(), int(k_max), count.data_ptr(), self._stream()), "zrk_ccp_requests")
+        return req, count
+
     def results(self):
         """(rows, verdicts, matched track index, launcher index) of the last tick's detections; raises if the device says the
         tick did not go through (zrk_hot.h: status)."""

@@ -2326,6 +2326,11 @@ __global__ void k_launch_solve(const double *__restrict__ vel, const uint8_t *__
     const int32_t j = rq.target_slot;
     zrk_launch_res out;
     out.rc = 0; out._pad = 0; out.velocity[0] = out.velocity[1] = out.velocity[2] = 0.0; out.t_hit = 0.0;
+    if (j < 0 || j >= cap) {                       // no such row (the padding behind a device-built request list): a failed request
+        out.rc = 6;
+        res[q] = out;
+        return;
+    }
     // target.velocity (unit) * target.speed_mod, modules/AirObject.py:35-36, modules/Missile.py:58.
     // A missile used as a target has velocity NaN forever (Missile.py:26-27).
     double vt[3];
@@ -3103,6 +3108,54 @@ __global__ __launch_bounds__(1024) void k_ccp_tail(const CcpStepArgs A, uint8_t 
         __syncthreads();                             // (the track is gone before anybody scans for the next detection)
     }
     if (tid == 0) counters[3] = 1;
+}
+
+// The step's launch decisions as the requests zrk_launch_salvo takes, in request order (= detection order, the order
+// try_to_launch_missile was called in), without the host: detection d with out.launcher[d] >= 0 becomes {target row, the
+// launcher's position, that launcher's missile parameters}.  One workgroup; entries [count, k_max) are filled with requests
+// for no row at all (target_slot -1: they fail the solve and take the dead rows behind the successes), so that the salvo can
+// be launched for k_max requests without anybody reading the count.
+__global__ __launch_bounds__(1024) void k_ccp_requests(const zrk_ccp_out out, int64_t dmax, const double *__restrict__ lpos,
+                                                       const double *__restrict__ params, zrk_launch_req *__restrict__ req,
+                                                       int64_t k_max, int32_t *count_out)
+{
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int D = out.count[0];
+    D = D < (int)dmax ? D : (int)dmax;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < D; base += 1024) {
+        const int d = base + tid;
+        const int l = d < D ? out.launcher[d] : -1;
+        const unsigned long long b = __ballot(l >= 0);
+        if (lane == 0) s_w[wave] = (int)__popcll(b);
+        __syncthreads();
+        int off = s_carry, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) off += s_w[w]; tot += s_w[w]; }
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const int64_t q = off + (int)__popcll(b & below);
+        if (l >= 0 && q < k_max) {
+            zrk_launch_req r;
+            r.target_slot = out.obj[d]; r._pad = 0;
+            r.missile_pos[0] = lpos[3 * l]; r.missile_pos[1] = lpos[3 * l + 1]; r.missile_pos[2] = lpos[3 * l + 2];
+            r.speed = params[3 * l]; r.period = params[3 * l + 1]; r.radius = params[3 * l + 2];
+            req[q] = r;
+        }
+        __syncthreads();
+        if (tid == 0) s_carry += tot;
+        __syncthreads();
+    }
+    const int count = s_carry;
+    if (tid == 0 && count_out) *count_out = count;
+    for (int64_t q = count + tid; q < k_max; q += 1024) {
+        zrk_launch_req r;
+        r.target_slot = -1; r._pad = 0;
+        r.missile_pos[0] = r.missile_pos[1] = r.missile_pos[2] = 0.0;
+        r.speed = 0.0; r.period = 0.0; r.radius = 0.0;
+        req[q] = r;
+    }
 }
 
 // the rounds are over: not everybody resolved -> status 1 (cannot happen behind k_ccp_tail; kept as the check that it ran)
@@ -4128,6 +4181,16 @@ ZRK_API int zrk_ccp_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const dou
     hipLaunchKernelGGL(k_ccp_apply, dim3(gd), dim3(256), 0, s, A, 1);
     hipLaunchKernelGGL(k_ccp_count_new, dim3(1), dim3(1), 0, s, A);
     return check_launch(ctx, "zrk_ccp_step");
+}
+
+ZRK_API int zrk_ccp_requests(zrk_ctx *ctx, const zrk_ccp_out *out, int64_t dmax, const zrk_ccp_launchers *lch, const double *missile_params,
+                             zrk_launch_req *req, int64_t k_max, int32_t *count, void *stream)
+{
+    if (!ctx || !out || !lch || !missile_params || (k_max > 0 && !req) || !out->obj || !out->launcher || !out->count)
+        return fail(ctx, ZRK_E_INVALID, "zrk_ccp_requests: null argument");
+    if (dmax < 0 || k_max < 0 || lch->L < 0 || lch->L > 64) return fail(ctx, ZRK_E_INVALID, "zrk_ccp_requests: size out of range");
+    hipLaunchKernelGGL(k_ccp_requests, dim3(1), dim3(1024), 0, (hipStream_t)stream, *out, dmax, lch->pos, missile_params, req, k_max, count);
+    return check_launch(ctx, "k_ccp_requests");
 }
 
 ZRK_API int zrk_ccp_add_missile(zrk_ctx *ctx, const zrk_ccp_tracks *trk, int32_t row, double now_s, void *stream)

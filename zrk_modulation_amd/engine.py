@@ -306,6 +306,40 @@ class HotPathEngine:
         self.loop.n = st.n_uploaded
         return c
 
+    def launch_requests_on_device(self, d_req, k):
+        """zrk_launch_salvo for k requests that already are on the device (a uint8 tensor of zrk_launch_req, e.g. from
+        association.DeviceCommandPost.requests: target ROWS, padded with requests for no row): nothing is uploaded, nothing read
+        back; the table grows by k rows (the failed and the padding requests' rows sit dead behind the successes).  Returns
+        the int32 device tensor [1] that receives the number of missiles that entered the air."""
+        C, _lib = self._C, self._lib
+        st = self.store
+        k = int(k)
+        count = torch.zeros(1, dtype=torch.int32, device=st.device)
+        if k == 0:
+            return count
+        assert d_req.numel() >= k * C.sizeof(_lib.ZrkLaunchReq)
+        st.flush()
+        if st.n + k > st.cap:
+            st._alloc_entities(max(st.n + k, 2 * st.cap))
+            self.loop.n = st.n_uploaded
+        if st.m + k > st.mcap:
+            st._alloc_missiles(max(2 * st.mcap, st.m + k))
+        d_res = torch.zeros(k * C.sizeof(_lib.ZrkLaunchRes), dtype=torch.uint8, device=st.device)
+        n0, list_base = st.n, self.n_list
+        st.ctx.check(st.lib.zrk_launch_salvo(st.ctx.handle, C.byref(st.ents), st.cur, C.byref(st.mis), n0, st.m, d_req.data_ptr(),
+                                             d_res.data_ptr(), k, int(self.loop.time_ms), list_base, count.data_ptr(), st._stream()),
+                     "zrk_launch_salvo")
+        st._bump()
+        st.adopt_device_rows(k, kind=1)
+        st.m += k
+        self.n_list += k
+        if self.row_of_list is not None:
+            self.row_of_list = np.concatenate([self.row_of_list, n0 + np.arange(k)])
+        self.loop.n = st.n_uploaded
+        self.launch_results = None
+        self._last_device_results = d_res
+        return count
+
     def run(self, K, sweep_ms=None, prof_stride=1, exchange=None):
         """Enqueue K ticks.  With `sweep_ms` (a float32 numpy array of ceil(K/prof_stride)) the call
         also times the sweep kernel with HIP events and synchronises the stream.  `exchange` (an
