@@ -1347,7 +1347,7 @@ __global__ __launch_bounds__(kCompBlock) void k_scatter(const uint32_t *__restri
 #define ZRK_PROBE(slot)                          // tools/compact_phases.hip records wall-clock stamps here
 #endif
 constexpr int kFusedMaxItems = 8;                // list slots per thread
-constexpr int kFusedMaxBlocks = 1024;
+constexpr int kFusedMaxBlocks = 2048;             // (16.8e6 rows at eight slots per thread)
 constexpr int kAggStride = 40;                   // 64-bit words per workgroup record (>= ZRK_MAX_RADARS + 1)
 constexpr int kGroupOffset = kFusedMaxBlocks * 2 * kAggStride;   // the group records' place behind the widest records (words)
 constexpr int kMinGroup = 4;
@@ -3450,7 +3450,7 @@ struct zrk_ctx {
     uint32_t rb_cache_flags[2] = {0, 0};
     bool pair_enabled = true;          // ZRK_PAIR=0: one tick per launch in the overlapped loop
     bool pair_compact = true;          // ZRK_PAIR_COMPACT=0: a pair's two compactions as two launches
-    int pair_compact_blocks = kFusedMaxBlocks;   // ... beyond this many workgroups too (ZRK_PAIR_COMPACT_BLOCKS, <= kFusedMaxBlocks)
+    int pair_compact_blocks = 1024;    // ... beyond this many workgroups too (ZRK_PAIR_COMPACT_BLOCKS, <= kFusedMaxBlocks)
     int pair_threads = 0;              // ZRK_PAIR_THREADS=256|512|1024: workgroup size of k_compact_pair (0: by the number of workgroups)
     int last_ticks_per_launch = 1;     // of the last zrk_run_ticks* call
     std::vector<int> tev_alias, tev_ticks;   // per timing sample: which event pair holds it, and the ticks its launch swept
@@ -5191,7 +5191,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             if (rc == 0) {
                 // (workgroups of 1024 threads up to 512 of them; beyond, beside a sweep that keeps every compute unit full for
                 // longer, half-size ones find room sooner: C3x4 83 against 119 us/tick, C3 the other way round, 22.7 against 20.9)
-                a.pair = 1; a.C2 = b.C; a.pair_threads = ctx->pair_threads ? ctx->pair_threads : (a.C.nb > kFusedMaxBlocks / 2 ? 512 : 1024);
+                a.pair = 1; a.C2 = b.C; a.pair_threads = ctx->pair_threads ? ctx->pair_threads : (a.C.nb > 512 ? 512 : 1024);
                 a.C.items = a.C2.items = kPairSlots / a.pair_threads;
                 int lanes = 1;
                 while (lanes < 2 * (R + 1)) lanes <<= 1;
