@@ -316,10 +316,10 @@ def test_a_failed_side_stream_is_not_sticky(monkeypatch):
         torch.mm(a, a, out=b)
     tick0 = int(ovl.loop.tick)
     with pytest.raises(ZrkError):
-        ovl.run(12)
+        ovl.run(40)
     torch.cuda.synchronize()
     done = int(ovl.loop.tick) - tick0
-    assert 0 < done < 12, "the call should have stopped at the ring slot whose compaction never came"
+    assert 0 < done < 40, "the call should have stopped at the ring slot whose compaction never came"
     monkeypatch.setenv("ZRK_HOST_WAIT_MS", "30000")
     st.lib.zrk_ctx_reload_env(st.ctx.handle)
     ref.run(done)
