@@ -23,6 +23,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c3 -- $B --st
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c3_driver -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-c4 > $out/stats_c3_driver.json 2> $out/stats_c3_driver.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c3x4 -- $B --workload C3x4 --steps 100 --warmup 30 --no-cpu-baseline > $out/stats_c3x4.json 2> $out/stats_c3x4.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c2 -- $B --workload C2 --steps 400 --warmup 50 --no-cpu-baseline > $out/stats_c2.json 2> $out/stats_c2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c4 -- $B --workload C4 --steps 40 --warmup 10 --no-cpu-baseline > $out/stats_c4.json 2> $out/stats_c4.err
+echo "== the command post's step at scale"
+python3 $R/tools/ccp_scale.py > $out/ccp_scale.txt 2> $out/ccp_scale.err
 echo "== traffic counters (separate passes)"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/traffic_C3_$c -- $B --steps 40 --warmup 20 --no-cpu-baseline --no-c4 > $out/traffic_C3_$c.log 2>&1

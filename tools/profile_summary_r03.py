@@ -65,6 +65,16 @@ st = kernel_stats("stats_c3x4", f"{tag}_c3x4_kernel_stats.csv")
 recorded["sweep_us_C3x4"] = pick(st, "k_tick_sweep")
 st = kernel_stats("stats_c2", f"{tag}_c2_kernel_stats.csv")
 recorded["sweep_us_C2"] = pick(st, "k_tick_sweep")
+st = kernel_stats("stats_c4", f"{tag}_c4_1gpu_kernel_stats.csv")
+recorded["sweep_us_C4_1gpu"] = pick(st, "k_tick_sweep")
+if (src / "ccp_scale.txt").exists():
+    body = [l for l in (src / "ccp_scale.txt").read_text().splitlines() if l.startswith("tick") or l.startswith("both")]
+    (dst / f"{tag}_ccp_scale.txt").write_text(
+        "# python tools/ccp_scale.py (MI355X, one GPU): the command post's step on the device (zrk_ccp_step), 10^6 tracks, 10^5\n"
+        "# detections a tick; candidate pass through the spatial index (default from 8192 tracks) against tiled all pairs\n"
+        "# (ZRK_CCP_GRID=0).  Wall clock around the call + synchronisation.  Tick 0 is the dictionaries filling up: 10^6 new\n"
+        "# targets, 40 000 missiles handed out one after the other by k_ccp_launch (sequential in the launchers' counts).\n"
+        + "\n".join(body) + "\n")
 for name in ("stats_c3", "stats_c3_plain", "stats_c3_driver"):
     rec = line(name)
     if rec:
