@@ -3349,6 +3349,7 @@ struct Side {
     // the word the compute stream raises (SideItem::flag_value) lives in pinned HOST memory: the side stream's thread
     // polls it there and launches the compaction when it is up -- a one-lane wait kernel in front of every compaction
     // cost the side stream 5 us a tick (a lone wave is slow to find a slot on a device full of sweep waves)
+    std::chrono::steady_clock::time_point last_launch{};   // of the side stream's thread (side_issue)
     volatile uint32_t *hflag = nullptr;
     uint32_t *hflag_dev = nullptr;  // the same word as the device addresses it
     // ... and the word in which a compaction says that the one before it is over (item numbers, in launch order), 64 bytes on
@@ -3732,6 +3733,7 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
         static const PairKernel pairs[4] = {k_tick_sweep<false, true, false, true, true>, k_tick_sweep<true, true, false, true, true>,
                                             k_tick_sweep<false, true, true, true, true>,  k_tick_sweep<true, true, true, true, true>};
         const int w = ((flags & ZRK_F_PHILOX) ? 1 : 0) + (P.lidx ? 2 : 0);
+        g_trace.mark("launch_sweep: arguments ready");
         if (ev_start && ev_stop) hipExtLaunchKernelGGL(pairs[w], grid, dim3(ZRK_BLOCK), 0, (hipStream_t)stream, ev_start, ev_stop, 0, PP, M);
         else hipLaunchKernelGGL(pairs[w], grid, dim3(ZRK_BLOCK), 0, (hipStream_t)stream, PP, M);
         return check_launch(ctx, "k_tick_sweep (pair)");
@@ -4601,8 +4603,21 @@ namespace {
 
 // ---- overlap mode: the side stream and its thread --------------------------------------------------------------
 
+__global__ void k_side_prime() {}
+
 int side_issue(Side *sd, const SideItem &it)
 {
+    // The first launch on a stream that has been idle costs its thread 15-20 us instead of 4-5 (the runtime's own
+    // bookkeeping for an idle queue).  This thread has nothing to do until the next sweep starts: it pays that now, with an
+    // empty launch, instead of in front of the call's first compaction -- which everything behind it would then lag.
+    {
+        const auto now = std::chrono::steady_clock::now();
+        if (!it.wait_event && now - sd->last_launch > std::chrono::microseconds(300)) {
+            hipLaunchKernelGGL(k_side_prime, dim3(1), dim3(64), 0, it.stream);
+            (void)hipGetLastError();
+            g_trace.mark("side: primed");
+        }
+    }
     // The compaction is launched when its input is there, not before: letting its workgroups wait on the device -- resident
     // ahead of their input -- deadlocks the device as soon as anything else on it needs whole compute units in dispatch
     // order (e.g. another engine's single-launch compaction), and a one-lane wait kernel in front of it costs the side
@@ -4640,6 +4655,7 @@ int side_issue(Side *sd, const SideItem &it)
         sd->posted[it.done_slot] = false;
         if (it.pair) sd->posted[it.done_slot2] = false;
     }
+    sd->last_launch = std::chrono::steady_clock::now();
     g_trace.mark("side: compaction issued");
     if (it.post_x && exchange_post_behind_flag(it.post_x, it.post_slot, it.post_send, it.post_recv, it.post_words, it.raise_value) != 0) {
         sd->err = std::string("side stream: ") + it.post_x->err;
