@@ -444,7 +444,9 @@ int zrk_exchange_all_gather(zrk_exchange *x, int slot, const int64_t *send /* DE
  * -- as does every later list of this exchange; zrk_run_ticks_x / zrk_exchange_sync / zrk_exchange_all_gather return
  * ZRK_E_STATE from then on.  A profiler that serialises kernels across streams (rocprofv3 --pmc) forces exactly that:
  * do not collect counters on the exchange path.  A host-side wait for a collective that does not end (a dead peer) is
- * bounded by ZRK_HOST_WAIT_MS and returns ZRK_E_STATE. */
+ * bounded by ZRK_HOST_WAIT_MS and returns ZRK_E_STATE.  Unlike a failure of the context's side stream (zrk_run_ticks: the
+ * next call starts afresh), a failed exchange -- a give-up, a collective that could not be launched -- is final for that
+ * object: the communicator's ranks are no longer in step; destroy it on every rank and create a new one. */
 int zrk_exchange_wait(zrk_exchange *x, int slot, void *stream);
 /* Block the host until the exchange's stream is idle. */
 int zrk_exchange_sync(zrk_exchange *x);
