@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ZRK_ABI_VERSION 7
+#define ZRK_ABI_VERSION 8
 #define ZRK_MAX_RADARS 32           /* one bit per radar in the visibility mask */
 #define ZRK_BLOCK 256               /* table rows per sweep workgroup */
 
@@ -414,8 +414,10 @@ int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *ents, const zrk_missiles *mi
  */
 typedef struct { char internal[128]; } zrk_rccl_id;          /* ncclUniqueId */
 /* Lists in flight: a tick's list is rewritten ZRK_EXCHANGE_SLOTS ticks later, and its collective must be through by
- * then (two were enough for correctness; four keep a late collective from ever stalling the compute stream's host). */
-#define ZRK_EXCHANGE_SLOTS 4
+ * then (two were enough for correctness; with two ticks per launch four are only two launches deep, and the calling thread
+ * then waits for a collective before every other launch -- 18 us gaps between sweeps in the kernel trace; eight keep a
+ * late collective from ever stalling the compute stream's host). */
+#define ZRK_EXCHANGE_SLOTS 8
 typedef struct zrk_exchange zrk_exchange;
 
 int zrk_exchange_unique_id(const char *rccl_path, zrk_rccl_id *id /* HOST out */);

@@ -112,7 +112,7 @@ def test_sharded_wire_matches_oracle_of_the_whole_population(loop, monkeypatch):
             assert e.store.lib.zrk_last_run_overlapped(e.store.ctx.handle) == (0 if loop == "tick-by-tick" else 1)
         for x in xs:
             x.sync()
-        for j in range(K):                               # ZRK_EXCHANGE_SLOTS = 4 ticks are still in their slots
+        for j in range(K):                               # (ZRK_EXCHANGE_SLOTS ticks are still in their slots)
             slot = (tick + j) % xs[0].slots
             gathered = torch.stack([x.recv[slot][0] for x in xs])
             idx, msk = decode_union_bits(gathered, R, offsets, ev_cap)

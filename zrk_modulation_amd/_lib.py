@@ -14,8 +14,8 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = CSRC / "libzrk_hot.so"
 
-ZRK_ABI_VERSION = 7
-EXCHANGE_SLOTS = 4          # ZRK_EXCHANGE_SLOTS
+ZRK_ABI_VERSION = 8
+EXCHANGE_SLOTS = 8          # ZRK_EXCHANGE_SLOTS
 ZRK_MAX_RADARS = 32
 ZRK_BLOCK = 256
 F_ADVANCE, F_PHILOX, F_EXACT_ONLY, F_UNION_BITS = 1, 2, 4, 8
