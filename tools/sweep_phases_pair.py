@@ -66,3 +66,38 @@ for tt in range(0, int(end.max()) + 2):
     inloop = int(((loaded <= tt) & (loop2 > tt)).sum())
     fin = int(((end >= tt) & (end < tt + 1)).sum())
     print(f"{tt:5d} {res:12d} {arr:18d} {inloop:24d} {fin:18d}")
+
+# where the heavy waves ran: HW_REG_HW_ID (simd 5:4, cu 11:8, sh 12, se 15:13) and HW_REG_XCC_ID (3:0)
+hw = t[:, 6]
+hwid, xcc = (hw & 0xFFFFFFFF).astype(np.int64), ((hw >> 32) & 0xF).astype(np.int64)
+simd, cu, sh, se = (hwid >> 4) & 3, (hwid >> 8) & 15, (hwid >> 12) & 1, (hwid >> 13) & 7
+unit = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
+cost = (loop1 - loaded) + (loop2 - loop1)
+nu = len(np.unique(unit))
+heavy_per = np.bincount(unit[~light], minlength=int(unit.max()) + 1)
+cost_per = np.bincount(unit, weights=np.where(light, 0.0, cost), minlength=int(unit.max()) + 1)
+used = np.bincount(unit, minlength=int(unit.max()) + 1) > 0
+print(f"{nu} SIMDs seen; heavy waves per SIMD: percentiles 0 10 50 90 100  {q(heavy_per[used])}")
+print(f"radar-loop time of the heavy waves summed per SIMD [us]:            {q(cost_per[used])}")
+first = start < 3.0
+print(f"of the waves that start in the first 3 us ({int(first.sum())}): {100 * float((~light)[first].mean()):.0f} % heavy; "
+      f"heavy waves per SIMD among them {q(np.bincount(unit[first & ~light], minlength=int(unit.max()) + 1)[used])}")
+
+# the dispatcher's placement: the first workgroups of XCD 0 in start order (wave 0 of each workgroup), as (se, sh, cu)
+w0 = (np.arange(len(ok))[ok] % 4) == 0
+sel = np.nonzero(w0 & (xcc == 0))[0]
+sel = sel[np.argsort(start[sel], kind="stable")][:96]
+print("XCD 0, workgroups in start order: se.sh.cu (heavy = *)")
+print(" ".join(f"{int(se[i])}.{int(sh[i])}.{int(cu[i]):02d}{'*' if not light[i] else ' '}" for i in sel))
+cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+per_cu = np.bincount(cuid[w0], minlength=int(cuid.max()) + 1)
+print("workgroups per CU over the launch: percentiles", q(per_cu[per_cu > 0]), " CUs used:", int((per_cu > 0).sum()))
+
+# the same in units of work: radars walked (tick t) per SIMD, and when each SIMD's last heavy wave ended
+walk_per = np.bincount(unit, weights=walked.astype(np.float64), minlength=int(unit.max()) + 1)
+print(f"radars walked in tick t, summed per SIMD: mean {walk_per[used].mean():.1f}; percentiles {q(walk_per[used])}")
+last_heavy = np.zeros(int(unit.max()) + 1)
+np.maximum.at(last_heavy, unit[~light], end[~light])
+print(f"end of the last heavy wave per SIMD [us]: {q(last_heavy[used])}")
+r = np.corrcoef(walk_per[used], last_heavy[used])[0, 1]
+print(f"correlation of a SIMD's walked sum with the end of its last heavy wave: {r:.2f}")
