@@ -984,8 +984,9 @@ __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) voi
     if (PAIR) pre_piece2 = pre_table_fetch(rbp2);
     ZRK_WAVE_PROBE(wave, 0, wall_clock64());
     // where the wave runs: HW_REG_HW_ID (wave / simd / cu / sh / se) and HW_REG_XCC_ID
+    // (bits 40 up: the workgroup's place in the dispatch)
     ZRK_WAVE_PROBE(wave, 6, (long long)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
-                                ((long long)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32));
+                                ((long long)((uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) << 32) | ((long long)bid << 40));
     const int64_t i = wave * 64 + (tid & 63);
     // every column load of the row is issued before anything waits for one: rows past the end read row 0
     const int64_t ic = (i < P.n) ? i : 0;
