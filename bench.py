@@ -30,17 +30,26 @@ The timed steps go through ONE zrk_run_ticks call, which (for calls of four tick
 compacts tick t's lists on a side stream beside tick t+1's sweep (`config.loop`); the kernels and their results are
 the two-launch loop's (tests/test_gpu_overlap.py).
 
-Prints ONE JSON line (rank 0).  `roofline` is the fused advance+sweep kernel: algorithmic bytes per launch (85 B per
-live entity, 1 B per tombstone) over its average duration, measured with HIP events inside the timed region on the
-stream the kernel is launched on (the pair rides on the dispatch -- hipExtLaunchKernel -- and reads the kernel's own
-begin and end stamps; every 4th sweep of a short run is timed, every 8th of a long one, because a timed launch costs
-the stream ~4 us).  In the overlapped loop the sweep shares the device with the previous tick's compaction and is
-~2 us slower than alone; the rocprofv3 figures of the same command are kept under profiles/ and echoed as
-`profiled_kernel_us_recorded` (this loop) and `profiled_kernel_us_alone_recorded` (ZRK_OVERLAP=0).  `traffic_recorded`
-is the PMC figure of the committed counter passes -- counters cannot be read from inside this process.  `cpu_baseline` is the oracle (C restatement of the reference, oracle/) timed
-on this host on a bounded number of ticks of the same scene.  Before the warm-up steps the device runs ~100 ms of an
-unrelated self-test kernel so that a 20-step run is not measured while the clocks are still ramping
-(`setup.clock_spinup_ms`; none of it counts as a step).
+Prints ONE JSON line (rank 0).  `roofline` is the fused advance+sweep kernel.  Its duration is measured live, inside the
+timed region, by the kernel itself: with zrk_sweep_stamps on, every sweep launch of the timed call (every k-th in runs of
+more than 64 launches) writes the wall clock (s_memrealtime, 100 MHz) as its first waves start and as each of its waves
+ends (zrk_read_sweep_stamps, read after the region).  That puts no event, signal or barrier on the stream: the timed
+launches run exactly as untimed ones do, and ALL of them are samples (per launch they spread from 28 to 44 us at C3,
+depending on what the compaction beside them is doing; the two event pairs of round 3's 20-step line happened to sit on
+slow ones, and cost the run 2-3 us per tick).  A launch's time on its stream as a profiler stamps it also holds the
+dispatch in front of its first wave and the release behind its last; that part (`dispatch_overhead_us`, 1.5-2 us) is
+measured behind the region on stand-alone launches timed both ways -- stamps and an event pair riding on the dispatch --
+and added: `avg_kernel_us` = first wave in to last wave out + dispatch overhead, which is what rocprofv3 reports for
+the same command (profiles/).  `achieved` = the bytes the launch MUST move -- a launch that sweeps two ticks reads the 57 B
+of trajectory columns once and writes 28 B per tick: 113 B per live entity, 1 B per tombstone -- over that duration;
+`effective` puts SURVEY section 8d's per-tick figure (85 B per live entity and tick swept, i.e. 170 B for a two-tick
+launch) over the same duration, for comparison with one-tick-per-launch figures of earlier rounds.  In the overlapped
+loop the sweep shares the device with the previous launch's compaction; the rocprofv3 figures of the same command are
+kept under profiles/ and echoed as `profiled_kernel_us_recorded`.  `traffic_recorded` is the PMC figure of the committed
+counter passes -- counters cannot be read from inside this process.  `cpu_baseline` is the oracle (C restatement of the
+reference, oracle/) timed on this host on a bounded number of ticks of the same scene.  Before the warm-up steps the
+device runs ~100 ms of an unrelated self-test kernel so that a 20-step run is not measured while the clocks are still
+ramping (`setup.clock_spinup_ms`; none of it counts as a step).
 """
 import argparse
 import json
@@ -55,7 +64,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 SPINUP_MS = 100.0
-PROFILE_TAG = "r03"            # profiles/<tag>_* hold the recorded figures echoed in the line
+PROFILE_TAG = "r04"            # profiles/<tag>_* hold the recorded figures echoed in the line
 
 
 def parse_args():
@@ -455,6 +464,9 @@ def main():
         # the warm-up steps go through the same code as the timed ones, sweep timing included: the library creates its timing
         # events on first use, and a first hipExtLaunchKernel is slow -- neither belongs into the timed region
         # (every warm-up sweep is timed, so that the timed region's events exist already)
+        stamping = hasattr(eng, "sweep_stamps") and not (exchanging and not state["c_side"])
+        if stamping:
+            eng.sweep_stamps(True)           # (the ring of stamps is allocated by the first call that uses it: a warm-up call)
         warm_ms = np.zeros(warmup, np.float32) if (warmup > 0 and deferred) else None
         run_ticks(warmup, warm_ms, every=1)
         if warm_ms is not None and deferred:
@@ -469,25 +481,43 @@ def main():
             size_exchange(int(seen.item() * 1.25) + 1024)
         barrier()
         live0 = eng.alive_count()
-        sweep_ms = np.zeros((steps + stride - 1) // stride, np.float32)
+        # with the sweeps timing themselves nothing else times them inside the region (two event pairs cost a 20-step run
+        # 2-3 us per tick); the rehearsal backends, which have no stamps, keep the event pairs
+        sweep_ms = np.zeros((steps + stride - 1) // stride if not stamping else 0, np.float32)
         spin_up()
         barrier()
         t0 = time.perf_counter()
-        run_ticks(steps, sweep_ms)
+        run_ticks(steps, sweep_ms if len(sweep_ms) else None)
         t_issued = time.perf_counter()
         if exchanging:
             drain_exchange()
         barrier()
         elapsed = time.perf_counter() - t0
         sweep_ticks = np.ones(len(sweep_ms), np.int32)
-        if deferred:
+        if deferred and len(sweep_ms):
             sweep_ms[:] = eng.read_sweep_ms(len(sweep_ms))
             if hasattr(eng, "read_sweep_ticks"):
                 sweep_ticks[:] = eng.read_sweep_ticks(len(sweep_ms))
+        stamp_us, stamp_ticks = eng.read_sweep_stamps() if stamping else (np.zeros(0, np.float32), np.zeros(0, np.int32))
         live1 = eng.alive_count()
         eng.store.compact_status()           # outside the timing: a compaction that did not run to completion raises here
         if exchanging:
             overflow = xchg["x"].overflowed() if state["c_side"] else any(e.overflowed() for e in xchg["ex"])
+        # What a launch costs its stream outside "first wave in to last wave out" -- the dispatch in front (the packet, 10-20 KB of
+        # arguments) and the release behind -- is what a profiler's begin / end stamps of the same launch add to the launch's own:
+        # measured behind the region on stand-alone launches (calls of one tick, device otherwise idle), each timed both ways
+        overhead_us = []
+        if stamping and deferred:
+            for _ in range(10):
+                run_ticks(1, np.zeros(1, np.float32), every=1)
+                ev_us = float(eng.read_sweep_ms(1)[0]) * 1e3
+                st_us, _tk = eng.read_sweep_stamps()
+                if len(st_us) and ev_us > 0:
+                    overhead_us.append(ev_us - float(st_us[0]))
+            if exchanging:
+                drain_exchange()
+            overhead_us = sorted(overhead_us)[1:-1]             # (without the two extremes)
+        dispatch_overhead_us = float(np.mean(overhead_us)) if len(overhead_us) else 0.0
 
         elapsed_rank0 = elapsed
         el = coll_device(torch.tensor([elapsed], dtype=torch.float64))
@@ -499,15 +529,28 @@ def main():
         if rank == 0:
             n_slots = eng.store.n_uploaded
             live_avg = 0.5 * (live0 + live1)
-            alg_bytes = 85.0 * live_avg + 1.0 * (n_slots - live_avg)
+            dead = n_slots - live_avg
             # a launch of the overlapped loop sweeps two consecutive ticks in one pass (zrk_hot.h: zrk_read_sweep_ticks): the
             # samples are launches; only those of the prevailing kind are averaged (an odd tick at a call's end is a launch of one)
-            tpl = int(np.bincount(sweep_ticks[sweep_ms > 0]).argmax()) if (sweep_ms > 0).any() else 1
-            good = sweep_ms[(sweep_ms > 0) & (sweep_ticks == tpl)]
-            sweep_avg_ms = float(good.mean()) if len(good) else float("nan")
-            alg_bytes_tick = alg_bytes
-            alg_bytes = alg_bytes_tick * tpl                   # algorithmic bytes per LAUNCH: 85 B per live entity and tick swept
-            achieved = alg_bytes / (sweep_avg_ms * 1e-3) / 1e9
+            ev_ok = sweep_ms > 0
+            if len(stamp_us):
+                tpl = int(np.bincount(stamp_ticks).argmax())
+                wave_us = stamp_us[stamp_ticks == tpl].astype(np.float64)
+                good = wave_us + dispatch_overhead_us
+                timing = ("the launches' own wall-clock stamps (zrk_sweep_stamps: first wave in to last wave out) + the dispatch / release "
+                          "overhead of a launch measured behind the region (dispatch_overhead_us)")
+            else:                                                  # (rehearsal backends: the event pairs are all there is)
+                tpl = int(np.bincount(sweep_ticks[ev_ok]).argmax()) if ev_ok.any() else 1
+                good = wave_us = sweep_ms[ev_ok & (sweep_ticks == tpl)].astype(np.float64) * 1e3
+                timing = "HIP events riding on the dispatch"
+            sweep_avg_us = float(good.mean()) if len(good) else float("nan")
+            # bytes the launch MUST move: the trajectory columns and the flag once (57 B), position and mask per tick swept
+            # (28 B), one flag byte per tombstone; and SURVEY 8d's per-tick figure times the ticks swept
+            alg_bytes_tick = 85.0 * live_avg + 1.0 * dead
+            alg_bytes = (57.0 + 28.0 * tpl) * live_avg + 1.0 * dead
+            eff_bytes = alg_bytes_tick * tpl
+            achieved = alg_bytes / (sweep_avg_us * 1e-6) / 1e9
+            eff_achieved = eff_bytes / (sweep_avg_us * 1e-6) / 1e9
             if ensemble:
                 what = (f"{workload}: {info['scenarios']} independent scenarios x {info['per_scenario']} AirObjects, "
                         f"{info['R']} SectorRadars and {info['m'] // info['scenarios']} missiles each, per GPU, one batched table")
@@ -540,8 +583,15 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                              "traffic_recorded": recorded(f"traffic_bytes_{workload}") if world == 1 else None,
-                             "kernel": "k_tick_sweep", "avg_kernel_us": sweep_avg_ms * 1e3, "samples": int(len(good)),
+                             "kernel": "k_tick_sweep", "avg_kernel_us": sweep_avg_us, "samples": int(len(good)),
+                             "min_kernel_us": float(good.min()) if len(good) else None,
+                             "max_kernel_us": float(good.max()) if len(good) else None, "timed_by": timing,
+                             "first_wave_in_to_last_wave_out_us": float(wave_us.mean()) if len(wave_us) else None,
+                             "dispatch_overhead_us": dispatch_overhead_us,
+                             "first_wave_in_to_last_wave_out_us_per_launch": [round(float(v), 2) for v in stamp_us] if 0 < len(stamp_us) <= 16 else None,
                              "algorithmic_bytes_per_launch": alg_bytes, "ticks_per_launch": tpl,
+                             "effective": {"bytes_per_launch": eff_bytes, "achieved": eff_achieved, "frac": eff_achieved / HBM_PEAK_GBS,
+                                           "what": "85 B per live entity and tick swept (SURVEY 8d) x ticks per launch, over the same duration"},
                              "profiled_kernel_us_recorded": recorded(f"sweep_us_{workload}") if world == 1 else None,
                              "profiled_kernel_us_alone_recorded": recorded(f"sweep_us_{workload}_plain_loop") if world == 1 else None,
                              "recorded_from": f"profiles/{PROFILE_TAG}_recorded.json (rocprofv3 passes of this command, committed)",

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ZRK_ABI_VERSION 8
+#define ZRK_ABI_VERSION 9
 #define ZRK_MAX_RADARS 32           /* one bit per radar in the visibility mask */
 #define ZRK_BLOCK 256               /* table rows per sweep workgroup */
 
@@ -519,6 +519,14 @@ int zrk_read_sweep_ms(zrk_ctx *ctx, float *sweep_ms /* HOST out */, int n);
  * what the last zrk_run_ticks* call did (1 or 2). */
 int zrk_read_sweep_ticks(zrk_ctx *ctx, int32_t *ticks /* HOST out */, int n);
 int zrk_last_run_ticks_per_launch(zrk_ctx *ctx);
+/* The sweeps time THEMSELVES: with stamps on, the sweep launches of zrk_run_ticks* (all of a call, or every k-th so that at most
+ * 64 are kept) write the wall clock (s_memrealtime, 100 MHz) when their first waves start and when each of their waves ends;
+ * zrk_read_sweep_stamps reduces them on `stream` (the stream the call ran on; it synchronises it) to one duration per sampled
+ * launch [us] -- first wave in to last wave out -- and says how many ticks each swept.  Unlike an event pair on the dispatch
+ * this puts no signal, no barrier and no packet on the stream: the launches run as untimed ones do.  Returns the number of
+ * samples written (<= cap), or an error.  No reference counterpart (measurement). */
+int zrk_sweep_stamps(zrk_ctx *ctx, int on);
+int zrk_read_sweep_stamps(zrk_ctx *ctx, float *sweep_us /* HOST out */, int32_t *ticks /* HOST out, may be NULL */, int cap, void *stream);
 
 /* Numerics self-test hooks used by tests/: y[i] = op(a[i], b[i]) in device binary64.
  * op: 0 sqrt(a), 1 a/b, 2 atan2(a,b), 3 asin(a), 4 fma-chain norm of (a,b,0). */

@@ -14,7 +14,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = CSRC / "libzrk_hot.so"
 
-ZRK_ABI_VERSION = 8
+ZRK_ABI_VERSION = 9
 EXCHANGE_SLOTS = 8          # ZRK_EXCHANGE_SLOTS
 ZRK_MAX_RADARS = 32
 ZRK_BLOCK = 256
@@ -235,6 +235,8 @@ _PROTOTYPES = {
                                    C.c_void_p]),
     "zrk_read_sweep_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "zrk_last_run_ticks_per_launch": (C.c_int, [C.c_void_p]),
+    "zrk_sweep_stamps": (C.c_int, [C.c_void_p, C.c_int]),
+    "zrk_read_sweep_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

@@ -159,6 +159,11 @@ struct SweepParams {
     int32_t bps;
     uint32_t bps_magic;         // ceil(2^32 / bps): block / bps == umulhi(block, magic) for block < 2^16
     uint32_t flags;
+    // wall-clock stamps of THIS launch (s_memrealtime, 100 MHz), NULL: none -- words [0, kStampBegins): when each wave of the
+    // first workgroups started; word kStampBegins + w: when wave w of the grid ended.  The launch ran from the smallest of
+    // the former to the largest of the latter (k_reduce_stamps): a duration measured without an event, a signal or a
+    // profiler on the stream (zrk_sweep_stamps)
+    unsigned long long *stamps;
     RadarBlock rb;
 };
 // a PAIR launch carries the second tick's records behind the first's (a plain launch does not pay for their 10 KB)
@@ -911,6 +916,41 @@ __device__ __forceinline__ CullAndBox cull_from_rows(const PreTable &T, int R, b
     return out;
 }
 
+constexpr int kStampSlots = 64;                        // launches a call's stamps are kept of (zrk_ctx::stamp_ring)
+constexpr int kStampBegins = 64;                       // begin stamps: the waves of the first kStampBegins * 64 / ZRK_BLOCK workgroups
+
+__device__ __forceinline__ void stamp_begin(unsigned long long *stamps)
+{
+    if (stamps && blockIdx.x < (unsigned)(kStampBegins * 64 / ZRK_BLOCK) && (threadIdx.x & 63) == 0)
+        stamps[blockIdx.x * (ZRK_BLOCK / 64) + (threadIdx.x >> 6)] = wall_clock64();
+}
+
+__device__ __forceinline__ void stamp_end(unsigned long long *stamps)
+{
+    if (stamps && (threadIdx.x & 63) == 0)
+        stamps[kStampBegins + (int64_t)blockIdx.x * (ZRK_BLOCK / 64) + (threadIdx.x >> 6)] = wall_clock64();
+}
+
+// min of the begin stamps, max of the end stamps of one launch (one workgroup): out[0], out[1]
+__global__ __launch_bounds__(1024) void k_reduce_stamps(const unsigned long long *stamps, int64_t waves, unsigned long long *out)
+{
+    __shared__ unsigned long long s_lo[16], s_hi[16];
+    unsigned long long lo = ~0ull, hi = 0ull;
+    const int64_t nb = waves < kStampBegins ? waves : kStampBegins;
+    for (int64_t k = threadIdx.x; k < nb; k += 1024) { const unsigned long long v = stamps[k]; lo = v < lo ? v : lo; }
+    for (int64_t k = threadIdx.x; k < waves; k += 1024) { const unsigned long long v = stamps[kStampBegins + k]; hi = v > hi ? v : hi; }
+    for (int d = 32; d; d >>= 1) {
+        const unsigned long long a = __shfl_xor(lo, d), b = __shfl_xor(hi, d);
+        lo = a < lo ? a : lo; hi = b > hi ? b : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) { lo = s_lo[w] < lo ? s_lo[w] : lo; hi = s_hi[w] > hi ? s_hi[w] : hi; }
+        out[0] = lo; out[1] = hi;
+    }
+}
+
 // One pass over the table: 64 consecutive rows per wave.  ADVANCE / LIDX mirror ZRK_F_ADVANCE and
 // list_index != NULL as template parameters so that the row's column loads sit in one basic block and are all in
 // flight before anything waits for one.  PAIR: two consecutive ticks in the one pass (SweepParams::t2).
@@ -920,6 +960,7 @@ template <bool PHILOX, bool ADVANCE, bool LIDX, bool MARKS = false, bool PAIR = 
 __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) void k_tick_sweep(const std::conditional_t<PAIR, SweepParamsPair, SweepParams> P, const MissileArgs M)
 {
     static_assert(!PAIR || (MARKS && ADVANCE), "a pair launch advances and carries removals as marks");
+    stamp_begin(P.stamps);
     // the previous tick's compaction is over and visible once this grid starts: tell the exchange stream, which waits
     // for this word instead of an event (an event record costs the compute stream a barrier packet per tick)
     if (P.flag && blockIdx.x == 0 && threadIdx.x == 0)
@@ -954,6 +995,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) voi
                                                    M.pos_abs[0], M.pos_abs[1], /* second tick of a pair: */ M.mark, rb_first, P.R,
                                                    PHILOX, P.seed, P.tick, P.gid0, M.t);
         }
+        stamp_end(P.stamps);
         return;
     }
     const int tid = threadIdx.x;
@@ -1151,6 +1193,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) voi
     }
     if (P.order_next && tid == 0 && (unsigned)next_slot < (unsigned)P.nb) P.order_next[next_slot] = blk;
     ZRK_WAVE_PROBE(wave, 3, wall_clock64());
+    stamp_end(P.stamps);
 }
 
 
@@ -3456,6 +3499,14 @@ struct zrk_ctx {
     int pair_threads = 0;              // ZRK_PAIR_THREADS=256|512|1024: workgroup size of k_compact_pair (0: by the number of workgroups)
     int last_ticks_per_launch = 1;     // of the last zrk_run_ticks* call
     std::vector<int> tev_alias, tev_ticks;   // per timing sample: which event pair holds it, and the ticks its launch swept
+    // zrk_sweep_stamps: the sweeps of zrk_run_ticks* time themselves (SweepParams::stamps): a ring of kStampSlots launches'
+    // worth of stamps, the sampled launches of the last call in its first stamp_used slots
+    bool stamps_on = false;
+    unsigned long long *stamp_ring = nullptr, *stamp_out = nullptr;      // DEVICE
+    int64_t stamp_slot_words = 0;
+    int stamp_used = 0;
+    std::vector<int> stamp_ticks;
+    std::vector<int64_t> stamp_waves;
     bool tail_by_event = false;        // ZRK_TAIL_EVENT=1: the last compaction of a call is released by an event recorded behind the last sweep, not by
                                        // a launch that raises the host word (medians equal, 24.6 / 24.7 us per tick in 20-step runs; the event has the worse tail)
 };
@@ -3586,6 +3637,8 @@ ZRK_API void zrk_ctx_destroy(zrk_ctx *ctx)
     side_destroy(ctx->side);
     std::free(ctx->rb_cache);
     if (ctx->grec) (void)hipFree(ctx->grec);
+    if (ctx->stamp_ring) (void)hipFree(ctx->stamp_ring);
+    if (ctx->stamp_out) (void)hipFree(ctx->stamp_out);
     for (hipEvent_t e : ctx->tev) (void)hipEventDestroy(e);
     delete ctx;
 }
@@ -3691,7 +3744,7 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
                  WaveBox *boxes = nullptr, const EnsLaunch *ens = nullptr, const RadarBlock *rb_device = nullptr,
                  uint32_t *flag = nullptr, uint32_t flag_value = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
                  uint32_t *order_ctr = nullptr, uint32_t *order_ctr_next = nullptr, uint8_t *pend = nullptr, uint32_t mark = 0,
-                 const PairLaunch *pair = nullptr)
+                 const PairLaunch *pair = nullptr, unsigned long long *stamps = nullptr)
 {
     if (!ctx || !e || !workspace || (R > 0 && !radars && !ens && !rb_device)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
     if (R < 0 || R > ZRK_MAX_RADARS)
@@ -3711,7 +3764,7 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
     P.seed = seed; P.tick = tick; P.gid0 = gid0;
     P.R = R; P.nb = nblocks(n, ZRK_BLOCK); P.flags = flags;
     P.mb = nblocks(M.m, ZRK_BLOCK); P.flag = flag; P.flag_value = flag_value;
-    P.boxes = boxes;
+    P.boxes = boxes; P.stamps = stamps;
     P.pend = pend; P.mark = mark; P.mark2 = pair ? pair->mark2 : mark; P.alive_w = e->alive; P.pos_prev = e->pos[cur ^ 1];
     P.pos_abs[0] = e->pos[0]; P.pos_abs[1] = e->pos[1];
     P.t2 = pair ? (double)pair->time2_ms / 1000.0 : P.t; P.vis2 = pair ? pair->vis2 : nullptr;
@@ -5073,6 +5126,35 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     // ticks' lists (two launches, in order) beside launch L + 1.  An odd tick at the end of a call is a launch of one.
     const bool pairing = sd && !ens && ctx->pair_enabled && K >= 2 && (m == 0 || m <= 1024 * (int64_t)kMissileItems);
     ctx->last_ticks_per_launch = pairing ? 2 : 1;
+    // the sweeps time themselves (zrk_sweep_stamps): every stamp_every-th launch of this call writes its waves' stamps into
+    // the next slot of the ring (all of them, up to kStampSlots launches per call)
+    int stamp_every = 0;
+    ctx->stamp_used = 0;
+    if (ctx->stamps_on && st->n > 0 && K > 0) {
+        const int64_t words = kStampBegins + ((int64_t)nblocks(e->capacity, ZRK_BLOCK) + nblocks(std::max<int64_t>(m, 0), ZRK_BLOCK) + 8) * (ZRK_BLOCK / 64);
+        if (ctx->stamp_slot_words < words) {
+            if (ctx->stamp_ring) (void)hipFree(ctx->stamp_ring);
+            ctx->stamp_ring = nullptr; ctx->stamp_slot_words = 0;
+            if (hipMalloc((void **)&ctx->stamp_ring, sizeof(unsigned long long) * (size_t)words * kStampSlots) == hipSuccess) ctx->stamp_slot_words = words;
+            else (void)hipGetLastError();
+        }
+        if (!ctx->stamp_out && hipMalloc((void **)&ctx->stamp_out, sizeof(unsigned long long) * 2 * kStampSlots) != hipSuccess) { (void)hipGetLastError(); ctx->stamp_out = nullptr; }
+        if (ctx->stamp_ring && ctx->stamp_out) {
+            const int launches = pairing ? (K + 1) / 2 : K;
+            stamp_every = (launches + kStampSlots - 1) / kStampSlots;
+            ctx->stamp_ticks.assign(kStampSlots, 0); ctx->stamp_waves.assign(kStampSlots, 0);
+        }
+    }
+    int stamp_launch = 0;
+    auto next_stamps = [&](int ticks, int64_t missile_rows) -> unsigned long long * {
+        if (!stamp_every) return nullptr;
+        const int l = stamp_launch++;
+        if (l % stamp_every != 0 || ctx->stamp_used >= kStampSlots) return nullptr;
+        const int slot = ctx->stamp_used++;
+        ctx->stamp_ticks[slot] = ticks;
+        ctx->stamp_waves[slot] = ((int64_t)nblocks(st->n, ZRK_BLOCK) + nblocks(missile_rows, ZRK_BLOCK)) * (ZRK_BLOCK / 64);
+        return ctx->stamp_ring + (int64_t)slot * ctx->stamp_slot_words;
+    };
     for (int k = 0; pairing && k < K && rc == 0;) {
         const int nt = (k + 1 < K) ? 2 : 1;
         const int32_t cur_before = st->cur, vis_cur_before = st->vis_cur;
@@ -5170,7 +5252,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                          (ordering && ctx->order_ready) ? w.order[oph] : nullptr, w.boxes, nullptr, nullptr,
                          k > 0 ? sd->hflag_dev : nullptr, sd->seq,
                          on_dispatch ? ev[2 * prof_idx] : nullptr, on_dispatch ? ev[2 * prof_idx + 1] : nullptr,
-                         w.order_ctr + kOrderCtrSet * (oph ^ 1), w.order_ctr + kOrderCtrSet * oph, sd->pend, mark_a, nt == 2 ? &pl : nullptr);
+                         w.order_ctr + kOrderCtrSet * (oph ^ 1), w.order_ctr + kOrderCtrSet * oph, sd->pend, mark_a, nt == 2 ? &pl : nullptr,
+                         next_stamps(nt, M.m));
         rc = rc_sweep;
         g_trace.mark(nt == 2 ? "run_ticks: pair launched" : "run_ticks: sweep launched");
         if (rc_sweep != 0) { st->vis_cur = vis_cur_before; break; }
@@ -5380,7 +5463,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                           rb_through_memory ? rb_dev[st->tick & 1u] : nullptr,
                           pend.on ? fx->flag : ((sd && k > 0) ? sd->hflag_dev : nullptr), pend.on ? pend.value : (sd ? sd->seq : 0u),
                           on_dispatch ? ev[2 * (k / stride)] : nullptr, on_dispatch ? ev[2 * (k / stride) + 1] : nullptr,
-                          w.order_ctr + kOrderCtrSet * (oph ^ 1), w.order_ctr + kOrderCtrSet * oph, marks ? sd->pend : nullptr, mark);
+                          w.order_ctr + kOrderCtrSet * (oph ^ 1), w.order_ctr + kOrderCtrSet * oph, marks ? sd->pend : nullptr, mark, nullptr,
+                          next_stamps(1, M.m));
         rc = rc_sweep;
         g_trace.mark("run_ticks: sweep launched");
         if (rc_sweep == 0 && marks) marks_used = true;
@@ -5582,6 +5666,35 @@ ZRK_API int zrk_read_sweep_ticks(zrk_ctx *ctx, int32_t *ticks, int n)
 }
 
 ZRK_API int zrk_last_run_ticks_per_launch(zrk_ctx *ctx) { return ctx ? ctx->last_ticks_per_launch : ZRK_E_INVALID; }
+
+ZRK_API int zrk_sweep_stamps(zrk_ctx *ctx, int on)
+{
+    if (!ctx) return ZRK_E_INVALID;
+    ctx->stamps_on = on != 0;
+    if (!on) ctx->stamp_used = 0;
+    return 0;
+}
+
+ZRK_API int zrk_read_sweep_stamps(zrk_ctx *ctx, float *sweep_us, int32_t *ticks, int cap, void *stream)
+{
+    if (!ctx || !sweep_us || cap < 0) return fail(ctx, ZRK_E_INVALID, "zrk_read_sweep_stamps: null argument");
+    const int n = std::min(cap, ctx->stamp_used);
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    for (int k = 0; k < n; ++k)
+        hipLaunchKernelGGL(k_reduce_stamps, dim3(1), dim3(1024), 0, s, ctx->stamp_ring + (int64_t)k * ctx->stamp_slot_words, ctx->stamp_waves[k],
+                           ctx->stamp_out + 2 * k);
+    if (int rc = check_launch(ctx, "k_reduce_stamps")) return rc;
+    std::vector<unsigned long long> host(2 * (size_t)n);
+    if (hipMemcpyAsync(host.data(), ctx->stamp_out, sizeof(unsigned long long) * 2 * (size_t)n, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+        return fail(ctx, ZRK_E_HIP, "zrk_read_sweep_stamps: the stamps could not be read");
+    for (int k = 0; k < n; ++k) {
+        sweep_us[k] = (float)((double)(host[2 * k + 1] - host[2 * k]) * 0.01);       // 100 MHz: 10 ns a count
+        if (ticks) ticks[k] = ctx->stamp_ticks[k];
+    }
+    return n;
+}
 
 ZRK_API int zrk_run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int64_t m, zrk_loop *st,
                           zrk_radar *radars, const zrk_scan *scan, int R, void *workspace, int32_t *det_idx,

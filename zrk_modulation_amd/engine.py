@@ -380,6 +380,23 @@ class HotPathEngine:
         st.ctx.check(st.lib.zrk_read_sweep_ms(st.ctx.handle, out.ctypes.data_as(C.POINTER(C.c_float)), int(n)), "zrk_read_sweep_ms")
         return out
 
+    def sweep_stamps(self, on=True):
+        """The sweeps of the following run() calls time themselves (zrk_sweep_stamps, include/zrk_hot.h)."""
+        st = self.store
+        st.ctx.check(st.lib.zrk_sweep_stamps(st.ctx.handle, 1 if on else 0), "zrk_sweep_stamps")
+
+    def read_sweep_stamps(self, cap=64):
+        """(durations [us], ticks swept) of the sampled sweep launches of the last run() call, from the launches' own
+        wall-clock stamps (synchronises the stream)."""
+        C = self._C
+        us, ticks = np.zeros(int(cap), np.float32), np.zeros(int(cap), np.int32)
+        st = self.store
+        k = st.lib.zrk_read_sweep_stamps(st.ctx.handle, us.ctypes.data_as(C.POINTER(C.c_float)),
+                                         ticks.ctypes.data_as(C.POINTER(C.c_int32)), int(cap), st._stream())
+        if k < 0:
+            st.ctx.check(k, "zrk_read_sweep_stamps")
+        return us[:k], ticks[:k]
+
     def read_sweep_ticks(self, n):
         """Ticks swept by the launch behind each timing sample of the last run (1, or 2 for a pair launch)."""
         C = self._C

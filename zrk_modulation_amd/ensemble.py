@@ -191,6 +191,19 @@ class EnsembleEngine:
         st.ctx.check(st.lib.zrk_read_sweep_ms(st.ctx.handle, out.ctypes.data_as(C.POINTER(C.c_float)), int(n)), "zrk_read_sweep_ms")
         return out
 
+    def sweep_stamps(self, on=True):
+        st = self.store
+        st.ctx.check(st.lib.zrk_sweep_stamps(st.ctx.handle, 1 if on else 0), "zrk_sweep_stamps")
+
+    def read_sweep_stamps(self, cap=64):
+        us, ticks = np.zeros(int(cap), np.float32), np.zeros(int(cap), np.int32)
+        st = self.store
+        k = st.lib.zrk_read_sweep_stamps(st.ctx.handle, us.ctypes.data_as(C.POINTER(C.c_float)),
+                                         ticks.ctypes.data_as(C.POINTER(C.c_int32)), int(cap), st._stream())
+        if k < 0:
+            st.ctx.check(k, "zrk_read_sweep_stamps")
+        return us[:k], ticks[:k]
+
     # ---- results (each synchronises) ------------------------------------------------------------------------
     def alive_count(self):
         return int(self.store.d_alive[:self.S * self.P].sum().item())
