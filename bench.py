@@ -73,6 +73,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C3x4", "C4", "C5", "tiny", "tiny4", "tiny5"])
+    ap.add_argument("--wire", default="union", choices=["union", "masks"],
+                    help="N > 1: what a rank's per-tick list carries -- the bitmap of the slots seen by any radar (default), or the "
+                         "bitmap and the radar masks of the seen slots")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true",
                     help="skip the strong-scaling sub-record (configs[3], one population of 1e7) a default C3 run adds to its line")
@@ -370,7 +373,7 @@ def main():
             from zrk_modulation_amd.exchange import DetectionExchange, RcclExchange, union_bits_words
             n_slots = coll_device(torch.tensor([int(eng.store.cap)], dtype=torch.int64))
             all_reduce(n_slots, dist.ReduceOp.MAX)
-            words = union_bits_words(int(n_slots.item()), info["R"], entries)
+            words = union_bits_words(int(n_slots.item()), info["R"], 0 if args.wire == "union" else entries)
             offsets = [g * info["stride"] for g in range(world)]
             made = False
             if state["c_side"] and xchg["x"] is not None:
@@ -379,7 +382,7 @@ def main():
                 made = True
             elif state["c_side"]:
                 try:
-                    xchg["x"] = RcclExchange(words, device, info["R"], offsets=offsets, ev_capacity=ev_cap)
+                    xchg["x"] = RcclExchange(words, device, info["R"], offsets=offsets, ev_capacity=ev_cap, wire=args.wire)
                     made = True
                 except Exception as exc:                     # the library's own communicator could not be set up here
                     print(f"[bench rank {rank}] C-side exchange unavailable ({exc}); falling back to torch.distributed", file=sys.stderr)
@@ -392,7 +395,8 @@ def main():
                         xchg["x"] = None
                     state["c_side"] = False
             if not state["c_side"]:
-                xchg["ex"] = [DetectionExchange(words, device, fmt="bits", offsets=offsets, R=info["R"]) for _ in range(2)]
+                xchg["ex"] = [DetectionExchange(words, device, fmt="bits", offsets=offsets, R=info["R"], union_only=args.wire == "union")
+                              for _ in range(2)]
                 xchg["buf"] = [torch.zeros(words, dtype=torch.int64, device=device) for _ in range(2)]
                 xchg["work"] = [None, None]
             xchg["entries"], xchg["words"] = int(entries), int(words)
@@ -608,6 +612,16 @@ def main():
                 out["config"]["exchange_entries_per_rank"] = xchg["entries"]
                 out["config"]["exchange_bytes_per_rank"] = 8 * (xchg["words"] + (1 + ev_cap if state["c_side"] else 0))
                 out["config"]["exchange_overflow"] = bool(overflow)
+                out["config"]["exchange_wire"] = ("bitmap of the slots seen by any radar" if args.wire == "union" else
+                                                  "bitmap + radar masks of the seen slots") + " + detonation events"
+                if state["c_side"]:
+                    xi = xchg["x"].info()
+                    # the first multi-rank record checks itself: RCCL's own count of the communicator's ranks, and how long
+                    # the calling thread waited for collectives (per tick of the timed call and the calibration ticks behind it)
+                    out["config"]["rccl_ranks_seen"] = xi["rccl_ranks_seen"]
+                    out["config"]["exchange_pattern"] = xi["pattern"]
+                    out["config"]["exchange_host_wait_us_per_tick"] = xi["host_wait_us"] / max(1, xi["collectives"])
+                    out["config"]["exchange_host_waits"] = xi["host_waits"]
             if world == 1 and cpu_base and not ensemble:
                 out["cpu_baseline"] = cpu_baseline(info, eng, args.cpu_budget)
             elif world == 1 and cpu_base and ensemble:

@@ -458,6 +458,17 @@ int zrk_exchange_all_gather(zrk_exchange *x, int slot, const int64_t *send /* DE
 int zrk_exchange_wait(zrk_exchange *x, int slot, void *stream);
 /* Block the host until the exchange's stream is idle. */
 int zrk_exchange_sync(zrk_exchange *x);
+/* What the first multi-rank record needs to check itself: the communicator's own idea of its size (ncclCommCount; -1: this RCCL
+ * does not say), which pattern the collectives use (ZRK_EXCHANGE_ALGO=direct: grouped ncclSend / ncclRecv to every peer, one hop
+ * each, instead of ncclAllGather), how many collectives were issued, and how often / how long in all the calling thread had to
+ * wait for a collective posted ZRK_EXCHANGE_SLOTS ticks earlier before it could reuse its send buffer.  No reference
+ * counterpart (the reference is one process). */
+typedef struct zrk_exchange_stats {
+    int32_t world, rank, comm_ranks, direct, helper_threads, _pad;
+    int64_t collectives, host_waits;
+    double host_wait_us;
+} zrk_exchange_stats;
+int zrk_exchange_info(zrk_exchange *x, zrk_exchange_stats *out /* HOST */);
 
 /* What zrk_run_ticks_x sends each tick: this rank's list in the wire format of zrk_compact_bits, followed -- when
  * ev_capacity > 0 -- by the tick's detonations, so that MissileDetonateMessage (modules/Missile.py:138-146) reaches

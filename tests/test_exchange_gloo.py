@@ -67,18 +67,19 @@ def _worker(rank, world, port, n, R, q, fmt="pairs"):
         ex.all_gather(torch.from_numpy(_pack(vis, lo, cap)))
     else:
         from zrk_modulation_amd.exchange import encode_union_bits, union_bits_words
-        words = union_bits_words(shard, R, cap)
-        ex = DetectionExchange(words, torch.device("cpu"), fmt="bits", offsets=[g * shard for g in range(world)], R=R)
+        union_only = fmt == "union"                  # the bitmap alone: no room for masks, none sent
+        words = union_bits_words(shard, R, 0 if union_only else cap)
+        ex = DetectionExchange(words, torch.device("cpu"), fmt="bits", offsets=[g * shard for g in range(world)], R=R, union_only=union_only)
         ex.all_gather(torch.from_numpy(encode_union_bits(vis, R, words)))
     idx, mask = ex.merged()
-    lists = [ex.radar_list(r).numpy() for r in range(R)]
+    lists = [ex.radar_list(r).numpy() for r in range(R)] if mask is not None else None
     if rank == 0:
-        q.put((idx.numpy(), mask.numpy(), lists, ex.counts(), ex.overflowed()))
+        q.put((idx.numpy(), None if mask is None else mask.numpy(), lists, ex.counts(), ex.overflowed()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fmt", ["pairs", "bits"])
+@pytest.mark.parametrize("fmt", ["pairs", "bits", "union"])
 def test_two_rank_exchange_reproduces_single_process_order(fmt):
     n, R, world = 4000, 5, 2
     ctx = mp.get_context("spawn")
@@ -95,7 +96,11 @@ def test_two_rank_exchange_reproduces_single_process_order(fmt):
     vis = _masks(sp, radars)
     seen = np.nonzero(vis)[0]
     assert not overflow and sum(counts) == len(seen)
-    assert np.array_equal(idx, seen) and np.array_equal(mask.astype(np.uint32), vis[seen])
+    assert np.array_equal(idx, seen)
+    if fmt == "union":                               # who was seen by any radar, in list order; nothing else travels
+        assert mask is None and lists is None
+        return
+    assert np.array_equal(mask.astype(np.uint32), vis[seen])
     for r in range(R):
         assert np.array_equal(lists[r], np.nonzero((vis >> r) & 1)[0]), f"radar {r}: order differs from single process"
 

@@ -106,3 +106,41 @@ def test_a_collective_whose_list_never_came_goes_out_poisoned_and_fails_the_call
     with pytest.raises(PoisonedList):
         decode_events(x.recv[slot], 128)
     x.close()
+
+
+@pytest.mark.parametrize("algo", ["allgather", "direct"])
+def test_union_only_wire_and_the_direct_pattern_on_one_rank(algo, monkeypatch):
+    """wire "union": the bitmap of the slots seen by any radar and the events, nothing else (a fifth of the bytes); and
+    ZRK_EXCHANGE_ALGO=direct: grouped send / receive to every peer instead of ncclAllGather -- with one rank that is the local
+    copy, which is all a one-GPU box can run of it.  zrk_exchange_info says what the communicator thinks of itself."""
+    from zrk_modulation_amd.exchange import RcclExchange, union_bits_words
+    monkeypatch.setenv("ZRK_EXCHANGE_ALGO", algo)
+    monkeypatch.setenv("ZRK_OVERLAP_MIN_ROWS", "0")
+    n, R, m = 30_000, 6, 400
+    eng_a, _, _ = _engines(n, R, m, 11)
+    eng_b, _, _ = _engines(n, R, m, 11)
+    eng_b.gid0 = eng_b.loop.gid0 = 0
+    words = union_bits_words(eng_b.store.cap, R, 0)
+    assert words == 2 + (eng_b.store.cap + 63) // 64
+    x = RcclExchange(words, eng_b.store.device, R, offsets=[0], ev_capacity=512, wire="union")
+    st = eng_a.store
+    tick, events = 0, 0
+    for K in (1, 6, 1, 9):                          # plain loop, overlapped pair launches, an odd tail
+        eng_a.run(K)
+        eng_b.run(K, exchange=x)
+        tick += K
+        slot = (tick - 1) % x.slots
+        idx, msk = x.merged(slot)
+        vis = st.vis()[:st.n_uploaded].cpu().numpy().view(np.uint32)
+        assert msk is None and np.array_equal(idx.cpu().numpy(), np.nonzero(vis)[0]), f"after {tick} ticks: union list differs"
+        ne = int(st.dm_evn.item())
+        lidx = st.d_lidx.cpu().numpy() if st.d_lidx is not None else None
+        to_list = lambda r: int(lidx[r]) if lidx is not None else int(r)      # noqa: E731
+        want = [(to_list(a), -1 if b < 0 else to_list(b)) for a, b in zip(st.dm_evm[:ne].cpu().numpy(), st.dm_evt[:ne].cpu().numpy())]
+        assert x.events(slot) == want
+        events += ne
+    assert not x.overflowed()
+    info = x.info()
+    assert info["world"] == 1 and info["rccl_ranks_seen"] in (1, -1) and info["collectives"] == tick
+    assert info["pattern"] == ("direct send/recv" if algo == "direct" else "ncclAllGather")
+    x.close()

@@ -249,3 +249,30 @@ def test_c5_at_its_stated_size_every_scenario_matches_its_own_oracle():
     st.dm_period[:st.m] = torch.where(rows % 5 == 2, 0.005 + 0.01 * ((rows // 5) % 9).double(), st.dm_period[:st.m])
     events, seen = _check_ensemble(eng, ticks_single=3, call_ticks=6, dt_ms=10)
     assert events > 200 and seen > 128 * 1000
+
+
+def test_sweeps_time_themselves(monkeypatch):
+    """zrk_sweep_stamps: the sweep launches of a call write the wall clock as their first waves start and as every wave ends;
+    zrk_read_sweep_stamps gives one duration per launch and the ticks it swept -- pair launches of the overlapped loop, one-tick
+    launches of the plain loop, nothing when off -- and the durations agree with an event pair riding on the same dispatch
+    (which also holds the dispatch in front and the release behind: a few microseconds more, never less)."""
+    from tests.test_gpu_engine import _engine
+    monkeypatch.setenv("ZRK_OVERLAP_MIN_ROWS", "0")
+    eng, _, _ = _engine(120_000, 6, 300, seed=3, noise="philox")
+    us, ticks = eng.read_sweep_stamps()
+    assert len(us) == 0                                            # off by default
+    eng.sweep_stamps(True)
+    eng.run(13)                                                    # six pair launches and an odd tick
+    us, ticks = eng.read_sweep_stamps()
+    assert ticks.tolist() == [2] * 6 + [1] and ((us > 1.0) & (us < 2000.0)).all(), (us, ticks)
+    for _ in range(3):                                             # the plain loop, one event pair per launch beside the stamps
+        ms = np.zeros(1, np.float32)
+        eng.run(1, sweep_ms=ms, prof_stride=1)
+        us1, t1 = eng.read_sweep_stamps()
+        assert t1.tolist() == [1] and 1.0 < us1[0] <= ms[0] * 1e3 + 0.5 and us1[0] > 0.3 * ms[0] * 1e3, (us1, ms)
+    eng.run(150)                                                   # more launches than slots: every k-th is kept
+    us, ticks = eng.read_sweep_stamps()
+    assert 32 <= len(us) <= 64 and set(ticks.tolist()) == {2}
+    eng.sweep_stamps(False)
+    eng.run(6)
+    assert len(eng.read_sweep_stamps()[0]) == 0

@@ -102,6 +102,12 @@ class ZrkLaunchRes(C.Structure):
     ]
 
 
+class ZrkExchangeStats(C.Structure):
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("comm_ranks", C.c_int32), ("direct", C.c_int32),
+                ("helper_threads", C.c_int32), ("_pad", C.c_int32), ("collectives", C.c_int64), ("host_waits", C.c_int64),
+                ("host_wait_us", C.c_double)]
+
+
 def launch_dtypes():
     """numpy views of zrk_launch_req / zrk_launch_res arrays."""
     import numpy as np
@@ -204,6 +210,7 @@ _PROTOTYPES = {
     "zrk_exchange_all_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "zrk_exchange_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "zrk_exchange_sync": (C.c_int, [C.c_void_p]),
+    "zrk_exchange_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "zrk_last_run_overlapped": (C.c_int, [C.c_void_p]),
     "zrk_read_sweep_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "zrk_noise_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p,

@@ -1756,10 +1756,35 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_side(const CompactArgs C
 __device__ __forceinline__ void missile_events_any(int *s_wave /* [16] */, const MissileArgs &M)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, T = (int)blockDim.x, waves = T >> 6;
-    const int64_t per = (M.m + T - 1) / T;
+    // each thread's run of rows: a multiple of 16, so that its codes come in with 16-byte loads that are all in flight at once
+    // (a thread of a 256-thread workgroup owns 40-odd rows of ten thousand: read a byte at a time, one after the other, that
+    // was 30 us of dependent loads -- the whole compaction launch waited for its event workgroups)
+    constexpr int kMaxVec = 4;                       // 16-byte pieces per thread: 16 384 rows (1024 * kMissileItems) at 256 threads
+    const int64_t per = (((M.m + T - 1) / T) + 15) & ~(int64_t)15;
     const int64_t row0 = (int64_t)tid * per, row1 = (row0 + per < M.m) ? row0 + per : M.m;
+    const bool vec = (((uintptr_t)M.ev_code & 15) == 0) && per <= 16 * kMaxVec;
+    uint4 cv[kMaxVec];
+#pragma unroll
+    for (int j = 0; j < kMaxVec; ++j) {
+        cv[j] = uint4{0u, 0u, 0u, 0u};
+        const int64_t r = row0 + 16 * j;
+        if (vec && 16 * j < per && r + 16 <= M.m) cv[j] = *(const uint4 *)(M.ev_code + r);
+    }
     int cnt = 0;
-    for (int64_t row = row0; row < row1; ++row) cnt += M.ev_code[row] != 0;
+    if (vec) {
+#pragma unroll
+        for (int j = 0; j < kMaxVec; ++j) {
+            const uint32_t w[4] = {cv[j].x, cv[j].y, cv[j].z, cv[j].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)                      // bytes that are not zero (codes are 0, 1 or 2)
+                cnt += (int)__popc(((w[q] | (w[q] >> 1)) & 0x01010101u));
+            const int64_t r = row0 + 16 * j;
+            if (16 * j < per && r < M.m && r + 16 > M.m)          // the table's last, partial piece: byte by byte
+                for (int64_t row = r; row < M.m; ++row) cnt += M.ev_code[row] != 0;
+        }
+    } else {
+        for (int64_t row = row0; row < row1; ++row) cnt += M.ev_code[row] != 0;
+    }
     int incl = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -4311,6 +4336,12 @@ struct RcclApi {
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    // (optional: the direct pattern and the self-check)
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
 };
 
 constexpr int kNcclInt64 = 4;          // ncclDataType_t: ncclInt64
@@ -4329,6 +4360,11 @@ bool load_rccl(const char *path, RcclApi &api, std::string &err)
     api.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(api.lib, "ncclAllGather");
     api.CommDestroy = (int (*)(void *))dlsym(api.lib, "ncclCommDestroy");
     api.GetErrorString = (const char *(*)(int))dlsym(api.lib, "ncclGetErrorString");
+    api.Send = (int (*)(const void *, size_t, int, int, void *, hipStream_t))dlsym(api.lib, "ncclSend");
+    api.Recv = (int (*)(void *, size_t, int, int, void *, hipStream_t))dlsym(api.lib, "ncclRecv");
+    api.GroupStart = (int (*)())dlsym(api.lib, "ncclGroupStart");
+    api.GroupEnd = (int (*)())dlsym(api.lib, "ncclGroupEnd");
+    api.CommCount = (int (*)(void *, int *))dlsym(api.lib, "ncclCommCount");
     if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) { err = "RCCL symbols missing"; return false; }
     return true;
 }
@@ -4360,6 +4396,13 @@ struct zrk_exchange {
     uint64_t side_item_no[ZRK_EXCHANGE_SLOTS] = {};
     bool one_helper = false;
     bool wait_in_stream = false;                        // ZRK_EXCHANGE_WAIT_IN_STREAM=1, see zrk_exchange_wait
+    // ZRK_EXCHANGE_ALGO=direct: every rank sends its list straight to each of its world - 1 peers (grouped ncclSend / ncclRecv:
+    // one hop over the peer's own xGMI link, all links at once) instead of ncclAllGather, whose ring passes every list through
+    // world - 1 links one after the other.  Default: ncclAllGather, as RCCL chooses to run it
+    bool direct = false;
+    // self-check for the first multi-rank record: what the communicator says its size is, how often and how long the calling
+    // thread had to wait for a collective posted ZRK_EXCHANGE_SLOTS ticks before (zrk_exchange_info)
+    std::atomic<int64_t> waits{0}, wait_ns{0}, collectives{0};
     // ... and those collectives are issued by a thread of the exchange's own: waiting for the value, the RCCL call and the
     // event record take the calling thread longer than the two launches of a tick, and the device would wait for its host
     struct PostItem { int slot; const int64_t *send; int64_t *recv; int64_t words; uint32_t value; };
@@ -4379,6 +4422,7 @@ struct zrk_exchange {
 namespace {
 
 int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, int64_t *recv, int64_t words, uint32_t value);
+int exchange_collective(zrk_exchange *x, const int64_t *send, int64_t *recv, int64_t words);
 __global__ void k_poison_if_gave_up(const uint32_t *gave_up, int64_t *send);
 
 // the wait kernel of some collective gave up (k_wait_flag): that list and every later one went out poisoned
@@ -4499,6 +4543,10 @@ ZRK_API int zrk_exchange_create(const char *rccl_path, const zrk_rccl_id *id, in
         ok = hipEventCreateWithFlags(&x->ready[k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&x->done[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) { x->err = "stream / event creation failed"; return ZRK_E_HIP; }
+    if (const char *algo = std::getenv("ZRK_EXCHANGE_ALGO")) {
+        x->direct = std::strcmp(algo, "direct") == 0;
+        if (x->direct && !(x->api.Send && x->api.Recv && x->api.GroupStart && x->api.GroupEnd)) { x->err = "ZRK_EXCHANGE_ALGO=direct: this RCCL has no ncclSend / ncclRecv"; return ZRK_E_HIP; }
+    }
     const char *in_stream = std::getenv("ZRK_EXCHANGE_WAIT_IN_STREAM");
     x->wait_in_stream = in_stream && in_stream[0] == '1';
     const char *force_events = std::getenv("ZRK_EXCHANGE_EVENTS");
@@ -4544,6 +4592,34 @@ ZRK_API void zrk_exchange_destroy(zrk_exchange *x)
 
 ZRK_API const char *zrk_exchange_last_error(zrk_exchange *x) { return x ? x->err.c_str() : "null exchange"; }
 
+namespace {
+// One tick's collective on the exchange's stream: recv[g] = rank g's send, for every g.
+int exchange_collective(zrk_exchange *x, const int64_t *send, int64_t *recv, int64_t words)
+{
+    x->collectives.fetch_add(1, std::memory_order_relaxed);
+    auto why = [&](const char *what, int rc) { x->err = std::string(what) + ": " + (x->api.GetErrorString ? x->api.GetErrorString(rc) : "error"); return ZRK_E_HIP; };
+    if (!x->direct) {
+        const int rc = x->api.AllGather(send, recv, (size_t)words, kNcclInt64, x->comm, x->cstream);
+        return rc != 0 ? why("ncclAllGather", rc) : 0;
+    }
+    // own list: a copy on the same stream; the others: one send and one receive per peer, grouped
+    if (hipMemcpyAsync(recv + (int64_t)x->rank * words, send, sizeof(int64_t) * (size_t)words, hipMemcpyDeviceToDevice, x->cstream) != hipSuccess) {
+        x->err = "the exchange's local copy failed"; return ZRK_E_HIP;
+    }
+    if (x->world == 1) return 0;
+    int rc = x->api.GroupStart();
+    for (int k = 1; k < x->world && rc == 0; ++k) {
+        // (rank r talks to r + k and r - k in step k: every step pairs the ranks off differently, every link is used once)
+        const int to = (x->rank + k) % x->world, from = (x->rank - k + x->world) % x->world;
+        rc = x->api.Send(send, (size_t)words, kNcclInt64, to, x->comm, x->cstream);
+        if (rc == 0) rc = x->api.Recv(recv + (int64_t)from * words, (size_t)words, kNcclInt64, from, x->comm, x->cstream);
+    }
+    const int rce = x->api.GroupEnd();
+    if (rc != 0) return why("ncclSend / ncclRecv", rc);
+    return rce != 0 ? why("ncclGroupEnd", rce) : 0;
+}
+}  // namespace
+
 ZRK_API int zrk_exchange_all_gather(zrk_exchange *x, int slot, const int64_t *send, int64_t *recv, int64_t words, void *stream)
 {
     if (!x || !x->comm || !send || !recv || words <= 0 || slot < 0 || slot >= ZRK_EXCHANGE_SLOTS) return ZRK_E_INVALID;
@@ -4555,8 +4631,7 @@ ZRK_API int zrk_exchange_all_gather(zrk_exchange *x, int slot, const int64_t *se
         hipLaunchKernelGGL(k_poison_if_gave_up, dim3(1), dim3(1), 0, x->cstream, x->gave_up_dev, (int64_t *)send);
         if (hipGetLastError() != hipSuccess) { x->err = "k_poison_if_gave_up launch failed"; return ZRK_E_HIP; }
     }
-    const int rc = x->api.AllGather(send, recv, (size_t)words, kNcclInt64, x->comm, x->cstream);
-    if (rc != 0) { x->err = std::string("ncclAllGather: ") + (x->api.GetErrorString ? x->api.GetErrorString(rc) : "error"); return ZRK_E_HIP; }
+    if (int rc = exchange_collective(x, send, recv, words)) return rc;
     if (hipEventRecord(x->done[slot], x->cstream) != hipSuccess) { x->err = "hipEventRecord failed"; return ZRK_E_HIP; }
     x->posted[slot] = true;
     return 0;
@@ -4612,8 +4687,7 @@ int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, in
     // job but cost the compute stream 3.5 us a tick in the measurement, this costs it nothing measurable)
     hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, x->cstream, x->flag, value, x->gave_up_dev, (int64_t *)send, x->wait_spins);
     if (hipGetLastError() != hipSuccess) { x->err = "k_wait_flag launch failed"; return ZRK_E_HIP; }
-    const int rc = x->api.AllGather(send, recv, (size_t)words, kNcclInt64, x->comm, x->cstream);
-    if (rc != 0) { x->err = std::string("ncclAllGather: ") + (x->api.GetErrorString ? x->api.GetErrorString(rc) : "error"); return ZRK_E_HIP; }
+    if (int rc = exchange_collective(x, send, recv, words)) return rc;
     if (hipEventRecord(x->done[slot], x->cstream) != hipSuccess) { x->err = "hipEventRecord failed"; return ZRK_E_HIP; }
     x->posted[slot] = true;
     return 0;
@@ -4637,11 +4711,26 @@ ZRK_API int zrk_exchange_wait(zrk_exchange *x, int slot, void *stream)
         return 0;
     }
     hipError_t q = hipErrorNotReady;
-    if (!spin_until([&] { q = hipEventQuery(x->done[slot]); return q != hipErrorNotReady; })) {
+    const auto t_wait = std::chrono::steady_clock::now();
+    const bool came = spin_until([&] { q = hipEventQuery(x->done[slot]); return q != hipErrorNotReady; });
+    x->waits.fetch_add(1, std::memory_order_relaxed);
+    x->wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_wait).count(), std::memory_order_relaxed);
+    if (!came) {
         x->err = "a collective posted ZRK_EXCHANGE_SLOTS ticks ago is not through within the host wait limit (ZRK_HOST_WAIT_MS): a peer rank is gone or stuck";
         return ZRK_E_STATE;
     }
     if (q != hipSuccess) { x->err = "hipEventQuery failed"; return ZRK_E_HIP; }
+    return 0;
+}
+
+ZRK_API int zrk_exchange_info(zrk_exchange *x, zrk_exchange_stats *out)
+{
+    if (!x || !out) return ZRK_E_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    out->world = x->world; out->rank = x->rank; out->direct = x->direct ? 1 : 0; out->helper_threads = x->one_helper ? 1 : 2;
+    out->comm_ranks = -1;
+    if (x->comm && x->api.CommCount) { int c = -1; if (x->api.CommCount(x->comm, &c) == 0) out->comm_ranks = c; }
+    out->collectives = x->collectives.load(); out->host_waits = x->waits.load(); out->host_wait_us = (double)x->wait_ns.load() * 1e-3;
     return 0;
 }
 

@@ -53,13 +53,21 @@ def check_not_poisoned(gathered):
         raise PoisonedList(f"the list of rank(s) {bad} is poisoned: its producer never handed it over to the collective")
 
 
-def decode_union_bits(gathered, R, offsets, ev_capacity=0):
+def decode_union_bits(gathered, R, offsets, ev_capacity=0, union_only=False):
     """Global union list from gathered wire-format buffers int64[world, words]: (indices int64, masks int64) in index
-    order.  Synchronises."""
+    order.  union_only: the buffers carry the bitmap alone (no masks behind it): (indices, None).  Synchronises."""
     world, words = gathered.shape
     check_not_poisoned(gathered)
     tail = 1 + int(ev_capacity) if ev_capacity else 0
     idx, msk = [], []
+    if union_only:
+        shifts = torch.arange(64, dtype=torch.int64, device=gathered.device)
+        for g in range(world):
+            n = int(gathered[g, 1].item())
+            nw = (n + 63) // 64
+            bits = ((gathered[g, 2:2 + nw].unsqueeze(1) >> shifts) & 1).reshape(-1)[:n]
+            idx.append(torch.nonzero(bits).reshape(-1) + offsets[g])
+        return (torch.cat(idx) if idx else gathered.new_zeros(0)), None
     shifts = torch.arange(64, dtype=torch.int64, device=gathered.device)
     for g in range(world):
         c, n = int(gathered[g, 0].item()), int(gathered[g, 1].item())
@@ -104,7 +112,10 @@ class RcclExchange:
     stream; zrk_run_ticks_x posts one all-gather per tick behind that tick's compaction, so no Python runs between a
     tick and its collective.  torch.distributed is used once, to hand rank 0's communicator id to the others."""
 
-    def __init__(self, words, device, R, offsets=None, ev_capacity=0, group=None):
+    def __init__(self, words, device, R, offsets=None, ev_capacity=0, group=None, wire="masks"):
+        """wire "masks": count, n, one bit per slot, the 16- or 32-bit radar masks of the seen slots (`words` from
+        union_bits_words(n, R, entries)); wire "union": the bitmap alone (union_bits_words(n, R, 0)): who was seen by
+        any radar, a fifth of the bytes -- what crosses xGMI when no consumer on another rank asks which radar saw it."""
         import ctypes as C
         from . import _lib
         self._C, self.lib = C, _lib.load()
@@ -112,6 +123,7 @@ class RcclExchange:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = torch.device(device)
         self.R, self.ev_capacity = int(R), int(ev_capacity)
+        self.union_only = wire == "union"
         self.words = int(words) + (1 + self.ev_capacity if self.ev_capacity else 0)
         self.offsets = list(offsets) if offsets is not None else [0] * self.world
         path = rccl_library_path()
@@ -178,12 +190,23 @@ class RcclExchange:
         for r in self.recv:
             check_not_poisoned(r)
         room = self.room()
+        if self.union_only:
+            room = 1 << 62                     # (nothing but the bitmap travels: no list to run out of room)
         ev_over = self.ev_capacity and any(int(r[:, self.words - 1 - self.ev_capacity].max().item()) > self.ev_capacity for r in self.recv)
         return any(c > room for r in self.recv for c in r[:, 0].cpu().tolist()) or bool(ev_over)
 
     def merged(self, slot):
         self.sync()
-        return decode_union_bits(self.recv[slot], self.R, self.offsets, self.ev_capacity)
+        return decode_union_bits(self.recv[slot], self.R, self.offsets, self.ev_capacity, self.union_only)
+
+    def info(self):
+        """zrk_exchange_info: the communicator's own size, the pattern in use, collectives issued, host waits."""
+        st = self._lib_mod.ZrkExchangeStats()
+        rc = self.lib.zrk_exchange_info(self.handle, self._C.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"zrk_exchange_info failed ({rc})")
+        return {"world": st.world, "rank": st.rank, "rccl_ranks_seen": st.comm_ranks, "pattern": "direct send/recv" if st.direct else "ncclAllGather",
+                "helper_threads": st.helper_threads, "collectives": st.collectives, "host_waits": st.host_waits, "host_wait_us": st.host_wait_us}
 
     def events(self, slot):
         self.sync()
@@ -202,7 +225,7 @@ class RcclExchange:
 
 
 class DetectionExchange:
-    def __init__(self, capacity, device, group=None, fmt="pairs", offsets=None, R=None):
+    def __init__(self, capacity, device, group=None, fmt="pairs", offsets=None, R=None, union_only=False):
         """fmt "pairs": buffers of capacity + 1 words, [count, (global index << 32 | mask) ...].
         fmt "bits": buffers of `capacity` WORDS in the wire format of zrk_compact_bits (union_bits_words); the slot
         numbers are local to each rank, `offsets[g]` is added to rank g's when the lists are merged, `R` tells the
@@ -214,6 +237,7 @@ class DetectionExchange:
         self.fmt = fmt
         self.offsets = list(offsets) if offsets is not None else [0] * self.world
         self.R = R
+        self.union_only = bool(union_only) and fmt == "bits"       # the bitmap alone (see RcclExchange: wire "union")
         words = self.capacity + 1 if fmt == "pairs" else self.capacity
         self.gathered = torch.zeros(self.world, words, dtype=torch.int64, device=device)
         backend = dist.get_backend(group) if dist.is_initialized() else "none"
@@ -247,6 +271,8 @@ class DetectionExchange:
     def overflowed(self):
         if self.fmt == "pairs":
             return any(c > self.capacity for c in self.counts())
+        if self.union_only:
+            return False
         return any(c > self._room(g) for g, c in enumerate(self.counts()))
 
     def merged(self):
@@ -256,6 +282,8 @@ class DetectionExchange:
             parts = [self.gathered[g, 1:1 + min(c, self.capacity)] for g, c in enumerate(cnt)]
             allp = torch.cat(parts) if parts else self.gathered.new_zeros(0)
             return allp >> 32, allp & 0xFFFFFFFF
+        if self.union_only:
+            return decode_union_bits(self.gathered, self.R, self.offsets, 0, True)
         idx, msk = [], []
         shifts = torch.arange(64, dtype=torch.int64, device=self.gathered.device)
         for g, c in enumerate(cnt):
