@@ -337,7 +337,45 @@ __host__ __device__ inline void scan_advance_one(zrk_radar &rd, const zrk_scan &
     }                               // any other mode string: the reference does nothing
 }
 
-__host__ __device__ inline void derive_radar(const zrk_radar &hr, double d2_max, bool exact_only, RadarHot &h, RadarCold &c)
+// The host derives the records of all radars of a scenario twice per launch, and radars of one battery often share their
+// angles (the benchmark's sixteen turn in phase): the last few sines are kept, by the argument's bits -- the same calls, the
+// same results, a tenth of the trigonometry (6 us per sixteen radars otherwise, on the thread that launches the sweeps).
+struct TrigMemo {
+    int ns = 0, nsc = 0;
+    double sx[8], sv[8], scx[8], scs[8], scc[8];
+};
+
+__host__ __device__ inline double memo_sin(TrigMemo *m, double x)
+{
+#ifndef __HIP_DEVICE_COMPILE__
+    if (m) {
+        for (int k = 0; k < (m->ns < 8 ? m->ns : 8); ++k)
+            if (std::memcmp(&m->sx[k], &x, sizeof(x)) == 0) return m->sv[k];
+        const double v = sin(x);
+        const int k = m->ns++ & 7;
+        m->sx[k] = x; m->sv[k] = v;
+        return v;
+    }
+#endif
+    return sin(x);
+}
+
+__host__ __device__ inline void memo_sincos(TrigMemo *m, double x, double *sv, double *cv)
+{
+#ifndef __HIP_DEVICE_COMPILE__
+    if (m) {
+        for (int k = 0; k < (m->nsc < 8 ? m->nsc : 8); ++k)
+            if (std::memcmp(&m->scx[k], &x, sizeof(x)) == 0) { *sv = m->scs[k]; *cv = m->scc[k]; return; }
+        sincos(x, sv, cv);
+        const int k = m->nsc++ & 7;
+        m->scx[k] = x; m->scs[k] = *sv; m->scc[k] = *cv;
+        return;
+    }
+#endif
+    sincos(x, sv, cv);
+}
+
+__host__ __device__ inline void derive_radar(const zrk_radar &hr, double d2_max, bool exact_only, RadarHot &h, RadarCold &c, TrigMemo *memo = nullptr)
 {
     const double deg = 3.14159265358979323846 / 180.0;
     h = RadarHot{};
@@ -366,8 +404,8 @@ __host__ __device__ inline void derive_radar(const zrk_radar &hr, double d2_max,
     // min(-c1,-c2) < 0, so the edges are stored negated and az_sgn = -1 flips the minimum back
     h.az_sgn = (hi - lo <= 180.0) ? 1.f : -1.f;
     double s_lo, c_lo, s_hi, c_hi;
-    sincos(lo * deg, &s_lo, &c_lo);
-    sincos(hi * deg, &s_hi, &c_hi);
+    memo_sincos(memo, lo * deg, &s_lo, &c_lo);
+    memo_sincos(memo, hi * deg, &s_hi, &c_hi);
     c.az_sgn = exact_only ? 0.0 : (double)h.az_sgn;        // ZRK_F_EXACT_ONLY: the reference's formula and nothing else
     c.elx = (double)h.az_sgn * c_lo; c.ely = (double)h.az_sgn * s_lo;
     c.ehx = (double)h.az_sgn * c_hi; c.ehy = (double)h.az_sgn * s_hi;
@@ -375,17 +413,17 @@ __host__ __device__ inline void derive_radar(const zrk_radar &hr, double d2_max,
     // elevation: dz >= 0 -> el = theta in [0,90];  dz < 0 -> el = 180 + theta in [90,180]
     const double lo_u = fmax(c.el_lo, 0.0), hi_u = fmin(c.el_hi, 90.0);
     if (lo_u <= hi_u) {
-        h.s_lo_up = (c.el_lo <= 0.0) ? -2.f : (float)sin(lo_u * deg);
-        h.s_hi_up = (c.el_hi >= 90.0) ? 2.f : (float)sin(hi_u * deg);
-        c.s_lo_up = (c.el_lo <= 0.0) ? -2.0 : sin(lo_u * deg);
-        c.s_hi_up = (c.el_hi >= 90.0) ? 2.0 : sin(hi_u * deg);
+        h.s_lo_up = (c.el_lo <= 0.0) ? -2.f : (float)memo_sin(memo, lo_u * deg);
+        h.s_hi_up = (c.el_hi >= 90.0) ? 2.f : (float)memo_sin(memo, hi_u * deg);
+        c.s_lo_up = (c.el_lo <= 0.0) ? -2.0 : memo_sin(memo, lo_u * deg);
+        c.s_hi_up = (c.el_hi >= 90.0) ? 2.0 : memo_sin(memo, hi_u * deg);
     }
     const double lo_d = fmax(c.el_lo - 180.0, -90.0), hi_d = fmin(c.el_hi - 180.0, 0.0);
     if (lo_d <= hi_d) {
-        h.s_lo_dn = (c.el_lo - 180.0 <= -90.0) ? -2.f : (float)sin(lo_d * deg);
-        h.s_hi_dn = (c.el_hi >= 180.0) ? 2.f : (float)sin(hi_d * deg);
-        c.s_lo_dn = (c.el_lo - 180.0 <= -90.0) ? -2.0 : sin(lo_d * deg);
-        c.s_hi_dn = (c.el_hi >= 180.0) ? 2.0 : sin(hi_d * deg);
+        h.s_lo_dn = (c.el_lo - 180.0 <= -90.0) ? -2.f : (float)memo_sin(memo, lo_d * deg);
+        h.s_hi_dn = (c.el_hi >= 180.0) ? 2.f : (float)memo_sin(memo, hi_d * deg);
+        c.s_lo_dn = (c.el_lo - 180.0 <= -90.0) ? -2.0 : memo_sin(memo, lo_d * deg);
+        c.s_hi_dn = (c.el_hi >= 180.0) ? 2.0 : memo_sin(memo, hi_d * deg);
     }
 }
 
@@ -3720,13 +3758,14 @@ void fill_radar_block(zrk_ctx *ctx, const zrk_radar *radars, int R, uint32_t fla
         }
     }
     std::memset(&rb, 0, sizeof(rb));
+    TrigMemo memo;
     for (int r = 0; r < ZRK_MAX_RADARS; ++r) {
         RadarPre pre;
         std::memset(&pre, 0, sizeof(pre));
         pre.d2_out = -1.f;                                  // beyond R: nobody is a candidate
         if (r < R) {
             RadarHot hot;
-            derive_radar(radars[r], ctx->d2_of(radars[r].max_distance, r), (flags & ZRK_F_EXACT_ONLY) != 0, hot, rb.cold[r]);
+            derive_radar(radars[r], ctx->d2_of(radars[r].max_distance, r), (flags & ZRK_F_EXACT_ONLY) != 0, hot, rb.cold[r], &memo);
             std::memcpy(rb.hotw[r], &hot, sizeof(hot));
             derive_pre(radars[r], hot, (flags & ZRK_F_PHILOX) != 0, r, pre);
         }
@@ -3987,8 +4026,12 @@ ZRK_API int zrk_compact_status(zrk_ctx *ctx, void *workspace, void *stream)
         uint32_t bar[2] = {0, 0};
         if (hipMemcpy(bar, ctx->side->bar, sizeof(bar), hipMemcpyDeviceToHost) != hipSuccess)
             return fail(ctx, ZRK_E_HIP, "zrk_compact_status: the missile barrier's words could not be read");
-        if (bar[1] != 0)
+        if (bar[1] != 0) {
+            // reported once: the word goes down again (every workgroup counts itself in whether it gave up or not, so the arrival
+            // counter still matches the epoch), and the next call starts clean
+            (void)hipMemset(ctx->side->bar + 1, 0, sizeof(uint32_t));
             return fail(ctx, ZRK_E_STATE, "a pair launch's missile workgroups did not all reach their barrier: the second tick's events are not valid");
+        }
     }
     uint32_t dev_fault = 0;
     if (hipMemcpyFromSymbol(&dev_fault, HIP_SYMBOL(g_device_fault), sizeof(dev_fault)) != hipSuccess)
@@ -5092,6 +5135,9 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             if (hipStreamSynchronize(sd->stream) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
                 return fail(ctx, ZRK_E_HIP, "zrk_run_ticks: the side stream did not drain after its thread's failure");
             *sd->hflag = 0u; sd->seq = 0;
+            // (both streams are drained: the missile barrier's words start afresh with the rest)
+            if (hipMemset(sd->bar, 0, 64) != hipSuccess) return fail(ctx, ZRK_E_HIP, "zrk_run_ticks: the missile barrier's words could not be cleared");
+            sd->bar_epoch = 0;
             sd->masks_dirty = true; sd->pend_rows = 0; sd->joined_upto = 0; sd->joined_stream = nullptr;
             sd->err.clear();
             sd->rc.store(0);
@@ -5292,7 +5338,9 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         M.pend = sd->pend; M.mark = mark_a; M.mark2 = mark_b; M.apply = 0;
         M.t2 = (double)(st->time_ms + st->dt_ms) / 1000.0;
         const int mb = nblocks(M.m, ZRK_BLOCK);
-        if (nt == 2 && mb > 0) { sd->bar_epoch += (uint32_t)mb; M.bar = sd->bar; M.bar_target = sd->bar_epoch; }
+        // (the arrivals asked for so far move on only once the launch is out: a launch that fails must not leave the target ahead
+        // of the counter, or every later pair launch would spin its barrier out)
+        if (nt == 2 && mb > 0) { M.bar = sd->bar; M.bar_target = sd->bar_epoch + (uint32_t)mb; }
         // the two compactions of the pair as ONE launch, where the table allows it (k_compact_pair)
         // (up to 512 workgroups: beyond, beside a sweep of that size, two launches of half as many fatter workgroups are faster
         // -- 89 against 94 us per tick at 4e6 rows)
@@ -5346,6 +5394,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         rc = rc_sweep;
         g_trace.mark(nt == 2 ? "run_ticks: pair launched" : "run_ticks: sweep launched");
         if (rc_sweep != 0) { st->vis_cur = vis_cur_before; break; }
+        if (nt == 2 && mb > 0) sd->bar_epoch += (uint32_t)mb;
         marks_used = true;
         if (ordering) { ctx->order_ready = true; ctx->order_phase = oph ^ 1; }
         // the radars move on by the ticks swept, and the next launch's records are derived while this one runs
