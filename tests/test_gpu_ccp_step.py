@@ -258,3 +258,16 @@ def test_launch_requests_feed_the_salvo_without_the_host():
     twin.run(6)
     assert eng.alive_count() == twin.alive_count()
     assert np.array_equal(eng.store.host_pos("cur")[n0:n0 + c].view(np.uint64), twin.store.host_pos("cur")[n0:n0 + c].view(np.uint64))
+    # the rows behind the successes are given back before the next salvo: the tables do not grow by k_max dead rows per call
+    assert st.n_uploaded == n0 + k_max and st.m == m0 + k_max
+    assert eng.settle_device_launches() == k_max - c and twin.settle_device_launches() == len(asked) - c
+    assert st.n_uploaded == n0 + c == twin.store.n_uploaded and st.m == m0 + c == twin.store.m
+    again = torch.from_numpy(want[:200].view(np.uint8).reshape(-1).copy()).cuda()
+    c2 = [int(e.launch_requests_on_device(again, 200).item()) for e in (eng, twin)]
+    assert c2[0] == c2[1] > 0 and eng.store.n_uploaded == n0 + c + 200
+    eng.run(5)
+    twin.run(5)
+    assert eng.alive_count() == twin.alive_count()
+    assert np.array_equal(eng.store.host_pos("cur")[:n0 + c + c2[0]].view(np.uint64), twin.store.host_pos("cur")[:n0 + c + c2[0]].view(np.uint64))
+    for r, (x, y) in enumerate(zip(eng.detections(), twin.detections())):
+        assert np.array_equal(x, y), f"radar {r}"

@@ -310,10 +310,15 @@ class HotPathEngine:
         """zrk_launch_salvo for k requests that already are on the device (a uint8 tensor of zrk_launch_req, e.g. from
         association.DeviceCommandPost.requests: target ROWS, padded with requests for no row): nothing is uploaded, nothing read
         back; the table grows by k rows (the failed and the padding requests' rows sit dead behind the successes).  Returns
-        the int32 device tensor [1] that receives the number of missiles that entered the air."""
+        the int32 device tensor [1] that receives the number of missiles that entered the air.
+
+        The dead rows do not pile up from call to call: the NEXT call (or settle_device_launches()) reads this call's count
+        -- long written by then, so nothing waits -- and gives the rows behind the successes back, provided nothing else
+        was appended in between."""
         C, _lib = self._C, self._lib
         st = self.store
         k = int(k)
+        self.settle_device_launches()
         count = torch.zeros(1, dtype=torch.int32, device=st.device)
         if k == 0:
             return count
@@ -338,7 +343,30 @@ class HotPathEngine:
         self.loop.n = st.n_uploaded
         self.launch_results = None
         self._last_device_results = d_res
+        self._pending_launch = (n0, st.m - k, list_base, k, count)
         return count
+
+    def settle_device_launches(self):
+        """The rows the last launch_requests_on_device call took for requests that did not put a missile in the air (failed
+        solves, padding) are given back: its count is read (one int32) and table, missile table and list shrink to the
+        successes.  Nothing happens when other rows were appended behind that call's."""
+        pend, self._pending_launch = getattr(self, "_pending_launch", None), None
+        if pend is None:
+            return 0
+        st = self.store
+        n0, m0, list_base, k, count = pend
+        if st.n != n0 + k or st.n_uploaded != st.n or st.m != m0 + k or self.n_list != list_base + k:
+            return 0
+        j = k - int(count.item())
+        if j <= 0:
+            return 0
+        st.drop_tail_rows(j)
+        st.m -= j
+        self.n_list -= j
+        if self.row_of_list is not None:
+            self.row_of_list = self.row_of_list[:-j]
+        self.loop.n = st.n_uploaded
+        return j
 
     def run(self, K, sweep_ms=None, prof_stride=1, exchange=None):
         """Enqueue K ticks.  With `sweep_ms` (a float32 numpy array of ceil(K/prof_stride)) the call

@@ -112,7 +112,15 @@ class CombatControlPoint(BaseModel):
     def check_if_missiles_launched(self):
         for msg in self._manager.give_messages_by_type(MessageType.LAUNCHED_MISSILE):
             self.add_missile(MissileCCP(msg.missile, self._now_s()))
-            self._post_stale = True       # (event rate: the mirror is rebuilt from the dictionaries)
+            # the device mirror takes the one new entry (zrk_ccp_add_missile) when the missile already is a row of its table;
+            # a missile that has not entered the air yet (the launcher announces it a tick before AirEnv appends it,
+            # MissileLauncher.py:103-124) has no row: the mirror is rebuilt from the dictionaries then
+            post, m = self._post, msg.missile
+            if (post is not None and not self._post_stale and getattr(m, "_store", None) is not None and m._slot >= 0
+                    and getattr(m, "_frozen", None) is None and m._store.device == post.dev):
+                post.add_missile(m._slot, self._now_s())
+            else:
+                self._post_stale = True
 
     # track association ---------------------------------------------------------------------------
     def _gate(self, detected, ref_pos, ref_time):
@@ -224,17 +232,23 @@ class CombatControlPoint(BaseModel):
         if self._post is None or self._post.dev != store.device or self._post.key_tt.numel() < store.cap or self._post.tcap < cap:
             self._post = DeviceCommandPost(store.ctx, store.device, store.cap, cap, list(self.missile_launcher_coords.values()),
                                            [0] * len(ml_ids), dmax=store.cap)
-            self._post_speed = np.zeros(store.cap)
+            self._post_speed_dev = torch.zeros(store.cap, dtype=torch.float64, device=store.device)
+            self._post_speed_known = np.zeros(store.cap, bool)
             self._post_stale = True
         post = self._post
-        for o, _ in dets:
-            self._post_speed[o._slot] = o.speed_mod
+        # speed_mod is a column of the device post, written once per row when the row is first detected
+        fresh = [o for o, _ in dets if not self._post_speed_known[o._slot]]
+        if fresh:
+            rows_new = torch.tensor([o._slot for o in fresh], dtype=torch.int64, device=store.device)
+            self._post_speed_dev[rows_new] = torch.tensor([o.speed_mod for o in fresh], dtype=torch.float64, device=store.device)
+            for o in fresh:
+                self._post_speed_known[o._slot] = True
         if self._post_stale and not self._mirror_dictionaries(post, store, now_s):
             return host("mirror")
         if ml_ids:
             post.l_cap.copy_(torch.tensor([self.missile_launcher_capacity[k] for k in ml_ids], dtype=torch.int32))
             post.l_launched.copy_(torch.tensor([self.missile_launcher_launched[k] for k in ml_ids], dtype=torch.int32))
-        speed = torch.from_numpy(self._post_speed).to(store.device)
+        speed = self._post_speed_dev
         slack = POSSIBLE_TARGET_RADIUS * to_seconds(self._manager.time.get_dt())
         post.step(store.ents, store.cur, speed, seq, cnt, now_s, slack)
         try:
@@ -401,7 +415,8 @@ class CombatControlPoint(BaseModel):
         if self._device_tick(found_msgs, dets):
             self.send_objects_to_GUI(to_draw, processed)
             return
-        self._post_stale = True
+        if dets:
+            self._post_stale = True          # (the host loop below changes the dictionaries behind the mirror's back)
         # ... otherwise every verdict of the tick at once on the device (zrk_ccp_link: a verdict depends on earlier ones only
         # through tracks they took -- updated "now", hence skipped --, which the device resolution reproduces), or the
         # reference's loop

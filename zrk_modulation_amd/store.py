@@ -264,6 +264,22 @@ class EntityStore:
         self.n_uploaded += k
         self._bump()
 
+    def drop_tail_rows(self, j):
+        """Forget the table's last j rows (dead rows behind a device-side salvo, engine.launch_requests_on_device): the next
+        rows appended take their place.  The loop's per-row records of this table start afresh."""
+        j = int(j)
+        if j <= 0:
+            return
+        assert self.n == self.n_uploaded and j <= self.n
+        for name in ("h_ids", "h_kind", "h_sp", "h_vel", "h_t0", "h_pos0", "h_alive") + (("h_lidx",) if self.h_lidx is not None else ()):
+            setattr(self, name, getattr(self, name)[:-j])
+        self.slots_of_id = None
+        self.n -= j
+        self.n_uploaded -= j
+        self.n_stepped = min(self.n_stepped, self.n_uploaded)
+        self.lib.zrk_ctx_invalidate_boxes(self.ctx.handle)
+        self._bump()
+
     def adopt_device_missile_rows(self, slots, target_slots):
         """Missile-table rows written on the device (zrk_launch_salvo): host mirrors of their static columns."""
         self.hm_slot = np.concatenate([self.hm_slot, np.asarray(slots, np.int32)])
