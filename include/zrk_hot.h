@@ -433,7 +433,11 @@ int zrk_exchange_create(const char *rccl_path, const zrk_rccl_id *id, int world,
 void zrk_exchange_destroy(zrk_exchange *x);
 const char *zrk_exchange_last_error(zrk_exchange *x);
 /* One all-gather of `words` 64-bit words per rank: recv = [world][words].  Enqueued on the exchange's stream
- * behind everything `stream` holds so far; ZRK_EXCHANGE_SLOTS slots may be in flight. */
+ * behind everything `stream` holds so far; ZRK_EXCHANGE_SLOTS slots may be in flight.  The pattern is ncclAllGather, as RCCL
+ * chooses to run it, or -- ZRK_EXCHANGE_ALGO=direct at zrk_exchange_create -- world - 1 grouped ncclSend / ncclRecv pairs per
+ * rank, one hop over each peer's own xGMI link; results are the same.  How much a rank sends is the
+ * caller's `words`: zrk_union_bits_words(n, R, 0) carries count, n and the bitmap of the slots seen by any radar -- the
+ * compaction writes no mask where the list has no room for one --, zrk_union_bits_words(n, R, entries) the radar masks too. */
 int zrk_exchange_all_gather(zrk_exchange *x, int slot, const int64_t *send /* DEVICE */, int64_t *recv /* DEVICE */,
                             int64_t words, void *stream);
 /* The last all-gather posted on `slot` is over before anything launched on `stream` after this call runs (nothing if
