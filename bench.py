@@ -358,7 +358,9 @@ def main():
         exchanging = (world > 1 or bool(os.environ.get("ZRK_BENCH_FORCE_EXCHANGE"))) and not ensemble
         state = {"c_side": exchanging and backend == "nccl"}     # may fall back to the Python exchange at set-up
         xchg = {"x": None, "ex": [], "buf": [], "work": [None, None], "tick": 0, "entries": 0, "words": 0}
-        ev_cap = max(64, info["m"]) if exchanging else 0
+        # room for a tick's detonations behind the list: 1024 of them (8 KB) -- a tick that has more is reported as an overflow
+        # (room for all 10^4 missiles at once would be 40 % of what a rank sends per tick, for a list that is nearly always empty)
+        ev_cap = max(64, min(info["m"], 1024)) if exchanging else 0
 
         def coll_device(t):
             return t.to(device) if backend == "nccl" else t.cpu()
