@@ -470,7 +470,8 @@ def main():
         # the warm-up steps go through the same code as the timed ones, sweep timing included: the library creates its timing
         # events on first use, and a first hipExtLaunchKernel is slow -- neither belongs into the timed region
         # (every warm-up sweep is timed, so that the timed region's events exist already)
-        stamping = hasattr(eng, "sweep_stamps") and not (exchanging and not state["c_side"])
+        stamping = (hasattr(eng, "sweep_stamps") and not (exchanging and not state["c_side"])
+                    and os.environ.get("ZRK_BENCH_STAMPS", "1") != "0")       # (=0: event pairs as in round 3, for A/B runs)
         if stamping:
             eng.sweep_stamps(True)           # (the ring of stamps is allocated by the first call that uses it: a warm-up call)
         warm_ms = np.zeros(warmup, np.float32) if (warmup > 0 and deferred) else None
