@@ -12,7 +12,8 @@ import subprocess
 from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
-LIB_PATH = CSRC / "libzrk_hot.so"
+# (ZRK_HOT_LIB: another build of the same ABI, for A/B runs on one box)
+LIB_PATH = Path(os.environ["ZRK_HOT_LIB"]) if os.environ.get("ZRK_HOT_LIB") else CSRC / "libzrk_hot.so"
 
 ZRK_ABI_VERSION = 9
 EXCHANGE_SLOTS = 8          # ZRK_EXCHANGE_SLOTS

@@ -113,13 +113,33 @@ struct RadarBlock {                                 // lives in the kernel-argum
 
 struct WaveBox;
 
-struct SweepParams {
+// The first kSweepHeadBytes of the sweep's arguments are what a wave needs before it can address its rows; the kernel takes
+// them in with ONE burst of scalar loads (SweepHead) instead of a dozen dependent ones, each waited for at its first use
+// (the prologue was a chain of ten scalar round trips in front of the row loads: a microsecond of every wave's life).
+struct SweepHead {
+    const int32_t *order;       // row block of each workgroup, expensive ones first (NULL: identity)
+    unsigned long long *stamps; // wall-clock stamps of THIS launch, see SweepParams::stamps
+    uint32_t *flag;
+    const char *rb_table;       // DEVICE RadarBlock per scenario (NULL: one scenario, records in `rb` below)
+    const uint64_t *seeds;
+    WaveBox *boxes;             // per-block box records (NULL: none kept), see WaveBox
     const double *sp, *vel, *t0;
     const uint8_t *alive;
     const int32_t *lidx;        // list index of each table row (NULL: the table is in list order)
+    uint8_t *pend;              // removal marks, see below
     double *pos;
+    int64_t n, cap;
+    uint64_t seed;
+    int32_t mb, nb, bps;        // mb leading workgroups step the missiles, nb sweep; bps: row blocks per scenario of an ensemble
+    uint32_t bps_magic;         // ceil(2^32 / bps): block / bps == umulhi(block, magic) for block < 2^16
+    uint32_t flags, flag_value;
+    int32_t R, _pad0;
+};
+constexpr int kSweepHeadBytes = 160;
+static_assert(sizeof(SweepHead) == kSweepHeadBytes, "the head is forty dwords");
+
+struct SweepParams : SweepHead {
     uint32_t *vis;              // indexed by LIST index
-    const int32_t *order;       // row block of each workgroup, expensive ones first (NULL: identity)
     int32_t *order_next;        // the same for the next tick, built as this sweep goes (NULL: not built), see below
     // overlapped loop: removals decided by this launch's missile phase are MARKS (pend[row] = the removal tick's mark value,
     // written only where there is none yet, never cleared inside a call) that the row's own thread carries out in the next
@@ -127,7 +147,6 @@ struct SweepParams {
     // effective from the next tick either way).  A mark value is 2 + 2 * (tick % 126) + b, b = the index of the position
     // buffer that was current in the removal tick: pos_abs[b] holds the frozen position, pos_abs[b ^ 1] is to receive it.
     // A mark other than this launch's means "removed before this launch".  NULL: no marks
-    uint8_t *pend;
     uint32_t mark, mark2;       // this launch's mark values (mark2: the second tick of a pair, else = mark)
     uint8_t *alive_w;           // (the alive column again, writable)
     double *pos_prev;           // the other position buffer: last tick's positions -- and, in a PAIR launch, the second tick's output
@@ -142,28 +161,17 @@ struct SweepParams {
     uint32_t *vis2;
     uint32_t *order_ctr;        // kOrderRegions pairs (expensive / cheap row blocks recorded so far), kOrderCtrStride words apart
     uint32_t *order_ctr_next;   // the next tick's set, cleared here
-    int64_t n, cap;
     double t;
-    uint64_t seed, tick;
+    uint64_t tick;
     int64_t gid0;
-    int32_t R, nb;              // nb: sweep workgroups, behind the mb leading workgroups that step the missiles
-    int32_t mb;
-    uint32_t flag_value;        // written to *flag by the first workgroup as it starts (see zrk_exchange: hand-over by flag)
-    uint32_t *flag;
-    WaveBox *boxes;             // per-block box records (NULL: none kept), see WaveBox
+    // (flag_value is written to *flag by the first workgroup as it starts: see zrk_exchange, hand-over by flag)
     // batched ensemble of independent scenarios (zrk_run_ticks_ensemble): scenario s owns rows_ps consecutive rows
     // (bps row blocks), its radar records are block s of rb_table, its noise key is seeds[s]; lists restart per scenario
-    const char *rb_table;       // DEVICE RadarBlock per scenario (NULL: one scenario, records in `rb` below)
-    const uint64_t *seeds;
     int64_t rows_ps;
-    int32_t bps;
-    uint32_t bps_magic;         // ceil(2^32 / bps): block / bps == umulhi(block, magic) for block < 2^16
-    uint32_t flags;
-    // wall-clock stamps of THIS launch (s_memrealtime, 100 MHz), NULL: none -- words [0, kStampBegins): when each wave of the
-    // first workgroups started; word kStampBegins + w: when wave w of the grid ended.  The launch ran from the smallest of
-    // the former to the largest of the latter (k_reduce_stamps): a duration measured without an event, a signal or a
-    // profiler on the stream (zrk_sweep_stamps)
-    unsigned long long *stamps;
+    // stamps (head): wall-clock stamps of THIS launch (s_memrealtime, 100 MHz), NULL: none -- words [0, kStampBegins): when each
+    // wave of the first workgroups started; word kStampBegins + w: when wave w of the grid ended.  The launch ran from the
+    // smallest of the former to the largest of the latter (k_reduce_stamps): a duration measured without an event, a signal or
+    // a profiler on the stream (zrk_sweep_stamps)
     RadarBlock rb;
 };
 // a PAIR launch carries the second tick's records behind the first's (a plain launch does not pay for their 10 KB)
@@ -998,15 +1006,25 @@ template <bool PHILOX, bool ADVANCE, bool LIDX, bool MARKS = false, bool PAIR = 
 __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) void k_tick_sweep(const std::conditional_t<PAIR, SweepParamsPair, SweepParams> P, const MissileArgs M)
 {
     static_assert(!PAIR || (MARKS && ADVANCE), "a pair launch advances and carries removals as marks");
-    stamp_begin(P.stamps);
-    // the previous tick's compaction is over and visible once this grid starts: tell the exchange stream, which waits
-    // for this word instead of an event (an event record costs the compute stream a barrier packet per tick)
-    if (P.flag && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(P.flag, P.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // one scenario: the radar records travel in this launch's kernel-argument segment (THE ONLY PLACE where that address is
     // formed: see g_device_fault); a batched ensemble: a table in device memory, indexed below
     const char *const kernarg = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
-    if ((int)blockIdx.x < P.mb) {              // leading workgroups: Missile.step for every in-flight row (a long
+    // the head of the arguments in one burst of scalar loads, waited for once (SweepHead)
+    typedef const uint32_t __attribute__((address_space(4))) *ConstWordsK;
+    uint32_t hw[kSweepHeadBytes / 4];
+    {
+        const ConstWordsK kw = (ConstWordsK)(uint64_t)kernarg;
+#pragma unroll
+        for (int k = 0; k < kSweepHeadBytes / 4; ++k) hw[k] = kw[k];
+    }
+    SweepHead H;
+    __builtin_memcpy(&H, hw, sizeof(H));
+    stamp_begin(H.stamps);
+    // the previous tick's compaction is over and visible once this grid starts: tell the exchange stream, which waits
+    // for this word instead of an event (an event record costs the compute stream a barrier packet per tick)
+    if (H.flag && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(H.flag, H.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((int)blockIdx.x < H.mb) {              // leading workgroups: Missile.step for every in-flight row (a long
         // dependent chain -- dispatched first, it is over long before the sweep's last wave is)
         const int64_t row = (int64_t)blockIdx.x * ZRK_BLOCK + threadIdx.x;
         const char *rb_first = P.rb_table ? P.rb_table : kernarg + offsetof(SweepParams, rb);
@@ -1037,24 +1055,24 @@ __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) voi
         return;
     }
     const int tid = threadIdx.x;
-    const int bid = (int)blockIdx.x - P.mb;
+    const int bid = (int)blockIdx.x - H.mb;
     // (scalar loads by hand: the compiler cannot prove these words read-only and would fetch a wave-uniform word
     // with a vector load, whose full latency then sits in front of every row load of the wave)
     int blk = bid;
-    if (P.order) {
-        const int32_t *po = P.order + bid;
+    if (H.order) {
+        const int32_t *po = H.order + bid;
         asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk) : "s"(po) : "memory");
     }
     const int64_t wave = (int64_t)blk * (ZRK_BLOCK / 64) + (tid >> 6);
-    const int64_t cap = P.cap;
+    const int64_t cap = H.cap;
     // a batched ensemble: block `scen` of a table in device memory (written by the previous tick's compaction launch),
     // its own noise key, its own lists
-    const int scen = P.bps ? (int)__umulhi((uint32_t)blk, P.bps_magic) : 0;
-    const char *rbp = P.rb_table ? P.rb_table + (size_t)scen * sizeof(RadarBlock) : kernarg + offsetof(SweepParams, rb);
+    const int scen = H.bps ? (int)__umulhi((uint32_t)blk, H.bps_magic) : 0;
+    const char *rbp = H.rb_table ? H.rb_table + (size_t)scen * sizeof(RadarBlock) : kernarg + offsetof(SweepParams, rb);
     const char *rbp2 = kernarg + sizeof(SweepParams);             // (PAIR: SweepParamsPair::rb2)
-    uint64_t seed = P.seed;
-    if (P.seeds) {
-        const uint64_t *ps = P.seeds + scen;
+    uint64_t seed = H.seed;
+    if (H.seeds) {
+        const uint64_t *ps = H.seeds + scen;
         asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seed) : "s"(ps) : "memory");
     }
     __shared__ PreTable s_pre;
@@ -1069,29 +1087,29 @@ __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) voi
                                 ((long long)((uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) << 32) | ((long long)bid << 40));
     const int64_t i = wave * 64 + (tid & 63);
     // every column load of the row is issued before anything waits for one: rows past the end read row 0
-    const int64_t ic = (i < P.n) ? i : 0;
-    const uint8_t al = P.alive[ic];
+    const int64_t ic = (i < H.n) ? i : 0;
+    const uint8_t al = H.alive[ic];
     // (removal marks: a variant of its own -- carried along unused they cost the plain loop's sweep 0.5 us)
-    const uint32_t pk = MARKS ? (uint32_t)P.pend[ic] : 0u;
-    const int32_t lix = LIDX ? P.lidx[ic] : 0;
+    const uint32_t pk = MARKS ? (uint32_t)H.pend[ic] : 0u;
+    const int32_t lix = LIDX ? H.lidx[ic] : 0;
     // (only the loads here: the arithmetic waits for them and comes after everything that does not)
     double t0 = 0.0, vx = 0.0, vy = 0.0, vz = 0.0, sx0, sy0, sz0;
     if (ADVANCE) {
-        t0 = P.t0[ic];
-        vx = P.vel[ic]; vy = P.vel[cap + ic]; vz = P.vel[2 * cap + ic];
-        sx0 = P.sp[ic]; sy0 = P.sp[cap + ic]; sz0 = P.sp[2 * cap + ic];
+        t0 = H.t0[ic];
+        vx = H.vel[ic]; vy = H.vel[cap + ic]; vz = H.vel[2 * cap + ic];
+        sx0 = H.sp[ic]; sy0 = H.sp[cap + ic]; sz0 = H.sp[2 * cap + ic];
     } else {
-        sx0 = P.pos[ic]; sy0 = P.pos[cap + ic]; sz0 = P.pos[2 * cap + ic];
+        sx0 = H.pos[ic]; sy0 = H.pos[cap + ic]; sz0 = H.pos[2 * cap + ic];
     }
     const bool removed = MARKS && (pk != 0u) & (pk != P.mark) & (pk != P.mark2);   // marked in an earlier launch of this call
-    const bool live = (i < P.n) & (al != 0) & !removed;
-    const int64_t li = (LIDX && i < P.n) ? (int64_t)lix : i;     // where this row sits in (its scenario's) AirEnv list
+    const bool live = (i < H.n) & (al != 0) & !removed;
+    const int64_t li = (LIDX && i < H.n) ? (int64_t)lix : i;     // where this row sits in (its scenario's) AirEnv list
     // the wave's box record, if the caller keeps any (zrk_run_ticks does): twelve scalar words
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 b0 = {0u, 0u, 0u, 0u}, b1 = {0u, 0u, 0u, 0u}, bv = {0u, 0u, 0u, 0u};     // lo[3] hi[0] | hi[1..2] vmax[0..1] | vmax[2] state t_ref
-    const bool cached = ADVANCE && P.boxes != nullptr;
+    const bool cached = ADVANCE && H.boxes != nullptr;
     if (cached) {
-        const WaveBox *pb = P.boxes + blk;
+        const WaveBox *pb = H.boxes + blk;
         asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(b0), "=&s"(b1), "=&s"(bv) : "s"(pb) : "memory");
     }
