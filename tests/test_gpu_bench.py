@@ -33,12 +33,13 @@ def test_single_rank_line_has_the_contract_fields():
     assert rec["value"] > 0 and "tiny" in rec["config"]["workload"]
 
 
-@pytest.mark.parametrize("workload,scaling", [("tiny", "weak"), ("tiny4", "strong")])
-def test_two_ranks_started_by_the_gpus_flag(workload, scaling):
-    rec = _bench(["--gpus", "2", "--workload", workload, "--steps", "10", "--warmup", "4", "--no-cpu-baseline"],
+@pytest.mark.parametrize("workload,scaling,wire", [("tiny", "weak", "union"), ("tiny4", "strong", "union"), ("tiny", "weak", "masks")])
+def test_two_ranks_started_by_the_gpus_flag(workload, scaling, wire):
+    rec = _bench(["--gpus", "2", "--workload", workload, "--steps", "10", "--warmup", "4", "--no-cpu-baseline", "--wire", wire],
                  env={"ZRK_BENCH_BACKEND": "gloo"})
     assert rec["n_gpus"] == 2 and rec["scaling"] == scaling
     assert rec["config"]["exchange_overflow"] is False
+    assert ("masks" in rec["config"]["exchange_wire"]) == (wire == "masks")
     assert rec["value"] > 0
 
 
@@ -47,6 +48,7 @@ def test_ensemble_workload_line():
     rec = _bench(["--workload", "tiny5", "--steps", "12", "--warmup", "4", "--cpu-budget", "1"])
     assert rec["n_gpus"] == 1 and rec["scaling"] == "weak" and "tiny5" in rec["config"]["workload"]
     assert rec["config"]["parallelism"] == "replicas1" and rec["roofline"]["achieved"] > 0
+    assert rec["roofline"]["samples"] >= 6 and rec["roofline"]["ticks_per_launch"] == 1      # (an ensemble's sweeps time themselves too)
     assert rec["cpu_baseline"]["kind"] == "port" and rec["value"] > 0
 
 
