@@ -1495,6 +1495,69 @@ __device__ __forceinline__ int sum_epoch_records(const unsigned long long *ra, i
     return acc;
 }
 
+// The walks over a workgroup's squeezed list (detected slots in list order: idx[], msk[]) that count and scatter per radar.
+// They are most of what a compaction launch executes -- 9e4 (64-entry step, radar) pairs per launch at C3, each walked twice --
+// and beside a sweep whose heavy waves are arithmetic-bound their instruction count is what the compaction costs (DESIGN.md
+// section 5.2).  So: the list is zero-padded to a multiple of 256 entries (no read of it hangs on a predicate), a wave walks it
+// ONCE for up to two radars (one LDS read per entry and per pass, the entries' list slots added up once), the lists' positions
+// are wave-uniform scalars, the stores take a 32-bit offset against the list's base, and the check against the list's capacity
+// is made once per step, not per lane (a list about to run out of room takes the careful store).  27 -> 12 instructions per
+// (step, radar) in the scatter, 12 -> 5 in the count.
+template <int JOBS>
+__device__ __forceinline__ void walk_count(const uint32_t *msk, int len_pad, const uint32_t (&sel)[JOBS], int (&cnt)[JOBS])
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < JOBS; ++q) cnt[q] = 0;
+    for (int c = 0; c < len_pad; c += 256) {
+        uint32_t m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m[u] = msk[c + u * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < JOBS; ++q) cnt[q] += (int)__popcll(__ballot((m[u] & sel[q]) != 0u));
+    }
+}
+
+template <int JOBS>
+__device__ __forceinline__ void walk_scatter(const uint32_t *msk, const unsigned short *idx, int len_pad, const uint32_t (&sel)[JOBS],
+                                             int (&run)[JOBS], int32_t *const (&out)[JOBS], int limit, int32_t slot0)
+{
+    const int lane = threadIdx.x & 63;
+    for (int c = 0; c < len_pad; c += 256) {
+        uint32_t m[4];
+        int32_t slot[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            m[u] = msk[c + u * 64 + lane];
+            slot[u] = slot0 + (int32_t)idx[c + u * 64 + lane];
+        }
+#pragma unroll
+        for (int q = 0; q < JOBS; ++q) {
+            if (run[q] + 256 <= limit) {                 // (wave-uniform: the list holds whatever these four steps add)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool bit = (m[u] & sel[q]) != 0u;
+                    const unsigned long long bb = __ballot(bit);
+                    const uint32_t at = (uint32_t)run[q] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u));
+                    if (bit) out[q][at] = slot[u];
+                    run[q] += (int)__popcll(bb);
+                }
+            } else {                                     // a list about to run out of room: every store looks
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool bit = (m[u] & sel[q]) != 0u;
+                    const unsigned long long bb = __ballot(bit);
+                    const uint32_t at = (uint32_t)run[q] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u));
+                    if (bit && (int)at < limit) out[q][at] = slot[u];
+                    run[q] += (int)__popcll(bb);
+                }
+            }
+        }
+    }
+}
+
 struct CompactArgs {
     const uint32_t *vis;           // NULL: nothing to compact
     uint32_t *zero_next;
@@ -1536,7 +1599,8 @@ struct CompactShared {
 template <int THREADS>
 __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const CompactArgs &C, int by_ticket)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (the wave's number as a scalar: what follows from it -- the radars it walks, their lists' bases -- then lives in SGPRs)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) S.ticket = by_ticket ? atomicAdd(&C.ctl[0], 1) : (int)blockIdx.x;
     if (tid <= ZRK_MAX_RADARS) S.pre[tid] = S.grp[tid] = 0;
     __syncthreads();
@@ -1601,21 +1665,21 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
             }
         }
     }
+    // (the list is zero-padded to a multiple of 256 entries: the walks read it without a predicate)
+    const int len_pad = (found + 255) & ~255;
+    if (tid < 256 && found + tid < len_pad) S.msk[found + tid] = 0u;
     __syncthreads();
     ZRK_PROBE(2);
-    for (int r = wave; r < C.R; r += (THREADS / 64)) {       // per-radar counts over the short list
-        int run = 0;
-        for (int c = 0; c < found; c += 256) {
-            uint32_t q[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = c + u * 64 + lane;
-                q[u] = (k < found) ? S.msk[k] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) run += (int)__popcll(__ballot((q[u] >> r) & 1u));
+    // per-radar counts over the short list: wave w takes radars w and w + WAVES in one walk
+    {
+        constexpr int WAVES = THREADS / 64;
+        for (int rb = wave; rb < C.R; rb += 2 * WAVES) {
+            const uint32_t sel[2] = {1u << rb, (rb + WAVES < C.R) ? (1u << (rb + WAVES)) : 0u};
+            int cnt[2];
+            if (sel[1]) walk_count<2>(S.msk, len_pad, sel, cnt);
+            else { const uint32_t sel1[1] = {sel[0]}; int c1[1]; walk_count<1>(S.msk, len_pad, sel1, c1); cnt[0] = c1[0]; cnt[1] = 0; }
+            if (lane == 0) { S.cnt[rb] = cnt[0]; if (sel[1]) S.cnt[rb + WAVES] = cnt[1]; }
         }
-        if (lane == 0) S.cnt[r] = run;
     }
     if (tid == 0) S.cnt[C.R] = found;
     __syncthreads();
@@ -1663,29 +1727,19 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
         }
     }
     if (C.det_idx) {
-        for (int r = wave; r < C.R; r += (THREADS / 64)) {
-            int run = S.pre[r];
-            int32_t *out = C.det_idx + ((int64_t)seg * C.R + r) * C.det_stride;
-            const int32_t slot0 = C.base_index + (int32_t)(blk0 - (int64_t)seg * C.seg_slots);
-            for (int c = 0; c < found; c += 256) {     // four steps of 64 entries, their LDS reads in flight together
-                uint32_t q[4];
-                unsigned short ix[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = c + u * 64 + lane;
-                    q[u] = (k < found) ? S.msk[k] : 0u;
-                    ix[u] = (k < found) ? S.idx[k] : (unsigned short)0;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool bit = (q[u] >> r) & 1u;
-                    const unsigned long long bb = __ballot(bit);
-                    if (bit) {
-                        const int64_t dst = (int64_t)run + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u));
-                        if (dst < C.det_stride) out[dst] = slot0 + (int32_t)ix[u];
-                    }
-                    run += (int)__popcll(bb);
-                }
+        constexpr int WAVES = THREADS / 64;
+        const int limit = (int)(C.det_stride < 0x7FFFFFFF ? C.det_stride : 0x7FFFFFFF);
+        const int32_t slot0 = C.base_index + (int32_t)(blk0 - (int64_t)seg * C.seg_slots);
+        int32_t *seg_out = C.det_idx + (int64_t)seg * C.R * C.det_stride;
+        for (int rb = wave; rb < C.R; rb += 2 * WAVES) {
+            const bool two = rb + WAVES < C.R;
+            const uint32_t sel[2] = {1u << rb, two ? (1u << (rb + WAVES)) : 0u};
+            int run[2] = {__builtin_amdgcn_readfirstlane(S.pre[rb]), two ? __builtin_amdgcn_readfirstlane(S.pre[rb + WAVES]) : 0};
+            int32_t *const out[2] = {seg_out + (int64_t)rb * C.det_stride, seg_out + (int64_t)(two ? rb + WAVES : rb) * C.det_stride};
+            if (two) walk_scatter<2>(S.msk, S.idx, len_pad, sel, run, out, limit, slot0);
+            else {
+                const uint32_t sel1[1] = {sel[0]}; int run1[1] = {run[0]}; int32_t *const out1[1] = {out[0]};
+                walk_scatter<1>(S.msk, S.idx, len_pad, sel1, run1, out1, limit, slot0);
             }
         }
     }
@@ -1900,7 +1954,7 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
                                                    int rm_cap)
 {
     constexpr int WAVES = THREADS / 64, kItems = kPairSlots / THREADS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) S.ticket = atomicAdd(&C0.ctl[0], 1);
     if (tid < 2 * (ZRK_MAX_RADARS + 1)) S.pre[tid] = S.grp[tid] = 0;
     __syncthreads();
@@ -1992,23 +2046,25 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
             }
         }
     }
+    for (int t = tid; t < 512; t += THREADS) {       // zero padding of both lists up to the next multiple of 256 entries
+        const int s = t >> 8, k = S.found[s] + (t & 255);
+        if (k < ((S.found[s] + 255) & ~255)) S.msk[s][k] = 0u;
+    }
     __syncthreads();
-    // per-radar counts over the two short lists: 2 R (tick, radar) jobs dealt out to the waves
-    for (int job = wave; job < 2 * R; job += WAVES) {
-        const int s = job >= R ? 1 : 0, r = job - s * R;
-        const int found = S.found[s];
-        int run = 0;
-        for (int c = 0; c < found; c += 256) {
-            uint32_t q[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = c + u * 64 + lane;
-                q[u] = (k < found) ? S.msk[s][k] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) run += (int)__popcll(__ballot((q[u] >> r) & 1u));
-        }
-        if (lane == 0) S.cnt[s][r] = run;
+    // (the lists are zero-padded to a multiple of 256 entries: the walks read them without a predicate; the barrier in front
+    // of this is the one behind the squeeze)
+    const int len_pad[2] = {(S.found[0] + 255) & ~255, (S.found[1] + 255) & ~255};
+    // per-radar counts over the two short lists: the first half of the waves takes the first tick, the second half the second;
+    // wave wv of a half walks its list once for radars wv and wv + WPT
+    constexpr int WPT = WAVES / 2;
+    const int ws = wave / WPT, wv = wave % WPT;
+    for (int rb = wv; rb < R; rb += 2 * WPT) {
+        const bool two = rb + WPT < R;
+        const uint32_t sel[2] = {1u << rb, two ? (1u << (rb + WPT)) : 0u};
+        int cnt[2];
+        if (two) walk_count<2>(S.msk[ws], len_pad[ws], sel, cnt);
+        else { const uint32_t sel1[1] = {sel[0]}; int c1[1]; walk_count<1>(S.msk[ws], len_pad[ws], sel1, c1); cnt[0] = c1[0]; cnt[1] = 0; }
+        if (lane == 0) { S.cnt[ws][rb] = cnt[0]; if (two) S.cnt[ws][rb + WPT] = cnt[1]; }
     }
     if (tid < 2) S.cnt[tid][R] = S.found[tid];
     __syncthreads();
@@ -2071,32 +2127,19 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
         }
     }
     if (C0.det_idx) {
-        for (int job = wave; job < 2 * R; job += WAVES) {
-            const int s = job >= R ? 1 : 0, r = job - s * R;
-            const CompactArgs &C = s ? C1 : C0;
-            const int found = S.found[s];
-            int run = S.pre[s * (R + 1) + r];
-            int32_t *out = C.det_idx + (int64_t)r * C.det_stride;
-            const int32_t slot0 = C.base_index + (int32_t)blk0;
-            for (int c = 0; c < found; c += 256) {     // four steps of 64 entries, their LDS reads in flight together
-                uint32_t q[4];
-                unsigned short ix[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = c + u * 64 + lane;
-                    q[u] = (k < found) ? S.msk[s][k] : 0u;
-                    ix[u] = (k < found) ? S.idx[s][k] : (unsigned short)0;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool bit = (q[u] >> r) & 1u;
-                    const unsigned long long bb = __ballot(bit);
-                    if (bit) {
-                        const int64_t dst = (int64_t)run + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u));
-                        if (dst < C.det_stride) out[dst] = slot0 + (int32_t)ix[u];
-                    }
-                    run += (int)__popcll(bb);
-                }
+        const CompactArgs &C = ws ? C1 : C0;
+        const int limit = (int)(C.det_stride < 0x7FFFFFFF ? C.det_stride : 0x7FFFFFFF);
+        const int32_t slot0 = C.base_index + (int32_t)blk0;
+        for (int rb = wv; rb < R; rb += 2 * WPT) {
+            const bool two = rb + WPT < R;
+            const uint32_t sel[2] = {1u << rb, two ? (1u << (rb + WPT)) : 0u};
+            int run[2] = {__builtin_amdgcn_readfirstlane(S.pre[ws * (R + 1) + rb]),
+                          two ? __builtin_amdgcn_readfirstlane(S.pre[ws * (R + 1) + rb + WPT]) : 0};
+            int32_t *const out[2] = {C.det_idx + (int64_t)rb * C.det_stride, C.det_idx + (int64_t)(two ? rb + WPT : rb) * C.det_stride};
+            if (two) walk_scatter<2>(S.msk[ws], S.idx[ws], len_pad[ws], sel, run, out, limit, slot0);
+            else {
+                const uint32_t sel1[1] = {sel[0]}; int run1[1] = {run[0]}; int32_t *const out1[1] = {out[0]};
+                walk_scatter<1>(S.msk[ws], S.idx[ws], len_pad[ws], sel1, run1, out1, limit, slot0);
             }
         }
     }
