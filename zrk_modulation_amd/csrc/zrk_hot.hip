@@ -1501,7 +1501,7 @@ __device__ __forceinline__ int sum_epoch_records(const unsigned long long *ra, i
 // section 5.2).  So: the list is zero-padded to a multiple of 256 entries (no read of it hangs on a predicate), a wave walks it
 // ONCE for up to two radars (one LDS read per entry and per pass, the entries' list slots added up once), the lists' positions
 // are wave-uniform scalars, the stores take a 32-bit offset against the list's base, and the check against the list's capacity
-// is made once per step, not per lane (a list about to run out of room takes the careful store).  27 -> 12 instructions per
+// is made once per four steps (256 entries), not per lane (a list about to run out of room takes the careful store).  27 -> 12 instructions per
 // (step, radar) in the scatter, 12 -> 5 in the count.
 template <int JOBS>
 __device__ __forceinline__ void walk_count(const uint32_t *msk, int len_pad, const uint32_t (&sel)[JOBS], int (&cnt)[JOBS])
@@ -1614,24 +1614,33 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
     const int first = seg * C.seg_blocks;                         // its first workgroup: nobody before it counts
     const bool last_of_seg = C.seg_blocks ? (b == first + C.seg_blocks - 1) : (b == C.nb - 1);
     ZRK_PROBE(0);
+    // (32-bit slot numbers against the block's own base address; a slot past the table's end reads the block's last one and
+    // counts as empty: no load of the burst hangs on a branch -- see compact_block_pair)
+    const int rem = (int)((C.n - blk0) < (int64_t)C.items * THREADS ? (C.n - blk0) : (int64_t)C.items * THREADS);
+    const uint32_t *vb = C.vis + blk0;
     uint32_t mk[kFusedMaxItems];
 #pragma unroll
     for (int it = 0; it < kFusedMaxItems; ++it) {  // every load in flight before anything looks at one
-        const int64_t i = blk0 + (int64_t)it * THREADS + tid;
-        mk[it] = (it < C.items && i < C.n) ? C.vis[i] : 0u;
+        const int slot = it * THREADS + tid;
+        mk[it] = (it < C.items) ? vb[slot < rem ? slot : rem - 1] : 0u;
     }
+    uint32_t *zb = C.zero_next ? C.zero_next + blk0 : nullptr;
+    const bool own = C.zero_own != 0;
+    int64_t *words = C.packed + 2 + (blk0 >> 6);
+    const int64_t wlimit = (C.packed && C.bits.words) ? C.bits.words - (blk0 >> 6) : 0;
 #pragma unroll
     for (int it = 0; it < kFusedMaxItems; ++it) {
         if (it < C.items) {
-            const int64_t i = blk0 + (int64_t)it * THREADS + tid;
+            const int slot = it * THREADS + tid;
+            mk[it] = slot < rem ? mk[it] : 0u;
             // next tick's (other) mask buffer, cleared in passing; the overlapped loop clears the buffer it has just read,
             // where only the detections are not zero already
-            if (C.zero_next && i < C.n && (!C.zero_own || mk[it] != 0u)) C.zero_next[i] = 0u;
+            if (zb && (own ? mk[it] != 0u : slot < rem)) zb[slot] = 0u;
             const unsigned long long bu = __ballot(mk[it] != 0u);
             if (lane == 0) {
                 S.wcnt[it * (THREADS / 64) + wave] = (int)__popcll(bu);
-                const int64_t word = (blk0 + (int64_t)it * THREADS + wave * 64) >> 6;      // 64 consecutive slots
-                if (C.packed && C.bits.words && word < C.bits.words) C.packed[2 + word] = (int64_t)bu;
+                const int w = it * (THREADS / 64) + wave;                                    // 64 consecutive slots: one word of the bitmap
+                if (w < wlimit) words[w] = (int64_t)bu;
             }
         }
     }
@@ -1963,32 +1972,39 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
         if (tid == 0) atomicExch(&C0.ctl[2], 1);
         return;
     }
-    const int R = C0.R, items = C0.items;
-    const int64_t blk0 = (int64_t)b * items * THREADS;
+    const int R = C0.R;
+    constexpr int items = kItems;                    // (C0.items says the same: kPairSlots slots per workgroup whatever its size)
+    const int64_t blk0 = (int64_t)b * kPairSlots;
     const bool last = b == C0.nb - 1;
-    // the rows the first tick removed (few, mostly none): their list indices
-    int rmn = rm ? __hip_atomic_load(rm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    rmn = rmn < rm_cap ? rmn : rm_cap;
+    // Every mask load of both ticks in flight before anything looks at one: 32-bit slot numbers against the block's own base
+    // addresses; a slot past the table's end reads the block's last one and counts as empty, so that no load of the burst
+    // hangs on a branch (as compiled before, each load sat behind a scalar reload of `n` and the first behind the removed-row
+    // list's round trip: a chain of ten dependent waits in front of the masks).
+    const int rem = (int)((C0.n - blk0) < (int64_t)kPairSlots ? (C0.n - blk0) : (int64_t)kPairSlots);
     uint32_t mk[2][kItems];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const CompactArgs &C = s ? C1 : C0;
+        const uint32_t *vb = (s ? C1.vis : C0.vis) + blk0;
 #pragma unroll
-        for (int it = 0; it < kItems; ++it) {    // every load in flight before anything looks at one
-            const int64_t i = blk0 + (int64_t)it * THREADS + tid;
-            mk[s][it] = (it < items && i < C.n) ? C.vis[i] : 0u;
+        for (int it = 0; it < kItems; ++it) {
+            const int slot = it * THREADS + tid;
+            mk[s][it] = vb[slot < rem ? slot : rem - 1];
         }
     }
+    // the rows the first tick removed (few, mostly none): their list indices, asked for while the masks are on their way
+    int rmn = rm ? __hip_atomic_load(rm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    rmn = rmn < rm_cap ? rmn : rm_cap;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const CompactArgs &C = s ? C1 : C0;
+        uint32_t *zb = C.zero_next ? C.zero_next + blk0 : nullptr;
+        const bool own = C.zero_own != 0;
 #pragma unroll
         for (int it = 0; it < kItems; ++it) {
-            if (it < items) {
-                const int64_t i = blk0 + (int64_t)it * THREADS + tid;
-                // (the loop's own mask buffers are cleared by the compaction that reads them: only the detections are not zero)
-                if (C.zero_next && i < C.n && (!C.zero_own || mk[s][it] != 0u)) C.zero_next[i] = 0u;
-            }
+            const int slot = it * THREADS + tid;
+            mk[s][it] = slot < rem ? mk[s][it] : 0u;
+            // (the loop's own mask buffers are cleared by the compaction that reads them: only the detections are not zero)
+            if (zb && (own ? mk[s][it] != 0u : slot < rem)) zb[slot] = 0u;
         }
     }
     for (int q = 0; q < rmn; ++q) {                  // (wave-uniform trip count; every thread compares its own slots)
