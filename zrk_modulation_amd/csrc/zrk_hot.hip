@@ -178,6 +178,8 @@ struct SweepParams : SweepHead {
 struct SweepParamsPair : SweepParams {
     RadarBlock rb2;
 };
+// (rb is SweepParams' last member: its offset without offsetof, which a struct with a base does not officially have)
+constexpr size_t kSweepRbOffset = sizeof(SweepParams) - sizeof(RadarBlock);
 static_assert(sizeof(SweepParams) % 8 == 0 && sizeof(SweepParamsPair) == sizeof(SweepParams) + sizeof(RadarBlock), "rb2 sits right behind SweepParams");
 
 // The missile phase rides along in other kernels' grids (its own launches would cost more in kernel
@@ -1027,7 +1029,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) voi
     if ((int)blockIdx.x < H.mb) {              // leading workgroups: Missile.step for every in-flight row (a long
         // dependent chain -- dispatched first, it is over long before the sweep's last wave is)
         const int64_t row = (int64_t)blockIdx.x * ZRK_BLOCK + threadIdx.x;
-        const char *rb_first = P.rb_table ? P.rb_table : kernarg + offsetof(SweepParams, rb);
+        const char *rb_first = P.rb_table ? P.rb_table : kernarg + kSweepRbOffset;
         if (row < M.m) {
             const uint8_t code = missile_step_row(M.sp, M.vel, M.t0, M.alive, M.lidx, M.pos_prev, M.cap, M.m_slot, M.m_tgt,
                                                   M.m_radius, M.m_period, M.m_status, row, M.t, M.dts, M.pend, M.mark, M.grec,
@@ -1068,7 +1070,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) voi
     // a batched ensemble: block `scen` of a table in device memory (written by the previous tick's compaction launch),
     // its own noise key, its own lists
     const int scen = H.bps ? (int)__umulhi((uint32_t)blk, H.bps_magic) : 0;
-    const char *rbp = H.rb_table ? H.rb_table + (size_t)scen * sizeof(RadarBlock) : kernarg + offsetof(SweepParams, rb);
+    const char *rbp = H.rb_table ? H.rb_table + (size_t)scen * sizeof(RadarBlock) : kernarg + kSweepRbOffset;
     const char *rbp2 = kernarg + sizeof(SweepParams);             // (PAIR: SweepParamsPair::rb2)
     uint64_t seed = H.seed;
     if (H.seeds) {
@@ -3512,7 +3514,12 @@ struct SideItem {
     // behind that sweep (an event record costs the compute stream a barrier packet -- harmless where no sweep follows)
     hipEvent_t wait_event;
     // both ticks of a pair launch in one compaction launch (k_compact_pair): C / M are the first tick's, C2 / M2 the second's
-    int pair, done_slot2, pair_threads, _pad5;
+    int pair, done_slot2, pair_threads;
+    // the LAST compaction of a call has no sweep to hide behind: it goes to the COMPUTE stream (`stream` is then the caller's),
+    // right behind the last sweep -- in order on one queue, instead of a word raised behind that sweep, seen by this thread and
+    // answered with a launch on the other queue (15 us of a 20-tick call).  The side stream's compaction before it is taken in
+    // through an event (Side::tail_ev)
+    int on_compute;
     CompactArgs C2;
     MissileArgs M2;
     const int32_t *rm;
@@ -3557,6 +3564,8 @@ struct Side {
     hipEvent_t done[kMasks + 1] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t done_of[kMasks + 1] = {nullptr};   // the event that says a slot's compaction is over (a pair item records ONE for its two)
     hipEvent_t last_sweep = nullptr;   // recorded behind the last sweep of a call (SideItem::wait_event)
+    hipEvent_t tail_ev = nullptr;      // recorded behind the side stream's last launch when an item goes to the compute stream (SideItem::on_compute)
+    bool side_busy = false;            // the side stream has launches the compute stream has not taken in (the thread's; the caller's between items)
     uint32_t *bar = nullptr;           // DEVICE: the barrier of a pair launch's missile workgroups (arrivals, gave-up word)
     uint32_t bar_epoch = 0;            // arrivals asked for so far
     // k_compact_pair: per ring slot the list of rows a pair's first tick removed (MissileArgs::rm), and where the FIRST tick's
@@ -3649,6 +3658,8 @@ struct zrk_ctx {
     std::vector<int64_t> stamp_waves;
     bool tail_by_event = false;        // ZRK_TAIL_EVENT=1: the last compaction of a call is released by an event recorded behind the last sweep, not by
                                        // a launch that raises the host word (medians equal, 24.6 / 24.7 us per tick in 20-step runs; the event has the worse tail)
+    bool tail_on_compute = true;       // the last compaction of a call goes to the compute stream, behind the last sweep (SideItem::on_compute);
+                                       // ZRK_TAIL_COMPUTE=0: to the side stream like the others, released as above.  Calls with an exchange: always the latter
 };
 
 namespace {
@@ -3735,6 +3746,7 @@ ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
     { const char *v = std::getenv("ZRK_OVERLAP_MIN_ROWS"); c->overlap_min_rows = v ? std::atoll(v) : 50000; }
     { const char *v = std::getenv("ZRK_GATHER_RECORDS"); c->grec_enabled = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_TAIL_EVENT"); c->tail_by_event = v && v[0] == '1'; }
+    { const char *v = std::getenv("ZRK_TAIL_COMPUTE"); c->tail_on_compute = !(v && v[0] == '0') && !c->tail_by_event; }
     { const char *v = std::getenv("ZRK_PAIR"); c->pair_enabled = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_PAIR_COMPACT"); c->pair_compact = !(v && v[0] == '0'); }
     if (const char *v = std::getenv("ZRK_PAIR_COMPACT_BLOCKS"))
@@ -4876,7 +4888,7 @@ int side_issue(Side *sd, const SideItem &it)
     // empty launch, instead of in front of the call's first compaction -- which everything behind it would then lag.
     {
         const auto now = std::chrono::steady_clock::now();
-        if (!it.wait_event && now - sd->last_launch > std::chrono::microseconds(300)) {
+        if (!it.wait_event && !it.on_compute && now - sd->last_launch > std::chrono::microseconds(300)) {
             hipLaunchKernelGGL(k_side_prime, dim3(1), dim3(64), 0, it.stream);
             (void)hipGetLastError();
             g_trace.mark("side: primed");
@@ -4886,15 +4898,24 @@ int side_issue(Side *sd, const SideItem &it)
     // ahead of their input -- deadlocks the device as soon as anything else on it needs whole compute units in dispatch
     // order (e.g. another engine's single-launch compaction), and a one-lane wait kernel in front of it costs the side
     // stream 5 us a tick.  This thread has nothing else to do.
-    if (it.wait_event) {
+    if (it.on_compute) {
+        // in order behind the call's last sweep; what the side stream still runs (the compaction before this one) comes first
+        if (sd->side_busy) {
+            if (hipEventRecord(sd->tail_ev, sd->stream) != hipSuccess || hipStreamWaitEvent(it.stream, sd->tail_ev, 0) != hipSuccess) {
+                sd->err = "side stream: the compute stream could not take it in (hipEventRecord / hipStreamWaitEvent)";
+                return ZRK_E_HIP;
+            }
+            sd->side_busy = false;
+        }
+    } else if (it.wait_event) {
         if (hipStreamWaitEvent(it.stream, it.wait_event, 0) != hipSuccess) { sd->err = "side stream: hipStreamWaitEvent failed"; return ZRK_E_HIP; }
     } else if (!spin_until([&] { return (int32_t)(*sd->hflag - it.flag_value) >= 0 || sd->stop.load(); })) {
         // (the caller queued more work in front of the loop than the limit allows for, or the device is gone)
         sd->err = "side stream: the compute stream did not reach the next sweep within the host wait limit (ZRK_HOST_WAIT_MS)";
         return ZRK_E_STATE;
     }
-    if (!it.wait_event && (int32_t)(*sd->hflag - it.flag_value) < 0) { sd->err = "side stream: stopped"; return ZRK_E_STATE; }
-    g_trace.mark("side: flag seen");
+    if (!it.wait_event && !it.on_compute && (int32_t)(*sd->hflag - it.flag_value) < 0) { sd->err = "side stream: stopped"; return ZRK_E_STATE; }
+    g_trace.mark(it.on_compute ? "side: the call's last item, to the compute stream" : "side: flag seen");
     const DoneWord dw{sd->hdone_dev, it.done_value - 1u};
     if (it.pair) {
         const dim3 grid(it.C.nb + (it.M.m > 0 ? 2 : 0));
@@ -4919,7 +4940,7 @@ int side_issue(Side *sd, const SideItem &it)
         sd->posted[it.done_slot] = false;
         if (it.pair) sd->posted[it.done_slot2] = false;
     }
-    sd->last_launch = std::chrono::steady_clock::now();
+    if (!it.on_compute) { sd->last_launch = std::chrono::steady_clock::now(); sd->side_busy = true; }
     g_trace.mark("side: compaction issued");
     if (it.post_x && exchange_post_behind_flag(it.post_x, it.post_slot, it.post_send, it.post_recv, it.post_words, it.raise_value) != 0) {
         sd->err = std::string("side stream: ") + it.post_x->err;
@@ -4987,6 +5008,7 @@ Side *side_of(zrk_ctx *ctx)
     }
     bool ok = (made || hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking) == hipSuccess) &&
               hipEventCreateWithFlags(&sd->last_sweep, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&sd->tail_ev, hipEventDisableTiming) == hipSuccess &&
               hipMalloc((void **)&sd->bar, 64) == hipSuccess && hipMemset(sd->bar, 0, 64) == hipSuccess &&
               hipHostMalloc((void **)&sd->hflag, 128, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
               hipHostGetDevicePointer((void **)&sd->hflag_dev, (void *)sd->hflag, 0) == hipSuccess;
@@ -4996,6 +5018,7 @@ Side *side_of(zrk_ctx *ctx)
         (void)hipGetLastError();
         for (int k = 0; k <= Side::kMasks; ++k) if (sd->done[k]) (void)hipEventDestroy(sd->done[k]);
         if (sd->last_sweep) (void)hipEventDestroy(sd->last_sweep);
+        if (sd->tail_ev) (void)hipEventDestroy(sd->tail_ev);
         if (sd->bar) (void)hipFree(sd->bar);
         if (sd->hflag) (void)hipHostFree((void *)sd->hflag);
         if (sd->stream) (void)hipStreamDestroy(sd->stream);
@@ -5075,6 +5098,7 @@ void side_destroy(Side *sd)
     if (sd->stream) { (void)hipStreamSynchronize(sd->stream); (void)hipStreamDestroy(sd->stream); }
     for (int k = 0; k <= Side::kMasks; ++k) if (sd->done[k]) (void)hipEventDestroy(sd->done[k]);
     if (sd->last_sweep) (void)hipEventDestroy(sd->last_sweep);
+    if (sd->tail_ev) (void)hipEventDestroy(sd->tail_ev);
     for (int k = 0; k < Side::kMasks; ++k) if (sd->masks[k]) (void)hipFree(sd->masks[k]);
     for (int k = 0; k < Side::kMasks; ++k) if (sd->codes[k]) (void)hipFree(sd->codes[k]);
     if (sd->pend) (void)hipFree(sd->pend);
@@ -5284,6 +5308,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     g_trace.mark("run_ticks: side ready");
     hipStream_t side_stream = sd ? sd->stream : nullptr;
     int side_last = -1;
+    bool tail_on_s = false;                              // the call's last compaction went to the compute stream (SideItem::on_compute)
     zrk_exchange *fx = (xio && xio->x->flag) ? xio->x : nullptr;
     if (fx && fx->seq > 0x7FFF0000u) {                   // far from wrapping: the comparison is on 32 bits
         if (hipStreamSynchronize(fx->cstream) != hipSuccess) return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
@@ -5483,6 +5508,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         zrk_scan_advance(radars_b, scan, R);
         radar_block_ahead(ctx, radars_b, R, st->flags, 1);
         const bool last_launch = k + nt == K;
+        const bool tail_here = last_launch && !xio && ctx->tail_on_compute;       // (SideItem::on_compute)
         if (last_launch && ctx->tail_by_event && hipEventRecord(sd->last_sweep, s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipEventRecord");
         // the side stream's work, released when the NEXT launch starts: both ticks' compactions in one launch ...
         if (pc && rc == 0) {
@@ -5514,7 +5540,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                 a.C.lanes = lanes;
                 a.C.group = a.C.nb > 512 ? 32 : (a.C.nb > 32 ? 16 : 0);   // (half as many records per batch of loads as the single compaction)
                 if (ctx->env_group >= 0) a.C.group = ctx->env_group;
-                a.stream = side_stream; a.flag_value = ++sd->seq; a.done_slot = slot_t[0]; a.done_slot2 = slot_t[1];
+                a.stream = tail_here ? s : side_stream; a.on_compute = tail_here ? 1 : 0;
+                a.flag_value = ++sd->seq; a.done_slot = slot_t[0]; a.done_slot2 = slot_t[1];
                 a.M = M; a.M.apply = 0; a.M.clear_vis = nullptr;
                 if (fused) {                               // the first tick's ordered events: a list of the context's own
                     a.M.ev_missile = sd->scratch_ev; a.M.ev_target = sd->scratch_ev + sd->scratch_ev_rows;
@@ -5553,6 +5580,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                     }
                 }
                 side_last = slot_t[1];
+                tail_on_s = tail_here;
                 if (slot_t[1] == Side::kMasks) ctx->ring_clean[st->vis_cur] = false;
             }
         }
@@ -5566,7 +5594,8 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                                 (st->flags & ZRK_F_UNION_BITS) != 0, nullptr, nullptr, &it);
             if (rc != 0) break;
             if (ev_words && !fused && hipMemsetAsync(list_t[j] + list_words, 0, sizeof(int64_t), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset events"); break; }
-            it.stream = side_stream; it.flag_value = ++sd->seq; it.done_slot = slot_t[j];
+            it.stream = tail_here ? s : side_stream; it.on_compute = tail_here ? 1 : 0;
+            it.flag_value = ++sd->seq; it.done_slot = slot_t[j];
             it.M = M; it.M.apply = 0;
             if (fused && j == 1) it.M.ev_code = M.ev_code2;
             if (fused && ev_words) it.M.ev_wire = list_t[j] + list_words;
@@ -5592,6 +5621,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                     rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(x));
             }
             side_last = slot_t[j];
+            tail_on_s = tail_here;
             if (slot_t[j] == Side::kMasks) ctx->ring_clean[st->vis_cur] = false;
         }
         st->cur = (nt == 2) ? cur_b : cur_a;
@@ -5729,7 +5759,9 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                 if ((rc = check_launch(ctx, "k_tick_small")) != 0) break;
             }
             if (ev_words && !fused && hipMemsetAsync(list + list_words, 0, sizeof(int64_t), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset events"); break; }
-            it.stream = side_stream; it.flag_value = v; it.done_slot = side_slot;
+            const bool tail_here = k + 1 == K && !xio && ctx->tail_on_compute;
+            it.stream = tail_here ? s : side_stream; it.on_compute = tail_here ? 1 : 0;
+            it.flag_value = v; it.done_slot = side_slot;
             it.M = M; it.M.apply = 0;
             it.record_event = (k + 1 == K) ? 1 : 0;
             if (k + 1 == K && ctx->tail_by_event) {
@@ -5748,6 +5780,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                 break;
             }
             side_last = side_slot;
+            tail_on_s = tail_here;
             if (side_slot == Side::kMasks) ctx->ring_clean[st->vis_cur] = false;
             st->time_ms += st->dt_ms;
             st->tick += 1;
@@ -5782,7 +5815,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (held.on && rc == 0) rc = issue_held();
         // behind the last tick: its removals as tombstones, the word the side stream's thread waits for, then the side
         // stream's work is issued to the last item and the compute stream takes it in: the lists are the caller's
-        if (rc == 0 && side_last >= 0 && !ctx->tail_by_event) {   // (first: the last compaction may start as soon as the last sweep is over)
+        if (rc == 0 && side_last >= 0 && !ctx->tail_by_event && !tail_on_s) {   // (first: the last compaction may start as soon as the last sweep is over)
             hipLaunchKernelGGL(k_raise_flag_system, dim3(1), dim3(1), 0, s, sd->hflag_dev, sd->seq);
             rc = check_launch(ctx, "k_raise_flag");
         }
@@ -5807,8 +5840,9 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (xio) xio->x->via_side = nullptr;                 // (everything it carried has been issued, or has failed with it)
         if (rc != 0) { sd->masks_dirty = true; sd->pend_rows = 0; }  // (marks: allocated and cleared anew)
         if (rc == 0 && side_last >= 0 && sd->posted[side_last]) {
-            if (hipStreamWaitEvent(s, sd->done_of[side_last], 0) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipStreamWaitEvent");
-            else { sd->joined_upto = sd->head.load(); sd->joined_stream = s; }
+            // (a last item on the compute stream is in it already; the event behind it is for a later call on ANOTHER stream)
+            if (!tail_on_s && hipStreamWaitEvent(s, sd->done_of[side_last], 0) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipStreamWaitEvent");
+            else { sd->joined_upto = sd->head.load(); sd->joined_stream = s; if (!tail_on_s) sd->side_busy = false; }
         }
     }
     g_trace.mark("run_ticks: exit");
