@@ -735,27 +735,38 @@ __device__ __forceinline__ Cull cull_box(const PreTable &T, int R, bool shortcut
 
 // Radars in `c.cand`, in order, over the wave's rows at (x, y, z); leaves the visibility mask in `mask` and the
 // (perturbed) position in place.  Called with the whole wave converged (the early-outs are wave-level votes).
-template <bool PHILOX>
+template <bool PHILOX, bool LAZY>
 __device__ __forceinline__ void sweep_rows(uint64_t tick, int64_t gid0, const char *rbp, uint64_t seed, const Cull &c, int64_t li,
                                            bool live, double &x, double &y, double &z, uint32_t &mask, int64_t probe_wave)
 {
     typedef const uint32_t __attribute__((address_space(4))) *ConstWords;
-    // keyed by list index: layout-independent.  Seeded when the first lane of the wave is detected -- in
-    // spatial order most waves never are, and the ten Philox rounds are a fifth of a quiet wave's work.
+    // The three masks are the workgroup's (one box per row block, handed round through LDS): scalars, so that the walk's
+    // control flow is the scalar unit's.  The noise stream is keyed by list index: layout-independent.  !LAZY (the
+    // overlapped loop's kernels): it is seeded once per wave that has any radar to walk (one in four at C3; the ten Philox
+    // rounds cost such a wave less than one radar) -- seeding at the first detection made every radar of the walk carry the
+    // "seeded yet?" selects, a third of the instructions of a radar that sees the whole block (77 -> 41 vector instructions).
+    // LAZY (stand-alone sweeps, the plain loop, ensembles): at the wave's first detection -- small scenarios with few
+    // radars have many waves that walk a radar or two and detect nothing.
+    const uint32_t cands = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.cand);
+    const uint32_t easy = (uint32_t)__builtin_amdgcn_readfirstlane((int)(c.inside | c.plane));
+    const uint32_t planes = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.plane);
     NoiseState ns = NoiseState{0u, 0u, 0u, 0u};
-    bool seeded = false;
+    bool seeded = !LAZY;
     mask = 0u;
+    if (PHILOX && !LAZY && cands) ns = noise_init(seed, tick, (uint64_t)(gid0 + li));
 #ifdef ZRK_PROBE_BUILD
     int probe_deep = 0;
 #endif
-    for (uint32_t cand = c.cand; cand; cand &= cand - 1) {
+    for (uint32_t cand = cands; cand; cand &= cand - 1) {
         const int r = __builtin_ctz(cand);
-        if (((c.inside | c.plane) >> r) & 1u) {       // every live row (above the radar's plane) is visible: no geometry
-            const bool by_plane = (c.plane >> r) & 1u;
-            const double rpz = __builtin_bit_cast(double, ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)c.pz_hi, r) << 32) |
-                                                               (uint32_t)__builtin_amdgcn_readlane((int)c.pz_lo, r));
-            const bool vis = live & (!by_plane | (z - rpz >= 0.0));
-            if (PHILOX && !seeded && __ballot(vis)) {
+        if ((easy >> r) & 1u) {                       // every live row (above the radar's plane) is visible: no geometry
+            bool vis = live;
+            if ((planes >> r) & 1u) {                 // (wave-uniform)
+                const double rpz = __builtin_bit_cast(double, ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)c.pz_hi, r) << 32) |
+                                                                   (uint32_t)__builtin_amdgcn_readlane((int)c.pz_lo, r));
+                vis = live & (z - rpz >= 0.0);
+            }
+            if (PHILOX && LAZY && !seeded && __ballot(vis)) {
                 ns = noise_init(seed, tick, (uint64_t)(gid0 + li));
                 seeded = true;
             }
@@ -818,7 +829,7 @@ __device__ __forceinline__ void sweep_rows(uint64_t tick, int64_t gid0, const ch
         bool vis = in_range & (t > gd);
         const bool amb = in_range & ((fabsf(t) <= gd) | !(d2f < d2f_in));
         if (amb) vis = visible_exact((uint64_t)(rbp + offsetof(RadarBlock, cold) + (size_t)r * sizeof(RadarCold)), dx, dy, dz);
-        if (PHILOX && !seeded && __ballot(vis)) {
+        if (PHILOX && LAZY && !seeded && __ballot(vis)) {
             ns = noise_init(seed, tick, (uint64_t)(gid0 + li));
             seeded = true;
         }
@@ -1215,7 +1226,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) voi
     __shared__ double s_hold[PAIR ? 3 : 1][PAIR ? ZRK_BLOCK : 1];
     if (c.cand) {
         if (PAIR) { s_hold[0][tid] = x2; s_hold[1][tid] = y2; s_hold[2][tid] = z2; }
-        sweep_rows<PHILOX>(P.tick, P.gid0, rbp, seed, c, li, live, x, y, z, mask, wave);
+        sweep_rows<PHILOX, !MARKS>(P.tick, P.gid0, rbp, seed, c, li, live, x, y, z, mask, wave);
         if (PAIR) { x2 = s_hold[0][tid]; y2 = s_hold[1][tid]; z2 = s_hold[2][tid]; }
     }
     // (the number is asked for here and used at the very end: its round trip hides behind the rows' stores)
@@ -1238,7 +1249,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) voi
         // the second tick: same rows, the next radar records, the next noise key.  (A row that tick t's missile phase removes
         // is swept here all the same -- its thread cannot know; see SweepParams::t2 for who puts that right.)
         uint32_t mask2 = 0u;
-        if (c2.cand) sweep_rows<PHILOX>(P.tick + 1, P.gid0, rbp2, seed, c2, li, live, x2, y2, z2, mask2, wave);
+        if (c2.cand) sweep_rows<PHILOX, !MARKS>(P.tick + 1, P.gid0, rbp2, seed, c2, li, live, x2, y2, z2, mask2, wave);
         ZRK_WAVE_PROBE(wave, 4, wall_clock64());              // (pair: slot 4 is the end of the second tick's radar loop)
         if (live) { P.pos_prev[i] = x2; P.pos_prev[cap + i] = y2; P.pos_prev[2 * cap + i] = z2; }
         if (i < P.n && (mask2 || !(P.flags & kSparseVis2))) P.vis2[li] = mask2;
