@@ -338,3 +338,30 @@ def _state_table(eng):
     return dict(pos_cur=st.host_pos("cur").view(np.uint64), pos_prev=st.host_pos("prev").view(np.uint64),
                 alive=st.d_alive[:n].cpu().numpy(), period=st.dm_period[:m].cpu().numpy().view(np.uint64),
                 status=st.dm_status[:m].cpu().numpy(), radar=np.array(eng.radar_state()))
+
+
+@pytest.mark.parametrize("tail", ["compute", "side"])
+def test_calls_on_alternating_streams(tail, monkeypatch):
+    """A call's last compaction runs on the caller's stream (ZRK_TAIL_COMPUTE=0: on the side stream, taken in through an
+    event), and the next call may come on ANOTHER stream that the caller has ordered behind the first: short calls (two
+    launches each) and long ones on two streams in turn must leave what the same calls on one stream leave."""
+    from tests.test_gpu_engine import _engine
+    monkeypatch.setenv("ZRK_OVERLAP_MIN_ROWS", "0")
+    monkeypatch.setenv("ZRK_OVERLAP", "1")
+    monkeypatch.setenv("ZRK_TAIL_COMPUTE", "1" if tail == "compute" else "0")
+    one, _, launched = _engine(120_000, 6, 400, seed=33, noise="philox")
+    two, _, _ = _engine(120_000, 6, 400, seed=33, noise="philox")
+    assert launched > 50
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for calls, K in enumerate([4, 4, 5, 4, 11, 4, 4, 6, 4, 4, 4, 4, 9, 4]):
+        one.run(K)
+        s = streams[calls % 2]
+        s.wait_stream(streams[(calls + 1) % 2])                 # (the caller's ordering of its own streams)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            two.run(K)
+        if calls % 4 == 3:
+            torch.cuda.current_stream().wait_stream(s)
+            _same(_state(one), _state(two), f"after call {calls} of {K} ticks on stream {calls % 2}")
+    torch.cuda.synchronize()
+    _same(_state(one), _state(two), "at the end")

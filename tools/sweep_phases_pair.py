@@ -101,3 +101,14 @@ np.maximum.at(last_heavy, unit[~light], end[~light])
 print(f"end of the last heavy wave per SIMD [us]: {q(last_heavy[used])}")
 r = np.corrcoef(walk_per[used], last_heavy[used])[0, 1]
 print(f"correlation of a SIMD's walked sum with the end of its last heavy wave: {r:.2f}")
+
+# what the heavy waves walk: radars that are candidates / see every row of the block (inside) / every row above their plane,
+# per wave of tick t (probe slot 7), the radars whose walk got to the full classification (slot 5), detected rows (slot 4 is
+# overwritten by the pair's second loop stamp)
+inside_n, plane_n = (t[:, 7] >> 8) & 0xFF, (t[:, 7] >> 16) & 0xFF
+deep = t[:, 5]
+hv = ~light
+print(f"heavy waves ({int(hv.sum())}): candidates per wave {q(walked[hv])}; inside {q(inside_n[hv])}; plane {q(plane_n[hv])}; "
+      f"to the full classification {q(deep[hv])}")
+print(f"sums over the launch (tick t): candidates {int(walked.sum())}, inside {int(inside_n.sum())}, plane {int(plane_n.sum())}, "
+      f"full classification {int(deep.sum())}")
