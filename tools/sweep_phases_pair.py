@@ -106,9 +106,9 @@ print(f"correlation of a SIMD's walked sum with the end of its last heavy wave: 
 # per wave of tick t (probe slot 7), the radars whose walk got to the full classification (slot 5), detected rows (slot 4 is
 # overwritten by the pair's second loop stamp)
 inside_n, plane_n = (t[:, 7] >> 8) & 0xFF, (t[:, 7] >> 16) & 0xFF
-deep = t[:, 5]
+deep, deep_all, deep_none = t[:, 5] & 0xFF, (t[:, 5] >> 8) & 0xFF, (t[:, 5] >> 16) & 0xFF   # (of the pair's SECOND tick: the slot is written twice)
 hv = ~light
 print(f"heavy waves ({int(hv.sum())}): candidates per wave {q(walked[hv])}; inside {q(inside_n[hv])}; plane {q(plane_n[hv])}; "
       f"to the full classification {q(deep[hv])}")
 print(f"sums over the launch (tick t): candidates {int(walked.sum())}, inside {int(inside_n.sum())}, plane {int(plane_n.sum())}, "
-      f"full classification {int(deep.sum())}")
+      f"full classification (tick t + 1) {int(deep.sum())}, of which every live row seen {int(deep_all.sum())}, none {int(deep_none.sum())}")

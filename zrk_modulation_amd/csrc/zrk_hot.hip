@@ -755,7 +755,7 @@ __device__ __forceinline__ void sweep_rows(uint64_t tick, int64_t gid0, const ch
     mask = 0u;
     if (PHILOX && !LAZY && cands) ns = noise_init(seed, tick, (uint64_t)(gid0 + li));
 #ifdef ZRK_PROBE_BUILD
-    int probe_deep = 0;
+    int probe_deep = 0, probe_all = 0, probe_none = 0;   // radars walked to the full classification; ... that saw every live row / none
 #endif
     for (uint32_t cand = cands; cand; cand &= cand - 1) {
         const int r = __builtin_ctz(cand);
@@ -829,6 +829,10 @@ __device__ __forceinline__ void sweep_rows(uint64_t tick, int64_t gid0, const ch
         bool vis = in_range & (t > gd);
         const bool amb = in_range & ((fabsf(t) <= gd) | !(d2f < d2f_in));
         if (amb) vis = visible_exact((uint64_t)(rbp + offsetof(RadarBlock, cold) + (size_t)r * sizeof(RadarCold)), dx, dy, dz);
+#ifdef ZRK_PROBE_BUILD
+        probe_all += (__ballot(vis) == __ballot(live)) ? 1 : 0;
+        probe_none += (__ballot(vis) == 0ull) ? 1 : 0;
+#endif
         if (PHILOX && LAZY && !seeded && __ballot(vis)) {
             ns = noise_init(seed, tick, (uint64_t)(gid0 + li));
             seeded = true;
@@ -843,7 +847,7 @@ __device__ __forceinline__ void sweep_rows(uint64_t tick, int64_t gid0, const ch
         }
     }
 #ifdef ZRK_PROBE_BUILD
-    ZRK_WAVE_PROBE(probe_wave, 5, (long long)probe_deep);
+    ZRK_WAVE_PROBE(probe_wave, 5, (long long)(probe_deep | (probe_all << 8) | (probe_none << 16)));
 #endif
 }
 
