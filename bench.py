@@ -622,7 +622,7 @@ def main():
                     # the first multi-rank record checks itself: RCCL's own count of the communicator's ranks, and how long
                     # the calling thread waited for collectives (per tick of the timed call and the calibration ticks behind it)
                     out["config"]["rccl_ranks_seen"] = xi["rccl_ranks_seen"]
-                    out["config"]["exchange_pattern"] = xi["pattern"]
+                    out["config"]["exchange_pattern"] = xi["pattern"] + (", the two ticks of a launch as one group" if xi["grouped_pairs"] else "")
                     out["config"]["exchange_host_wait_us_per_tick"] = xi["host_wait_us"] / max(1, xi["collectives"])
                     out["config"]["exchange_host_waits"] = xi["host_waits"]
             if world == 1 and cpu_base and not ensemble:

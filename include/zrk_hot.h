@@ -371,7 +371,10 @@ typedef struct {
  * compute stream says, through a word of pinned host memory, that sweep t + 1 has started), and `stream` carries one
  * launch per tick: removals decided by a tick's missile phase are marks that the rows' own threads carry out in the
  * next sweep (tombstones again when the call returns), radar records travel in the sweep's arguments.  Same results;
- * `stream` takes the side stream in before the call returns, so the outputs are the caller's as before.  Differences
+ * `stream` takes the side stream in before the call returns, so the outputs are the caller's as before.  The call's LAST
+ * compaction (no exchange) is launched on `stream` itself, in order behind the last sweep -- by the context's thread: a
+ * caller must not be capturing `stream` into a graph, and must order its own streams if consecutive calls come on
+ * different ones (ZRK_TAIL_COMPUTE=0: on the side stream like the others, released by a launch behind the last sweep).  Differences
  * a caller can see: the masks of all ticks but the LAST of such a call live in buffers of the context
  * (ents->vis_mask / vis_mask_alt hold the last tick's, as st->vis_cur says), likewise mis->ev_code; the dispatch order
  * of a sweep's workgroups is never the same twice (it does not enter any result).
@@ -394,7 +397,7 @@ typedef struct {
  * ZRK_PAIR_THREADS=256|512|1024 and ZRK_PAIR_COMPACT_BLOCKS (workgroup size of the pair compaction, and up to how many
  * workgroups a pair's compactions are one launch), ZRK_COMPACT_GROUP=0|4|8|16|32 (two-level sums of the workgroup records),
  * ZRK_COMPACT_ITEMS, ZRK_COMPACT_FUSED_MAX_BLOCKS, ZRK_SIDE_CUS=n[,first] / ZRK_SIDE_PRIORITY=high|low (the side stream's
- * place on the device), ZRK_TAIL_EVENT=1 (the call's last compaction released by an event), ZRK_CCP_GRID=0|1 (zrk_ccp_step's
+ * place on the device), ZRK_TAIL_COMPUTE=0 / ZRK_TAIL_EVENT=1 (the call's last compaction on the side stream, released by a launch / an event), ZRK_CCP_GRID=0|1 (zrk_ccp_step's
  * candidate pass: all pairs / spatial index), ZRK_TRACE=1 (host time stamps of a call on stderr).
  * Every host-side wait is bounded by ZRK_HOST_WAIT_MS (default 30000): if the
  * side stream's thread waits that long for the compute stream to reach the next sweep (the caller had queued more work in
@@ -468,7 +471,8 @@ int zrk_exchange_sync(zrk_exchange *x);
  * wait for a collective posted ZRK_EXCHANGE_SLOTS ticks earlier before it could reuse its send buffer.  No reference
  * counterpart (the reference is one process). */
 typedef struct zrk_exchange_stats {
-    int32_t world, rank, comm_ranks, direct, helper_threads, _pad;
+    int32_t world, rank, comm_ranks, direct, helper_threads;
+    int32_t grouped_pairs;          /* 1: the two collectives of a two-tick launch go out as one RCCL group (ZRK_EXCHANGE_GROUP=0: not) */
     int64_t collectives, host_waits;
     double host_wait_us;
 } zrk_exchange_stats;

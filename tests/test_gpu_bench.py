@@ -59,6 +59,6 @@ def test_exchange_control_flow_on_one_rank_with_real_rccl():
                  env={"ZRK_BENCH_FORCE_EXCHANGE": "1"})
     assert rec["n_gpus"] == 1 and rec["config"]["exchange"] == "rccl, C side"
     assert rec["config"]["exchange_overflow"] is False and rec["config"]["exchange_entries_per_rank"] > 0
-    assert rec["config"]["rccl_ranks_seen"] in (1, -1) and rec["config"]["exchange_pattern"] == "ncclAllGather"
+    assert rec["config"]["rccl_ranks_seen"] in (1, -1) and rec["config"]["exchange_pattern"].startswith("ncclAllGather")
     assert rec["config"]["exchange_host_wait_us_per_tick"] >= 0 and "bitmap" in rec["config"]["exchange_wire"]
     assert rec["value"] > 0

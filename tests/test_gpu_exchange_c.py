@@ -108,13 +108,17 @@ def test_a_collective_whose_list_never_came_goes_out_poisoned_and_fails_the_call
     x.close()
 
 
-@pytest.mark.parametrize("algo", ["allgather", "direct"])
+@pytest.mark.parametrize("algo", ["allgather", "direct", "allgather-ungrouped", "direct-ungrouped"])
 def test_union_only_wire_and_the_direct_pattern_on_one_rank(algo, monkeypatch):
     """wire "union": the bitmap of the slots seen by any radar and the events, nothing else (a fifth of the bytes); and
     ZRK_EXCHANGE_ALGO=direct: grouped send / receive to every peer instead of ncclAllGather -- with one rank that is the local
-    copy, which is all a one-GPU box can run of it.  zrk_exchange_info says what the communicator thinks of itself."""
+    copy, which is all a one-GPU box can run of it.  The two collectives of a two-tick launch go out as one RCCL group
+    (ZRK_EXCHANGE_GROUP=0: one after the other).  zrk_exchange_info says what the communicator thinks of itself."""
     from zrk_modulation_amd.exchange import RcclExchange, union_bits_words
+    grouped = not algo.endswith("-ungrouped")
+    algo = algo.split("-")[0]
     monkeypatch.setenv("ZRK_EXCHANGE_ALGO", algo)
+    monkeypatch.setenv("ZRK_EXCHANGE_GROUP", "1" if grouped else "0")
     monkeypatch.setenv("ZRK_OVERLAP_MIN_ROWS", "0")
     n, R, m = 30_000, 6, 400
     eng_a, _, _ = _engines(n, R, m, 11)
@@ -142,5 +146,5 @@ def test_union_only_wire_and_the_direct_pattern_on_one_rank(algo, monkeypatch):
     assert not x.overflowed()
     info = x.info()
     assert info["world"] == 1 and info["rccl_ranks_seen"] in (1, -1) and info["collectives"] == tick
-    assert info["pattern"] == ("direct send/recv" if algo == "direct" else "ncclAllGather")
+    assert info["pattern"] == ("direct send/recv" if algo == "direct" else "ncclAllGather") and info["grouped_pairs"] == grouped
     x.close()

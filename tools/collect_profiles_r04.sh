@@ -33,7 +33,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/traffic_C3_$c -- $B --steps 40 --warmup 20 --no-cpu-baseline --no-c4 > $out/traffic_C3_$c.log 2>&1
 done
 echo "== SQ counters"
-for c in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD"; do
+for c in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD" "SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH"; do
   n=$(echo $c | tr ' ' '_')
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/sq_$n -- $B --steps 24 --warmup 12 --no-cpu-baseline --no-c4 > $out/sq_$n.log 2>&1
 done

@@ -129,32 +129,38 @@ if len(vals) == 2:
            "per tick swept, 1 B per tombstone (113 B per live entity); `effective` in the bench line keeps SURVEY 8d's 85 B per "
            "entity and tick swept."), indent=1) + "\n")
 
-# SQ counters of the pair sweep: per-dispatch averages
-sq = {}
+# SQ counters of the pair sweep and of the pair compaction beside it: per-dispatch averages
+sq = {"k_tick_sweep": {}, "k_compact_pair": {}}
 for d in glob.glob(str(src / "sq_*")):
     f = newest(d + "/*/*counter_collection.csv")
     if not f:
         continue
-    acc = {}
+    acc = {"k_tick_sweep": {}, "k_compact_pair": {}}
     for r in csv.DictReader(open(f[0])):
-        if "k_tick_sweep" in r["Kernel_Name"]:
-            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        v = v[6:] or v
-        sq[k] = sum(v) / len(v)
-if sq:
+        for kern in acc:
+            if kern in r["Kernel_Name"] and (kern != "k_tick_sweep" or "std::conditional<true" in r["Kernel_Name"]):
+                acc[kern].setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for kern in acc:
+        for k, v in acc[kern].items():
+            v = v[6:] or v
+            sq[kern][k] = sum(v) / len(v)
+if sq["k_tick_sweep"]:
     with open(dst / f"{tag}_pmc_sq.txt", "w") as o:
-        o.write("# k_tick_sweep (pair launch, C3), rocprofv3 --pmc, per dispatch (kernels serialised by the counter passes)\n")
-        for k in sorted(sq):
-            o.write(f"{k:24s} {sq[k]:16.1f}\n")
-        if sq.get("SQ_WAVES"):
-            for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD"):
-                if k in sq:
-                    o.write(f"{k + ' / wave':24s} {sq[k] / sq['SQ_WAVES']:16.1f}\n")
-        if sq.get("SQ_WAVE_CYCLES"):
-            for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
-                if k in sq:
-                    o.write(f"{k + ' / wave cycles':32s} {sq[k] / sq['SQ_WAVE_CYCLES']:8.3f}\n")
+        for kern, title in (("k_tick_sweep", "k_tick_sweep (pair launch, C3)"), ("k_compact_pair", "k_compact_pair<1024> (the launch beside it)")):
+            q = sq[kern]
+            if not q:
+                continue
+            o.write(f"# {title}, rocprofv3 --pmc, per dispatch (kernels serialised by the counter passes)\n")
+            for k in sorted(q):
+                o.write(f"{k:24s} {q[k]:16.1f}\n")
+            if q.get("SQ_WAVES"):
+                for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS"):
+                    if k in q:
+                        o.write(f"{k + ' / wave':24s} {q[k] / q['SQ_WAVES']:16.1f}\n")
+            if q.get("SQ_WAVE_CYCLES"):
+                for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+                    if k in q:
+                        o.write(f"{k + ' / wave cycles':32s} {q[k] / q['SQ_WAVE_CYCLES']:8.3f}\n")
 
 for name in ("bench_c3_driver_1", "bench_c3_driver_2", "bench_c3_driver_3", "bench_c3", "bench_c3_one_tick_per_launch", "bench_c3_plain_loop",
              "bench_c3_exchange_one_rank", "bench_c2", "bench_c5", "bench_c3x4", "bench_c4_1gpu"):

@@ -105,7 +105,7 @@ class ZrkLaunchRes(C.Structure):
 
 class ZrkExchangeStats(C.Structure):
     _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("comm_ranks", C.c_int32), ("direct", C.c_int32),
-                ("helper_threads", C.c_int32), ("_pad", C.c_int32), ("collectives", C.c_int64), ("host_waits", C.c_int64),
+                ("helper_threads", C.c_int32), ("grouped_pairs", C.c_int32), ("collectives", C.c_int64), ("host_waits", C.c_int64),
                 ("host_wait_us", C.c_double)]
 
 

@@ -4547,12 +4547,16 @@ struct zrk_exchange {
     // one hop over the peer's own xGMI link, all links at once) instead of ncclAllGather, whose ring passes every list through
     // world - 1 links one after the other.  Default: ncclAllGather, as RCCL chooses to run it
     bool direct = false;
+    bool group_pairs = true;                            // a pair launch's two collectives in one RCCL group (ZRK_EXCHANGE_GROUP=0: not)
     // self-check for the first multi-rank record: what the communicator says its size is, how often and how long the calling
     // thread had to wait for a collective posted ZRK_EXCHANGE_SLOTS ticks before (zrk_exchange_info)
     std::atomic<int64_t> waits{0}, wait_ns{0}, collectives{0};
     // ... and those collectives are issued by a thread of the exchange's own: waiting for the value, the RCCL call and the
     // event record take the calling thread longer than the two launches of a tick, and the device would wait for its host
-    struct PostItem { int slot; const int64_t *send; int64_t *recv; int64_t words; uint32_t value; };
+    // (slot2 >= 0: the two ticks of a pair launch, whose lists one compaction launch hands over: ONE wait, the two
+    // collectives in one RCCL group -- one launch on the exchange stream instead of two)
+    struct PostItem { int slot; const int64_t *send; int64_t *recv; int64_t words; uint32_t value;
+                      int slot2 = -1; const int64_t *send2 = nullptr; int64_t *recv2 = nullptr; };
     static constexpr uint64_t kRing = 8;
     PostItem ring[kRing];
     std::atomic<uint64_t> head{0}, tail{0};             // items handed to the thread / items it has issued
@@ -4568,7 +4572,8 @@ struct zrk_exchange {
 
 namespace {
 
-int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, int64_t *recv, int64_t words, uint32_t value);
+int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, int64_t *recv, int64_t words, uint32_t value,
+                              int slot2 = -1, const int64_t *send2 = nullptr, int64_t *recv2 = nullptr);
 int exchange_collective(zrk_exchange *x, const int64_t *send, int64_t *recv, int64_t words);
 __global__ void k_poison_if_gave_up(const uint32_t *gave_up, int64_t *send);
 
@@ -4602,7 +4607,7 @@ void exchange_poster_main(zrk_exchange *x)
         const uint64_t t = x->tail.load(std::memory_order_relaxed);
         if (x->head.load(std::memory_order_acquire) != t) {
             const zrk_exchange::PostItem it = x->ring[t % zrk_exchange::kRing];
-            if (x->post_rc.load() == 0 && exchange_post_behind_flag(x, it.slot, it.send, it.recv, it.words, it.value) != 0) {
+            if (x->post_rc.load() == 0 && exchange_post_behind_flag(x, it.slot, it.send, it.recv, it.words, it.value, it.slot2, it.send2, it.recv2) != 0) {
                 x->post_err = x->err;
                 x->post_rc.store(ZRK_E_HIP);
             }
@@ -4633,6 +4638,7 @@ int exchange_enqueue(zrk_exchange *x, const zrk_exchange::PostItem &it)
     x->ring[h % zrk_exchange::kRing] = it;
     x->head.store(h + 1, std::memory_order_release);
     x->item_no[it.slot] = h + 1;
+    if (it.slot2 >= 0) x->item_no[it.slot2] = h + 1;
     if (x->asleep.load()) { std::lock_guard<std::mutex> lk(x->mu); x->cv.notify_one(); }
     return 0;
 }
@@ -4694,6 +4700,7 @@ ZRK_API int zrk_exchange_create(const char *rccl_path, const zrk_rccl_id *id, in
         x->direct = std::strcmp(algo, "direct") == 0;
         if (x->direct && !(x->api.Send && x->api.Recv && x->api.GroupStart && x->api.GroupEnd)) { x->err = "ZRK_EXCHANGE_ALGO=direct: this RCCL has no ncclSend / ncclRecv"; return ZRK_E_HIP; }
     }
+    { const char *v = std::getenv("ZRK_EXCHANGE_GROUP"); x->group_pairs = !(v && v[0] == '0') && x->api.GroupStart && x->api.GroupEnd; }
     const char *in_stream = std::getenv("ZRK_EXCHANGE_WAIT_IN_STREAM");
     x->wait_in_stream = in_stream && in_stream[0] == '1';
     const char *force_events = std::getenv("ZRK_EXCHANGE_EVENTS");
@@ -4805,7 +4812,7 @@ __global__ void k_raise_flag(uint32_t *flag, uint32_t value)
 // the wire at the latest one tick on.  (A profiler that serialises kernels across streams -- rocprofv3 --pmc -- makes the
 // producer on the other stream wait for this kernel: the give-up is then certain.  Do not collect counters on the
 // exchange path.)
-__global__ void k_wait_flag(const uint32_t *flag, uint32_t value, uint32_t *gave_up, int64_t *send, int spins)
+__global__ void k_wait_flag(const uint32_t *flag, uint32_t value, uint32_t *gave_up, int64_t *send, int spins, int64_t *send2)
 {
     bool up = false;
     // (once it has given up, the later lists are poisoned BEHIND their compaction: those waits take the full default)
@@ -4815,8 +4822,10 @@ __global__ void k_wait_flag(const uint32_t *flag, uint32_t value, uint32_t *gave
         if (!up) __builtin_amdgcn_s_sleep(32);
     }
     if (!up) __hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (!up || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+    if (!up || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
         __hip_atomic_store(send, (int64_t)-1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (send2) __hip_atomic_store(send2, (int64_t)-1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a pair's second list)
+    }
 }
 
 // The same for a list that is handed over by an event (the last tick of a call): poisoned if the exchange has given up before.
@@ -4828,15 +4837,31 @@ __global__ void k_poison_if_gave_up(const uint32_t *gave_up, int64_t *send)
 
 // The collective of a list whose producer has no event behind it: the exchange stream waits until the flag word
 // reaches `value`, which a kernel launched BEHIND the producer on the compute stream writes as it starts.
-int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, int64_t *recv, int64_t words, uint32_t value)
+int exchange_post_behind_flag(zrk_exchange *x, int slot, const int64_t *send, int64_t *recv, int64_t words, uint32_t value,
+                              int slot2, const int64_t *send2, int64_t *recv2)
 {
+    const bool pair = slot2 >= 0 && send2 && recv2;
     // (a wait kernel of our own on a word of device memory: hipStreamWaitValue32 on signal memory does the same
     // job but cost the compute stream 3.5 us a tick in the measurement, this costs it nothing measurable)
-    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, x->cstream, x->flag, value, x->gave_up_dev, (int64_t *)send, x->wait_spins);
+    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, x->cstream, x->flag, value, x->gave_up_dev, (int64_t *)send, x->wait_spins,
+                       pair ? (int64_t *)send2 : (int64_t *)nullptr);
     if (hipGetLastError() != hipSuccess) { x->err = "k_wait_flag launch failed"; return ZRK_E_HIP; }
-    if (int rc = exchange_collective(x, send, recv, words)) return rc;
+    if (pair) {
+        // the two ticks of a pair launch: both collectives in ONE group -- RCCL issues a group's operations as one launch
+        // (ZRK_EXCHANGE_GROUP=0: one after the other, as two single ticks would go)
+        int rcg = x->group_pairs ? x->api.GroupStart() : 0;
+        int rc = rcg != 0 ? ZRK_E_HIP : exchange_collective(x, send, recv, words);
+        if (rc == 0) rc = exchange_collective(x, send2, recv2, words);
+        if (x->group_pairs && rcg == 0 && x->api.GroupEnd() != 0 && rc == 0) { x->err = "ncclGroupEnd failed"; rc = ZRK_E_HIP; }
+        if (rcg != 0) x->err = "ncclGroupStart failed";
+        if (rc != 0) return rc;
+    } else if (int rc = exchange_collective(x, send, recv, words)) return rc;
     if (hipEventRecord(x->done[slot], x->cstream) != hipSuccess) { x->err = "hipEventRecord failed"; return ZRK_E_HIP; }
     x->posted[slot] = true;
+    if (pair) {
+        if (hipEventRecord(x->done[slot2], x->cstream) != hipSuccess) { x->err = "hipEventRecord failed"; return ZRK_E_HIP; }
+        x->posted[slot2] = true;
+    }
     return 0;
 }
 
@@ -4875,6 +4900,7 @@ ZRK_API int zrk_exchange_info(zrk_exchange *x, zrk_exchange_stats *out)
     if (!x || !out) return ZRK_E_INVALID;
     std::memset(out, 0, sizeof(*out));
     out->world = x->world; out->rank = x->rank; out->direct = x->direct ? 1 : 0; out->helper_threads = x->one_helper ? 1 : 2;
+    out->grouped_pairs = x->group_pairs ? 1 : 0;
     out->comm_ranks = -1;
     if (x->comm && x->api.CommCount) { int c = -1; if (x->api.CommCount(x->comm, &c) == 0) out->comm_ranks = c; }
     out->collectives = x->collectives.load(); out->host_waits = x->waits.load(); out->host_wait_us = (double)x->wait_ns.load() * 1e-3;
@@ -4957,12 +4983,8 @@ int side_issue(Side *sd, const SideItem &it)
     }
     if (!it.on_compute) { sd->last_launch = std::chrono::steady_clock::now(); sd->side_busy = true; }
     g_trace.mark("side: compaction issued");
-    if (it.post_x && exchange_post_behind_flag(it.post_x, it.post_slot, it.post_send, it.post_recv, it.post_words, it.raise_value) != 0) {
-        sd->err = std::string("side stream: ") + it.post_x->err;
-        return ZRK_E_HIP;
-    }
-    if (it.post_x && it.post2_send &&
-        exchange_post_behind_flag(it.post_x, it.post2_slot, it.post2_send, it.post2_recv, it.post_words, it.raise_value) != 0) {
+    if (it.post_x && exchange_post_behind_flag(it.post_x, it.post_slot, it.post_send, it.post_recv, it.post_words, it.raise_value,
+                                                it.post2_send ? it.post2_slot : -1, it.post2_send, it.post2_recv) != 0) {
         sd->err = std::string("side stream: ") + it.post_x->err;
         return ZRK_E_HIP;
     }
@@ -5584,14 +5606,14 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                     zrk_exchange *x = xio->x;
                     if (x->one_helper) { x->via_side = sd; x->side_item_no[xslot[0]] = x->side_item_no[xslot[1]] = sd->head.load(); }
                     else {
-                        for (int j = 0; j < 2 && rc == 0; ++j) {
-                            const uint32_t v = j ? a.raise_value : v_first;
-                            if (x->poster.joinable()) {
-                                if (int rce = exchange_enqueue(x, zrk_exchange::PostItem{xslot[j], list_t[j], xio->recv[xslot[j]], xio->words, v}))
-                                    rc = fail(ctx, rce, zrk_exchange_last_error(x));
-                            } else if (exchange_post_behind_flag(x, xslot[j], list_t[j], xio->recv[xslot[j]], xio->words, v) != 0)
-                                rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(x));
-                        }
+                        (void)v_first;
+                        if (x->poster.joinable()) {
+                            zrk_exchange::PostItem pi{xslot[0], list_t[0], xio->recv[xslot[0]], xio->words, a.raise_value};
+                            pi.slot2 = xslot[1]; pi.send2 = list_t[1]; pi.recv2 = xio->recv[xslot[1]];
+                            if (int rce = exchange_enqueue(x, pi)) rc = fail(ctx, rce, zrk_exchange_last_error(x));
+                        } else if (exchange_post_behind_flag(x, xslot[0], list_t[0], xio->recv[xslot[0]], xio->words, a.raise_value,
+                                                             xslot[1], list_t[1], xio->recv[xslot[1]]) != 0)
+                            rc = fail(ctx, ZRK_E_HIP, zrk_exchange_last_error(x));
                     }
                 }
                 side_last = slot_t[1];

@@ -206,7 +206,7 @@ class RcclExchange:
         if rc != 0:
             raise RuntimeError(f"zrk_exchange_info failed ({rc})")
         return {"world": st.world, "rank": st.rank, "rccl_ranks_seen": st.comm_ranks, "pattern": "direct send/recv" if st.direct else "ncclAllGather",
-                "helper_threads": st.helper_threads, "collectives": st.collectives, "host_waits": st.host_waits, "host_wait_us": st.host_wait_us}
+                "helper_threads": st.helper_threads, "grouped_pairs": bool(st.grouped_pairs), "collectives": st.collectives, "host_waits": st.host_waits, "host_wait_us": st.host_wait_us}
 
     def events(self, slot):
         self.sync()
