@@ -506,6 +506,14 @@ def main():
             if hasattr(eng, "read_sweep_ticks"):
                 sweep_ticks[:] = eng.read_sweep_ticks(len(sweep_ms))
         stamp_us, stamp_ticks = eng.read_sweep_stamps() if stamping else (np.zeros(0, np.float32), np.zeros(0, np.int32))
+        # when the sampled launches ran, by the device's clock: with every launch of the call sampled (up to 64), the span of the
+        # call's sweeps and the idle time between them -- what is left of the region is the call's start and its drain
+        span_us = gaps_us = None
+        if stamping and hasattr(eng, "sweep_stamp_times") and len(stamp_us) and int(stamp_ticks.sum()) == steps:
+            sb, se = eng.sweep_stamp_times()
+            if len(sb) == len(stamp_us):
+                span_us = float(se[-1] - sb[0])
+                gaps_us = float(np.maximum(sb[1:] - se[:-1], 0.0).sum())
         live1 = eng.alive_count()
         eng.store.compact_status()           # outside the timing: a compaction that did not run to completion raises here
         if exchanging:
@@ -608,7 +616,10 @@ def main():
                 "setup": {"clock_spinup_ms": SPINUP_MS, "sweep_timing_stride": stride,
                           # of the timed region: until the one zrk_run_ticks call returned (everything issued, the side stream's
                           # work handed over), and the synchronisation behind it
-                          "call_returned_after_us": (t_issued - t0) * 1e6, "sync_us": (elapsed_rank0 - (t_issued - t0)) * 1e6},
+                          "call_returned_after_us": (t_issued - t0) * 1e6, "sync_us": (elapsed_rank0 - (t_issued - t0)) * 1e6,
+                          # by the launches' own stamps (all launches of the call sampled): first wave of the first sweep to last
+                          # wave of the last one, and the idle time between consecutive sweeps within that span
+                          "sweeps_span_us": span_us, "sweep_gaps_us": gaps_us},
             }
             if exchanging:
                 out["config"]["exchange"] = "rccl, C side" if state["c_side"] else f"torch.distributed {backend}"

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ZRK_ABI_VERSION 9
+#define ZRK_ABI_VERSION 10
 #define ZRK_MAX_RADARS 32           /* one bit per radar in the visibility mask */
 #define ZRK_BLOCK 256               /* table rows per sweep workgroup */
 
@@ -546,6 +546,10 @@ int zrk_last_run_ticks_per_launch(zrk_ctx *ctx);
  * samples written (<= cap), or an error.  No reference counterpart (measurement). */
 int zrk_sweep_stamps(zrk_ctx *ctx, int on);
 int zrk_read_sweep_stamps(zrk_ctx *ctx, float *sweep_us /* HOST out */, int32_t *ticks /* HOST out, may be NULL */, int cap, void *stream);
+/* ... and WHEN those launches ran: first wave in / last wave out of each sampled launch of the last zrk_read_sweep_stamps, in
+ * microseconds from the first one's first wave (the device's own clock): the span of a call's sweeps and the gaps between them,
+ * without a profiler (bench.py: setup.sweeps_span_us, setup.sweep_gaps_us).  Returns how many. */
+int zrk_last_sweep_stamp_times(zrk_ctx *ctx, double *begin_us /* HOST out */, double *end_us /* HOST out */, int cap);
 
 /* Numerics self-test hooks used by tests/: y[i] = op(a[i], b[i]) in device binary64.
  * op: 0 sqrt(a), 1 a/b, 2 atan2(a,b), 3 asin(a), 4 fma-chain norm of (a,b,0). */

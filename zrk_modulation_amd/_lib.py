@@ -15,7 +15,7 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 # (ZRK_HOT_LIB: another build of the same ABI, for A/B runs on one box)
 LIB_PATH = Path(os.environ["ZRK_HOT_LIB"]) if os.environ.get("ZRK_HOT_LIB") else CSRC / "libzrk_hot.so"
 
-ZRK_ABI_VERSION = 9
+ZRK_ABI_VERSION = 10
 EXCHANGE_SLOTS = 8          # ZRK_EXCHANGE_SLOTS
 ZRK_MAX_RADARS = 32
 ZRK_BLOCK = 256
@@ -245,6 +245,7 @@ _PROTOTYPES = {
     "zrk_last_run_ticks_per_launch": (C.c_int, [C.c_void_p]),
     "zrk_sweep_stamps": (C.c_int, [C.c_void_p, C.c_int]),
     "zrk_read_sweep_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
+    "zrk_last_sweep_stamp_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

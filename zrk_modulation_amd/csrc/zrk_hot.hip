@@ -3581,6 +3581,14 @@ struct Side {
     hipEvent_t last_sweep = nullptr;   // recorded behind the last sweep of a call (SideItem::wait_event)
     hipEvent_t tail_ev = nullptr;      // recorded behind the side stream's last launch when an item goes to the compute stream (SideItem::on_compute)
     bool side_busy = false;            // the side stream has launches the compute stream has not taken in (the thread's; the caller's between items)
+    // on_compute == 2 (a pair's ONE compaction launch as the call's last): that launch has control words and records of its
+    // own (tail_ws) and nothing of the caller's is written by the launch before it, so it waits for nobody -- the event above
+    // cost 11 us between the last sweep and it.  The side stream's launch before it then stands alone: an event behind it
+    // (tail_ev, asked only by the host, when its mask buffers come up for reuse), and the tail itself is known by number
+    void *tail_ws = nullptr;
+    uint64_t tail_item = 0;            // the last call's last item, issued on tail_stream
+    hipStream_t tail_stream = nullptr;
+    int last_side_slot[2] = {-1, -1};  // ring slots of the side stream's last launch (the thread's)
     uint32_t *bar = nullptr;           // DEVICE: the barrier of a pair launch's missile workgroups (arrivals, gave-up word)
     uint32_t bar_epoch = 0;            // arrivals asked for so far
     // k_compact_pair: per ring slot the list of rows a pair's first tick removed (MissileArgs::rm), and where the FIRST tick's
@@ -3671,8 +3679,10 @@ struct zrk_ctx {
     int stamp_used = 0;
     std::vector<int> stamp_ticks;
     std::vector<int64_t> stamp_waves;
+    std::vector<unsigned long long> stamp_host;   // what the last zrk_read_sweep_stamps read: (first wave in, last wave out) per sampled launch
     bool tail_by_event = false;        // ZRK_TAIL_EVENT=1: the last compaction of a call is released by an event recorded behind the last sweep, not by
                                        // a launch that raises the host word (medians equal, 24.6 / 24.7 us per tick in 20-step runs; the event has the worse tail)
+    bool tail_free = true;             // ... without waiting for the side stream's launch before it (Side::tail_ws; ZRK_TAIL_FREE=0: an event)
     bool tail_on_compute = true;       // the last compaction of a call goes to the compute stream, behind the last sweep (SideItem::on_compute);
                                        // ZRK_TAIL_COMPUTE=0: to the side stream like the others, released as above.  Calls with an exchange: always the latter
 };
@@ -3761,6 +3771,7 @@ ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
     { const char *v = std::getenv("ZRK_OVERLAP_MIN_ROWS"); c->overlap_min_rows = v ? std::atoll(v) : 50000; }
     { const char *v = std::getenv("ZRK_GATHER_RECORDS"); c->grec_enabled = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_TAIL_EVENT"); c->tail_by_event = v && v[0] == '1'; }
+    { const char *v = std::getenv("ZRK_TAIL_FREE"); c->tail_free = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_TAIL_COMPUTE"); c->tail_on_compute = !(v && v[0] == '0') && !c->tail_by_event; }
     { const char *v = std::getenv("ZRK_PAIR"); c->pair_enabled = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_PAIR_COMPACT"); c->pair_compact = !(v && v[0] == '0'); }
@@ -4122,8 +4133,20 @@ ZRK_API int zrk_compact_status(zrk_ctx *ctx, void *workspace, void *stream)
     if (!ctx || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_compact_status: null argument");
     int32_t ctl[4] = {0, 0, 0, 0};
     hipStream_t s = (hipStream_t)stream;
-    if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(ctl, workspace, sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess)
+    // (the side stream's last launch of a call is not always taken in by the caller's stream: Side::tail_ws)
+    if (hipStreamSynchronize(s) != hipSuccess || (ctx->side && hipStreamSynchronize(ctx->side->stream) != hipSuccess) ||
+        hipMemcpy(ctl, workspace, sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess)
         return fail(ctx, ZRK_E_HIP, "zrk_compact_status: copy failed");
+    if (ctx->side && ctx->side->tail_ws) {
+        int32_t tctl[4] = {0, 0, 0, 0};
+        if (hipMemcpy(tctl, ctx->side->tail_ws, sizeof(tctl), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(ctx, ZRK_E_HIP, "zrk_compact_status: copy failed");
+        if (tctl[2] != 0 || tctl[0] != 0 || tctl[1] != 0) {
+            (void)hipMemset(ctx->side->tail_ws, 0, kFusedCtlInts * sizeof(int32_t));
+            return fail(ctx, ZRK_E_STATE, tctl[2] == 2 ? "zrk_compact: a workgroup of a call's last compaction gave up waiting for its predecessors"
+                                                        : "zrk_compact: the control words of a call's last compaction were not as this library left them");
+        }
+    }
     if (ctx->side && ctx->side->rc.load() != 0)    // overlap mode: the side stream's thread gave up (its lists are not valid)
         return fail(ctx, ZRK_E_STATE, ctx->side->err);
     if (ctx->side && ctx->side->bar) {
@@ -4939,7 +4962,15 @@ int side_issue(Side *sd, const SideItem &it)
     // ahead of their input -- deadlocks the device as soon as anything else on it needs whole compute units in dispatch
     // order (e.g. another engine's single-launch compaction), and a one-lane wait kernel in front of it costs the side
     // stream 5 us a tick.  This thread has nothing else to do.
-    if (it.on_compute) {
+    if (it.on_compute == 2) {
+        // in order behind the call's last sweep and independent of what the side stream still runs: an event behind that, for
+        // the host (side_wait)
+        if (sd->side_busy && sd->last_side_slot[0] >= 0) {
+            if (hipEventRecord(sd->tail_ev, sd->stream) != hipSuccess) { sd->err = "side stream: hipEventRecord failed"; return ZRK_E_HIP; }
+            for (int q = 0; q < 2; ++q)
+                if (sd->last_side_slot[q] >= 0) { sd->done_of[sd->last_side_slot[q]] = sd->tail_ev; sd->posted[sd->last_side_slot[q]] = true; }
+        }
+    } else if (it.on_compute) {
         // in order behind the call's last sweep; what the side stream still runs (the compaction before this one) comes first
         if (sd->side_busy) {
             if (hipEventRecord(sd->tail_ev, sd->stream) != hipSuccess || hipStreamWaitEvent(it.stream, sd->tail_ev, 0) != hipSuccess) {
@@ -4957,7 +4988,8 @@ int side_issue(Side *sd, const SideItem &it)
     }
     if (!it.wait_event && !it.on_compute && (int32_t)(*sd->hflag - it.flag_value) < 0) { sd->err = "side stream: stopped"; return ZRK_E_STATE; }
     g_trace.mark(it.on_compute ? "side: the call's last item, to the compute stream" : "side: flag seen");
-    const DoneWord dw{sd->hdone_dev, it.done_value - 1u};
+    // (a launch that waited for nobody cannot say that the one before it is over)
+    const DoneWord dw{it.on_compute == 2 ? nullptr : sd->hdone_dev, it.done_value - 1u};
     if (it.pair) {
         const dim3 grid(it.C.nb + (it.M.m > 0 ? 2 : 0));
         if (it.pair_threads == 256)
@@ -4981,7 +5013,10 @@ int side_issue(Side *sd, const SideItem &it)
         sd->posted[it.done_slot] = false;
         if (it.pair) sd->posted[it.done_slot2] = false;
     }
-    if (!it.on_compute) { sd->last_launch = std::chrono::steady_clock::now(); sd->side_busy = true; }
+    if (!it.on_compute) {
+        sd->last_launch = std::chrono::steady_clock::now(); sd->side_busy = true;
+        sd->last_side_slot[0] = it.done_slot; sd->last_side_slot[1] = it.pair ? it.done_slot2 : -1;
+    }
     g_trace.mark("side: compaction issued");
     if (it.post_x && exchange_post_behind_flag(it.post_x, it.post_slot, it.post_send, it.post_recv, it.post_words, it.raise_value,
                                                 it.post2_send ? it.post2_slot : -1, it.post2_send, it.post2_recv) != 0) {
@@ -5001,6 +5036,7 @@ void side_main(Side *sd, int device)
             const SideItem it = sd->ring[t % Side::kRing];
             if (sd->rc.load() == 0) { const int rc = side_issue(sd, it); if (rc != 0) sd->rc.store(rc); }
             sd->tail.store(t + 1, std::memory_order_release);
+
             idle_since = std::chrono::steady_clock::now();
             continue;
         }
@@ -5107,6 +5143,7 @@ int side_wait(zrk_ctx *ctx, Side *sd, int slot, hipStream_t compute)
     // on it now is behind that -- nothing to ask the runtime, whose first answer after a pause takes 10 us)
     if (sd->item_no[slot] == 0) return 0;                    // (never used, or started afresh after a failure)
     if (sd->item_no[slot] <= sd->joined_upto && compute == sd->joined_stream) return 0;
+    if (sd->item_no[slot] == sd->tail_item && compute == sd->tail_stream) return 0;     // (a call's last item, launched on this very stream)
     // the word in which the NEXT compaction of the side stream says that this one is over (the next one is always in the
     // thread's hands by now -- the ring is several items deep -- and starts without this thread's help)
     const uint32_t want = (uint32_t)sd->item_no[slot];
@@ -5136,6 +5173,7 @@ void side_destroy(Side *sd)
     for (int k = 0; k <= Side::kMasks; ++k) if (sd->done[k]) (void)hipEventDestroy(sd->done[k]);
     if (sd->last_sweep) (void)hipEventDestroy(sd->last_sweep);
     if (sd->tail_ev) (void)hipEventDestroy(sd->tail_ev);
+    if (sd->tail_ws) (void)hipFree(sd->tail_ws);
     for (int k = 0; k < Side::kMasks; ++k) if (sd->masks[k]) (void)hipFree(sd->masks[k]);
     for (int k = 0; k < Side::kMasks; ++k) if (sd->codes[k]) (void)hipFree(sd->codes[k]);
     if (sd->pend) (void)hipFree(sd->pend);
@@ -5299,6 +5337,15 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             sd->mask_rows = e->capacity; sd->masks_dirty = false;
             for (int k = 0; k <= Side::kMasks; ++k) { sd->posted[k] = false; sd->item_no[k] = 0; }
         }
+        if (!sd->tail_ws && ctx->tail_on_compute && ctx->tail_free && !ens && !xio) {
+            // (the control words and records of a call's last compaction, Side::tail_ws: with the first overlapped call, not
+            // in front of the first launch that needs them)
+            if (hipMalloc(&sd->tail_ws, (size_t)kFusedBytes) != hipSuccess || hipMemsetAsync(sd->tail_ws, 0, (size_t)kFusedBytes, s) != hipSuccess) {
+                (void)hipGetLastError();
+                if (sd->tail_ws) (void)hipFree(sd->tail_ws);
+                sd->tail_ws = nullptr;               // (then: the event)
+            }
+        }
         if (sd->pend_rows < e->capacity) {
             if (sd->pend) (void)hipFree(sd->pend);
             sd->pend = nullptr; sd->pend_rows = 0;
@@ -5346,6 +5393,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     hipStream_t side_stream = sd ? sd->stream : nullptr;
     int side_last = -1;
     bool tail_on_s = false;                              // the call's last compaction went to the compute stream (SideItem::on_compute)
+    bool tail_alone = false;                             // ... and waited for nobody (on_compute == 2)
     zrk_exchange *fx = (xio && xio->x->flag) ? xio->x : nullptr;
     if (fx && fx->seq > 0x7FFF0000u) {                   // far from wrapping: the comparison is on 32 bits
         if (hipStreamSynchronize(fx->cstream) != hipSuccess) return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
@@ -5546,6 +5594,10 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         radar_block_ahead(ctx, radars_b, R, st->flags, 1);
         const bool last_launch = k + nt == K;
         const bool tail_here = last_launch && !xio && ctx->tail_on_compute;       // (SideItem::on_compute)
+        // ... and independent of the side stream's launch before it (Side::tail_ws): a pair's one compaction launch, the second
+        // tick's lists of every launch but the call's last in the context's own buffers like the first tick's
+        const bool spare_outputs = pc && !xio && ctx->tail_on_compute && ctx->tail_free && sd->tail_ws;
+        const bool tail_free = tail_here && spare_outputs;
         if (last_launch && ctx->tail_by_event && hipEventRecord(sd->last_sweep, s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipEventRecord");
         // the side stream's work, released when the NEXT launch starts: both ticks' compactions in one launch ...
         if (pc && rc == 0) {
@@ -5561,8 +5613,11 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                 rc = launch_compact(ctx, vis_t[0], st->n, R, st->base_index, workspace, det_idx ? sd->scratch_det : nullptr, det_stride,
                                     det_idx ? sd->scratch_cnt : nullptr, xio ? list_t[0] : (packed ? sd->scratch_packed : nullptr), list_words,
                                     st->gid0, stream, no_missiles(), vis_t[0], (st->flags & ZRK_F_UNION_BITS) != 0, nullptr, nullptr, &a, items);
+            // (the second tick's lists: the caller's -- of the call's last launch only, where its last compaction stands alone)
+            const bool spare = spare_outputs && !last_launch;
             if (rc == 0)
-                rc = launch_compact(ctx, vis_t[1], st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, list_t[1], list_words,
+                rc = launch_compact(ctx, vis_t[1], st->n, R, st->base_index, workspace, (det_idx && spare) ? sd->scratch_det : det_idx, det_stride,
+                                    (det_idx && spare) ? sd->scratch_cnt : det_cnt, (spare && packed) ? sd->scratch_packed : list_t[1], list_words,
                                     st->gid0, stream, no_missiles(), (slot_t[1] < Side::kMasks) ? vis_t[1] : nullptr,
                                     (st->flags & ZRK_F_UNION_BITS) != 0, nullptr, nullptr, &b, items);
             for (int j = 0; j < 2 && rc == 0 && ev_words && !fused; ++j)     // (no missiles: an empty event list behind each list)
@@ -5577,7 +5632,11 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                 a.C.lanes = lanes;
                 a.C.group = a.C.nb > 512 ? 32 : (a.C.nb > 32 ? 16 : 0);   // (half as many records per batch of loads as the single compaction)
                 if (ctx->env_group >= 0) a.C.group = ctx->env_group;
-                a.stream = tail_here ? s : side_stream; a.on_compute = tail_here ? 1 : 0;
+                a.stream = tail_here ? s : side_stream; a.on_compute = tail_here ? (tail_free ? 2 : 1) : 0;
+                if (tail_free) {                           // control words and records of its own
+                    const Workspace tw = carve(sd->tail_ws, 0, 0);
+                    a.C.ctl = a.C2.ctl = tw.ctl; a.C.agg = a.C2.agg = tw.agg;
+                }
                 a.flag_value = ++sd->seq; a.done_slot = slot_t[0]; a.done_slot2 = slot_t[1];
                 a.M = M; a.M.apply = 0; a.M.clear_vis = nullptr;
                 if (fused) {                               // the first tick's ordered events: a list of the context's own
@@ -5585,6 +5644,10 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                     a.M.ev_count = sd->scratch_ev + 2 * sd->scratch_ev_rows;
                 }
                 a.M2 = M; a.M2.apply = 0; a.M2.ev_code = M.ev_code2; a.M2.clear_vis = nullptr;
+                if (fused && spare) {                      // (its ordered events as well)
+                    a.M2.ev_missile = sd->scratch_ev; a.M2.ev_target = sd->scratch_ev + sd->scratch_ev_rows;
+                    a.M2.ev_count = sd->scratch_ev + 2 * sd->scratch_ev_rows;
+                }
                 if (fused && ev_words) { a.M.ev_wire = list_t[0] + list_words; a.M2.ev_wire = list_t[1] + list_words; }
                 a.rm = fused ? sd->rm[slot_t[1]] : nullptr; a.rm_cap = sd->rm_cap;
                 if (last_launch && ctx->tail_by_event) a.wait_event = sd->last_sweep;
@@ -5618,6 +5681,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                 }
                 side_last = slot_t[1];
                 tail_on_s = tail_here;
+                tail_alone = tail_free;
                 if (slot_t[1] == Side::kMasks) ctx->ring_clean[st->vis_cur] = false;
             }
         }
@@ -5879,6 +5943,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (rc == 0 && side_last >= 0 && sd->posted[side_last]) {
             // (a last item on the compute stream is in it already; the event behind it is for a later call on ANOTHER stream)
             if (!tail_on_s && hipStreamWaitEvent(s, sd->done_of[side_last], 0) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipStreamWaitEvent");
+            else if (tail_alone) { sd->tail_item = sd->head.load(); sd->tail_stream = s; }     // (the side stream's last launch stands alone: Side::tail_ws)
             else { sd->joined_upto = sd->head.load(); sd->joined_stream = s; if (!tail_on_s) sd->side_busy = false; }
         }
     }
@@ -5978,6 +6043,18 @@ ZRK_API int zrk_read_sweep_stamps(zrk_ctx *ctx, float *sweep_us, int32_t *ticks,
     for (int k = 0; k < n; ++k) {
         sweep_us[k] = (float)((double)(host[2 * k + 1] - host[2 * k]) * 0.01);       // 100 MHz: 10 ns a count
         if (ticks) ticks[k] = ctx->stamp_ticks[k];
+    }
+    ctx->stamp_host = host;
+    return n;
+}
+
+ZRK_API int zrk_last_sweep_stamp_times(zrk_ctx *ctx, double *begin_us, double *end_us, int cap)
+{
+    if (!ctx || !begin_us || !end_us || cap < 0) return fail(ctx, ZRK_E_INVALID, "zrk_last_sweep_stamp_times: null argument");
+    const int n = std::min(cap, (int)(ctx->stamp_host.size() / 2));
+    for (int k = 0; k < n; ++k) {
+        begin_us[k] = (double)(long long)(ctx->stamp_host[2 * k] - ctx->stamp_host[0]) * 0.01;
+        end_us[k] = (double)(long long)(ctx->stamp_host[2 * k + 1] - ctx->stamp_host[0]) * 0.01;
     }
     return n;
 }

@@ -425,6 +425,17 @@ class HotPathEngine:
             st.ctx.check(k, "zrk_read_sweep_stamps")
         return us[:k], ticks[:k]
 
+    def sweep_stamp_times(self, cap=64):
+        """(first wave in [us], last wave out [us]) of the launches the last read_sweep_stamps() sampled, from the first one's
+        first wave on, by the device's clock: the span of a call's sweeps and the gaps between them."""
+        C = self._C
+        b, e = np.zeros(int(cap), np.float64), np.zeros(int(cap), np.float64)
+        st = self.store
+        k = st.lib.zrk_last_sweep_stamp_times(st.ctx.handle, b.ctypes.data_as(C.POINTER(C.c_double)), e.ctypes.data_as(C.POINTER(C.c_double)), int(cap))
+        if k < 0:
+            st.ctx.check(k, "zrk_last_sweep_stamp_times")
+        return b[:k], e[:k]
+
     def read_sweep_ticks(self, n):
         """Ticks swept by the launch behind each timing sample of the last run (1, or 2 for a pair launch)."""
         C = self._C
