@@ -374,7 +374,10 @@ typedef struct {
  * `stream` takes the side stream in before the call returns, so the outputs are the caller's as before.  The call's LAST
  * compaction (no exchange) is launched on `stream` itself, in order behind the last sweep -- by the context's thread: a
  * caller must not be capturing `stream` into a graph, and must order its own streams if consecutive calls come on
- * different ones (ZRK_TAIL_COMPUTE=0: on the side stream like the others, released by a launch behind the last sweep).  Differences
+ * different ones (ZRK_TAIL_COMPUTE=0: on the side stream like the others, released by a launch behind the last sweep;
+ * ZRK_TAIL_FREE=0: behind an event that takes the side stream's compaction before it in -- by default a two-tick call's last
+ * compaction has control words of its own and waits for nobody, and the lists of every tick but the call's last go to
+ * buffers of the context).  Differences
  * a caller can see: the masks of all ticks but the LAST of such a call live in buffers of the context
  * (ents->vis_mask / vis_mask_alt hold the last tick's, as st->vis_cur says), likewise mis->ev_code; the dispatch order
  * of a sweep's workgroups is never the same twice (it does not enter any result).
