@@ -371,7 +371,8 @@ typedef struct {
  * compute stream says, through a word of pinned host memory, that sweep t + 1 has started), and `stream` carries one
  * launch per tick: removals decided by a tick's missile phase are marks that the rows' own threads carry out in the
  * next sweep (tombstones again when the call returns), radar records travel in the sweep's arguments.  Same results;
- * `stream` takes the side stream in before the call returns, so the outputs are the caller's as before.  The call's LAST
+ * everything the caller reads is written on `stream` or taken in by it before the call returns, so the outputs are the
+ * caller's as before (what the side stream may still be running then touches buffers of the context only).  The call's LAST
  * compaction (no exchange) is launched on `stream` itself, in order behind the last sweep -- by the context's thread: a
  * caller must not be capturing `stream` into a graph, and must order its own streams if consecutive calls come on
  * different ones (ZRK_TAIL_COMPUTE=0: on the side stream like the others, released by a launch behind the last sweep;
