@@ -3489,15 +3489,34 @@ int usable_host_cores()
 }
 
 // Spins (pause) until ok() holds; false when the limit ran out first.  The clock is read every 4096 looks.
+// ZRK_STALL_US=n (diagnostics): a host-side wait of the library, or a launch call of the loop, that takes longer than n
+// microseconds is reported on stderr with the source line it stands in.
+inline int stall_us()
+{
+    static const int us = [] { const char *v = std::getenv("ZRK_STALL_US"); return v ? std::atoi(v) : 0; }();
+    return us;
+}
+inline void stall_report(std::chrono::steady_clock::time_point t0, int line, const char *what)
+{
+    const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (us > stall_us()) std::fprintf(stderr, "[zrk stall] %lld us in %s (zrk_hot.hip:%d)\n", (long long)us, what, line);
+}
+
 template <class Pred>
-bool spin_until(Pred ok, std::chrono::milliseconds limit = host_wait_limit())
+bool spin_until(Pred ok, std::chrono::milliseconds limit = host_wait_limit(), int line = __builtin_LINE())
 {
     if (ok()) return true;
     const auto t0 = std::chrono::steady_clock::now();
+    bool yielding = false;
     for (unsigned spins = 1;; ++spins) {
-        __builtin_ia32_pause();
-        if (ok()) return true;
-        if ((spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > limit) return false;
+        // (a wait that has lasted 50 us may be for a thread that wants this very core: give it up between looks)
+        if (yielding) sched_yield(); else __builtin_ia32_pause();
+        if (ok()) { if (stall_us() > 0) stall_report(t0, line, "a host-side wait"); return true; }
+        if ((spins & (yielding ? 0x3Fu : 0x3FFu)) == 0) {
+            const auto waited = std::chrono::steady_clock::now() - t0;
+            if (waited > limit) return false;
+            if (waited > std::chrono::microseconds(50)) yielding = true;
+        }
     }
 }
 }  // namespace
@@ -3589,6 +3608,7 @@ struct Side {
     uint64_t tail_item = 0;            // the last call's last item, issued on tail_stream
     hipStream_t tail_stream = nullptr;
     int last_side_slot[2] = {-1, -1};  // ring slots of the side stream's last launch (the thread's)
+    bool tail_ev_live = false;         // tail_ev stands behind the side stream's last launch of the running call (the thread's)
     uint32_t *bar = nullptr;           // DEVICE: the barrier of a pair launch's missile workgroups (arrivals, gave-up word)
     uint32_t bar_epoch = 0;            // arrivals asked for so far
     // k_compact_pair: per ring slot the list of rows a pair's first tick removed (MissileArgs::rm), and where the FIRST tick's
@@ -4621,6 +4641,17 @@ std::chrono::milliseconds helper_idle()
     static const int ms = [] { const char *v = std::getenv("ZRK_HELPER_IDLE_MS"); return v ? std::max(0, std::atoi(v)) : 1; }();
     return std::chrono::milliseconds(ms);
 }
+// ... and between the two a phase in which they stay runnable but give their core to whoever wants it (sched_yield between
+// looks): ZRK_HELPER_YIELD_MS, default 250.  A thread that sleeps on its condition variable is woken at the next call's entry,
+// and three times in some 150 runs of the driver's 20-tick command that took 3-12 ms instead of 50 us (the scheduler's
+// slice: the calling thread, which spins while it waits for this one, had the core the wakee was put on): a 20-tick call
+// of 0.45 ms then took 3-13.  Calls less than a quarter of a second apart -- bench.py's warm-up and timed call, any loop of
+// calls -- now find the threads awake; spin_until yields as well once a wait has lasted 50 us.
+std::chrono::milliseconds helper_yield()
+{
+    static const int ms = [] { const char *v = std::getenv("ZRK_HELPER_YIELD_MS"); return v ? std::max(0, std::atoi(v)) : 250; }();
+    return std::chrono::milliseconds(ms);
+}
 
 void exchange_poster_main(zrk_exchange *x)
 {
@@ -4639,9 +4670,10 @@ void exchange_poster_main(zrk_exchange *x)
             continue;
         }
         if (x->stop.load()) return;
-        if (std::chrono::steady_clock::now() - idle_since < helper_idle()) {
-            __builtin_ia32_pause();
-            continue;
+        {
+            const auto idle = std::chrono::steady_clock::now() - idle_since;
+            if (idle < helper_idle()) { __builtin_ia32_pause(); continue; }
+            if (idle < helper_idle() + helper_yield()) { sched_yield(); continue; }
         }
         std::unique_lock<std::mutex> lk(x->mu);         // nothing for a while: sleep (the bounded wait covers a lost wake-up)
         x->asleep.store(true);
@@ -4965,10 +4997,12 @@ int side_issue(Side *sd, const SideItem &it)
     if (it.on_compute == 2) {
         // in order behind the call's last sweep and independent of what the side stream still runs: an event behind that, for
         // the host (side_wait)
+        sd->tail_ev_live = false;
         if (sd->side_busy && sd->last_side_slot[0] >= 0) {
             if (hipEventRecord(sd->tail_ev, sd->stream) != hipSuccess) { sd->err = "side stream: hipEventRecord failed"; return ZRK_E_HIP; }
             for (int q = 0; q < 2; ++q)
                 if (sd->last_side_slot[q] >= 0) { sd->done_of[sd->last_side_slot[q]] = sd->tail_ev; sd->posted[sd->last_side_slot[q]] = true; }
+            sd->tail_ev_live = true;
         }
     } else if (it.on_compute) {
         // in order behind the call's last sweep; what the side stream still runs (the compaction before this one) comes first
@@ -4988,6 +5022,7 @@ int side_issue(Side *sd, const SideItem &it)
     }
     if (!it.wait_event && !it.on_compute && (int32_t)(*sd->hflag - it.flag_value) < 0) { sd->err = "side stream: stopped"; return ZRK_E_STATE; }
     g_trace.mark(it.on_compute ? "side: the call's last item, to the compute stream" : "side: flag seen");
+    const auto t_issue = std::chrono::steady_clock::now();
     // (a launch that waited for nobody cannot say that the one before it is over)
     const DoneWord dw{it.on_compute == 2 ? nullptr : sd->hdone_dev, it.done_value - 1u};
     if (it.pair) {
@@ -5013,10 +5048,18 @@ int side_issue(Side *sd, const SideItem &it)
         sd->posted[it.done_slot] = false;
         if (it.pair) sd->posted[it.done_slot2] = false;
     }
+    // The side stream's launch that a free tail did not wait for is taken in by the compute stream BEHIND the tail (it has been
+    // over for a while when that packet is reached: it costs the next launch nothing), so that everything of the call -- also
+    // what only read the caller's tables or used the caller's workspace -- is the caller's stream's when the call returns.
+    // (From this thread, which has nothing else to do: the call takes the calling thread tens of microseconds.)
+    if (it.on_compute == 2 && sd->tail_ev_live && hipStreamWaitEvent(it.stream, sd->tail_ev, 0) != hipSuccess) {
+        sd->err = "side stream: hipStreamWaitEvent failed"; return ZRK_E_HIP;
+    }
     if (!it.on_compute) {
         sd->last_launch = std::chrono::steady_clock::now(); sd->side_busy = true;
         sd->last_side_slot[0] = it.done_slot; sd->last_side_slot[1] = it.pair ? it.done_slot2 : -1;
     }
+    if (stall_us() > 0) stall_report(t_issue, __LINE__, "the side stream's thread issuing an item");
     g_trace.mark("side: compaction issued");
     if (it.post_x && exchange_post_behind_flag(it.post_x, it.post_slot, it.post_send, it.post_recv, it.post_words, it.raise_value,
                                                 it.post2_send ? it.post2_slot : -1, it.post2_send, it.post2_recv) != 0) {
@@ -5034,6 +5077,7 @@ void side_main(Side *sd, int device)
         const uint64_t t = sd->tail.load(std::memory_order_relaxed);
         if (sd->head.load(std::memory_order_acquire) != t) {
             const SideItem it = sd->ring[t % Side::kRing];
+            g_trace.mark("side: item taken");
             if (sd->rc.load() == 0) { const int rc = side_issue(sd, it); if (rc != 0) sd->rc.store(rc); }
             sd->tail.store(t + 1, std::memory_order_release);
 
@@ -5041,13 +5085,18 @@ void side_main(Side *sd, int device)
             continue;
         }
         if (sd->stop.load()) return;
-        if (std::chrono::steady_clock::now() - idle_since < helper_idle()) { __builtin_ia32_pause(); continue; }
+        {
+            const auto idle = std::chrono::steady_clock::now() - idle_since;
+            if (idle < helper_idle()) { __builtin_ia32_pause(); continue; }
+            if (idle < helper_idle() + helper_yield()) { sched_yield(); continue; }
+        }
         std::unique_lock<std::mutex> lk(sd->mu);
         sd->asleep.store(true);
         bool woken = false;
         if (sd->head.load(std::memory_order_acquire) == sd->tail.load() && !sd->stop.load())
             woken = sd->cv.wait_for(lk, std::chrono::milliseconds(20)) == std::cv_status::no_timeout;
         sd->asleep.store(false);
+        if (woken) g_trace.mark("side: woken");
         if (woken) idle_since = std::chrono::steady_clock::now();      // somebody is about to hand over work: stay up
     }
 }
@@ -5319,7 +5368,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             sd->rc.store(0);
         }
         // (its thread sleeps after a millisecond without work: wake it now, not at the first item two launches from here)
-        if (sd->asleep.load()) { std::lock_guard<std::mutex> lk(sd->mu); sd->cv.notify_one(); }
+        if (sd->asleep.load()) { std::lock_guard<std::mutex> lk(sd->mu); sd->cv.notify_one(); g_trace.mark("run_ticks: side thread notified"); }
         if (xio && xio->x->asleep.load()) { std::lock_guard<std::mutex> lk(xio->x->mu); xio->x->cv.notify_one(); }
         if (sd->mask_rows < e->capacity || sd->masks_dirty) {
             if (int rc0 = side_drain(ctx, sd, sd->head.load())) return rc0;
@@ -5570,6 +5619,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         PairLaunch pl{st->time_ms + st->dt_ms, radars_b, vis_t[1], mark_b};
         const bool on_dispatch = prof_idx >= 0;
         if (k == 0) g_trace.mark("run_ticks: first launch prepared");
+        const auto t_launch = std::chrono::steady_clock::now();
         const int rc_sweep =
             launch_sweep(ctx, e, st->n, cur_a, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse_t[0] | (nt == 2 ? sparse_t[1] : 0u),
                          st->seed, st->tick, st->gid0, workspace, stream, M, vis_t[0], ordering ? w.order[oph ^ 1] : nullptr,
@@ -5579,6 +5629,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                          w.order_ctr + kOrderCtrSet * (oph ^ 1), w.order_ctr + kOrderCtrSet * oph, sd->pend, mark_a, nt == 2 ? &pl : nullptr,
                          next_stamps(nt, M.m));
         rc = rc_sweep;
+        if (stall_us() > 0) stall_report(t_launch, __LINE__, "launch_sweep");
         g_trace.mark(nt == 2 ? "run_ticks: pair launched" : "run_ticks: sweep launched");
         if (rc_sweep != 0) { st->vis_cur = vis_cur_before; break; }
         if (nt == 2 && mb > 0) sd->bar_epoch += (uint32_t)mb;
@@ -5943,7 +5994,11 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (rc == 0 && side_last >= 0 && sd->posted[side_last]) {
             // (a last item on the compute stream is in it already; the event behind it is for a later call on ANOTHER stream)
             if (!tail_on_s && hipStreamWaitEvent(s, sd->done_of[side_last], 0) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipStreamWaitEvent");
-            else if (tail_alone) { sd->tail_item = sd->head.load(); sd->tail_stream = s; }     // (the side stream's last launch stands alone: Side::tail_ws)
+            else if (tail_alone) {
+                // (the side stream's last launch stood alone, and the thread has put the wait for it BEHIND the call's last
+                // compaction on the compute stream: see side_issue)
+                sd->tail_item = sd->head.load(); sd->tail_stream = s; sd->joined_upto = sd->head.load(); sd->joined_stream = s; sd->side_busy = false;
+            }
             else { sd->joined_upto = sd->head.load(); sd->joined_stream = s; if (!tail_on_s) sd->side_busy = false; }
         }
     }
