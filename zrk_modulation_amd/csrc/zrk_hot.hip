@@ -752,6 +752,7 @@ __device__ __forceinline__ void sweep_rows(uint64_t tick, int64_t gid0, const ch
     const uint32_t planes = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.plane);
     NoiseState ns = NoiseState{0u, 0u, 0u, 0u};
     bool seeded = !LAZY;
+    const unsigned long long live_m = __ballot(live);
     mask = 0u;
     if (PHILOX && !LAZY && cands) ns = noise_init(seed, tick, (uint64_t)(gid0 + li));
 #ifdef ZRK_PROBE_BUILD
@@ -801,15 +802,19 @@ __device__ __forceinline__ void sweep_rows(uint64_t tick, int64_t gid0, const ch
         const double dx = x - rpx, dy = y - rpy, dz = z - rpz;
         const float fx = (float)dx, fy = (float)dy, fz = (float)dz;
         const float d2f = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
-        const bool in_range = live & (d2f <= d2f_out);
+        const bool ranged = d2f <= d2f_out;
+        const bool in_range = live & ranged;
         // float32 range gate.  With rows stored in spatial order the lanes of a wave mostly agree,
         // so a wave none of whose lanes is in range (or, below, anywhere near the azimuth wedge)
-        // leaves the radar here instead of paying for the rest of the classification.
-        if (!__ballot(in_range)) continue;
+        // leaves the radar here instead of paying for the rest of the classification.  (The votes as masks of the
+        // comparisons themselves, joined by the scalar unit: a vote on a compound predicate costs two vector instructions
+        // to make the predicate a value again.)
+        const unsigned long long range_m = __ballot(ranged) & live_m;
+        if (!range_m) continue;
         const float cl = __builtin_fmaf(elx, fy, -(ely * fx));               // az_sgn * cross(e_lo, p)
         const float ch = __builtin_fmaf(fx, ehy, -(fy * ehx));               // az_sgn * cross(p, e_hi)
         const float m_az = az_sgn * fminf(cl, ch);                           // > 0 inside the azimuth sector [m]
-        if (!__ballot(in_range & !(m_az < -az_guard))) continue;             // every lane certainly outside the wedge
+        if (!(__ballot(!(m_az < -az_guard)) & range_m)) continue;            // every lane certainly outside the wedge
 #ifdef ZRK_PROBE_BUILD
         ++probe_deep;
 #endif
