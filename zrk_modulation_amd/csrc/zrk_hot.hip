@@ -1041,6 +1041,13 @@ __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) voi
         const ConstWordsK kw = (ConstWordsK)(uint64_t)kernarg;
 #pragma unroll
         for (int k = 0; k < kSweepHeadBytes / 4; ++k) hw[k] = kw[k];
+        // (all forty words resident at this point: left to itself the compiler asks for them in three rounds, by first use)
+        static_assert(kSweepHeadBytes / 4 == 40, "the two statements below name every word of the head");
+        asm volatile("" ::"s"(hw[0]), "s"(hw[1]), "s"(hw[2]), "s"(hw[3]), "s"(hw[4]), "s"(hw[5]), "s"(hw[6]), "s"(hw[7]), "s"(hw[8]), "s"(hw[9]),
+                     "s"(hw[10]), "s"(hw[11]), "s"(hw[12]), "s"(hw[13]), "s"(hw[14]), "s"(hw[15]), "s"(hw[16]), "s"(hw[17]), "s"(hw[18]), "s"(hw[19]),
+                     "s"(hw[20]), "s"(hw[21]), "s"(hw[22]), "s"(hw[23]), "s"(hw[24]), "s"(hw[25]), "s"(hw[26]), "s"(hw[27]), "s"(hw[28]), "s"(hw[29]));
+        asm volatile("" ::"s"(hw[30]), "s"(hw[31]), "s"(hw[32]), "s"(hw[33]), "s"(hw[34]), "s"(hw[35]), "s"(hw[36]), "s"(hw[37]), "s"(hw[38]), "s"(hw[39]),
+                     "s"(hw[0]), "s"(hw[10]), "s"(hw[20]));
     }
     SweepHead H;
     __builtin_memcpy(&H, hw, sizeof(H));
