@@ -396,8 +396,10 @@ typedef struct {
  * ticks per call; ZRK_OVERLAP_MIN_ROWS=n from n rows; ZRK_GATHER_RECORDS=0 the missile phase reads its targets from the
  * columns instead of the 64-byte records the loop keeps per row (64 B x capacity of device memory, the context's);
  * ZRK_SWEEP_ORDER=0 sweep in table order; ZRK_COMPACT_ORDER=block|ticket; ZRK_TIME_BY_RECORDS=1 time between two
- * recorded events; ZRK_HELPER_IDLE_MS how long the library's threads spin after their last item before they sleep
- * (default 1: they spin inside a call only); tuning / diagnostics, defaults chosen by measurement:
+ * recorded events; ZRK_HELPER_IDLE_MS how long the library's threads spin after their last item (default 1) and
+ * ZRK_HELPER_YIELD_MS how long they then stay runnable, yielding their core between looks (default 250), before they sleep --
+ * calls less than that apart find them awake; ZRK_STALL_US=n reports on stderr every host-side wait of the library longer
+ * than n microseconds with the line it stands in; tuning / diagnostics, defaults chosen by measurement:
  * ZRK_PAIR_THREADS=256|512|1024 and ZRK_PAIR_COMPACT_BLOCKS (workgroup size of the pair compaction, and up to how many
  * workgroups a pair's compactions are one launch), ZRK_COMPACT_GROUP=0|4|8|16|32 (two-level sums of the workgroup records),
  * ZRK_COMPACT_ITEMS, ZRK_COMPACT_FUSED_MAX_BLOCKS, ZRK_SIDE_CUS=n[,first] / ZRK_SIDE_PRIORITY=high|low (the side stream's
