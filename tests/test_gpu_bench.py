@@ -31,6 +31,18 @@ def test_single_rank_line_has_the_contract_fields():
     assert rec["roofline"]["effective"]["achieved"] >= rec["roofline"]["achieved"]
     assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cpu_model"]
     assert rec["value"] > 0 and "tiny" in rec["config"]["workload"]
+    # (a table this small takes the plain loop) ... and the line says when the timed call's sweeps ran
+    assert rec["roofline"]["ticks_per_launch"] == 1 and rec["config"]["loop"] == "two launches per tick on one stream"
+    assert rec["setup"]["sweeps_span_us"] > rec["roofline"]["first_wave_in_to_last_wave_out_us"] and rec["setup"]["sweep_gaps_us"] >= 0
+
+
+def test_the_line_names_the_loop_of_the_timed_call():
+    """C2 runs overlapped with two ticks per launch; the one-tick calibration calls behind the timed region take the plain loop
+    and must not be what `config.loop` describes."""
+    rec = _bench(["--workload", "C2", "--steps", "12", "--warmup", "4", "--no-cpu-baseline"])
+    assert rec["roofline"]["ticks_per_launch"] == 2 and rec["roofline"]["samples"] == 6
+    assert rec["config"]["loop"].startswith("overlapped, two ticks per sweep launch")
+    assert rec["setup"]["sweeps_span_us"] > 0 and rec["setup"]["sweep_gaps_us"] >= 0
 
 
 @pytest.mark.parametrize("workload,scaling,wire", [("tiny", "weak", "union"), ("tiny4", "strong", "union"), ("tiny", "weak", "masks")])
