@@ -372,7 +372,8 @@ typedef struct {
  * launch per tick: removals decided by a tick's missile phase are marks that the rows' own threads carry out in the
  * next sweep (tombstones again when the call returns), radar records travel in the sweep's arguments.  Same results;
  * everything the caller reads is written on `stream` or taken in by it before the call returns, so the outputs are the
- * caller's as before (what the side stream may still be running then touches buffers of the context only).  The call's LAST
+ * caller's as before (a wait for whatever the side stream may still be running then stands behind the call's last launch
+ * on `stream`).  The call's LAST
  * compaction (no exchange) is launched on `stream` itself, in order behind the last sweep -- by the context's thread: a
  * caller must not be capturing `stream` into a graph, and must order its own streams if consecutive calls come on
  * different ones (ZRK_TAIL_COMPUTE=0: on the side stream like the others, released by a launch behind the last sweep;
