@@ -63,7 +63,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-SPINUP_MS = 100.0
+SPINUP_MS = float(os.environ.get("ZRK_BENCH_SPINUP_MS", "100"))   # (0: none -- what the spin-up is worth: profiles/r04_bench_c3_driver_no_spinup.json)
 PROFILE_TAG = "r04"            # profiles/<tag>_* hold the recorded figures echoed in the line
 
 

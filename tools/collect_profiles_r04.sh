@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py"
 echo "== bench lines"
 for i in 1 2 3; do $B --steps 20 --warmup 5 > $out/bench_c3_driver_$i.json 2> $out/bench_c3_driver_$i.err; done
+ZRK_BENCH_SPINUP_MS=0 $B --steps 20 --warmup 5 --no-c4 --no-cpu-baseline > $out/bench_c3_driver_no_spinup.json 2>> $out/bench_c3.err
 $B --steps 1000 --warmup 50 --no-c4 > $out/bench_c3.json 2> $out/bench_c3.err
 ZRK_PAIR=0 $B --steps 1000 --warmup 50 --no-cpu-baseline --no-c4 > $out/bench_c3_one_tick_per_launch.json 2>> $out/bench_c3.err
 ZRK_OVERLAP=0 $B --steps 1000 --warmup 50 --no-cpu-baseline --no-c4 > $out/bench_c3_plain_loop.json 2>> $out/bench_c3.err

@@ -162,7 +162,7 @@ if sq["k_tick_sweep"]:
                     if k in q:
                         o.write(f"{k + ' / wave cycles':32s} {q[k] / q['SQ_WAVE_CYCLES']:8.3f}\n")
 
-for name in ("bench_c3_driver_1", "bench_c3_driver_2", "bench_c3_driver_3", "bench_c3", "bench_c3_one_tick_per_launch", "bench_c3_plain_loop",
+for name in ("bench_c3_driver_1", "bench_c3_driver_2", "bench_c3_driver_3", "bench_c3_driver_no_spinup", "bench_c3", "bench_c3_one_tick_per_launch", "bench_c3_plain_loop",
              "bench_c3_exchange_one_rank", "bench_c2", "bench_c5", "bench_c3x4", "bench_c4_1gpu"):
     rec = line(name)
     if rec:
@@ -180,7 +180,7 @@ if drv and recorded.get("sweep_us_C3_driver_run"):
 (dst / f"{tag}_recorded.json").write_text(json.dumps(recorded, indent=1) + "\n")
 print(json.dumps(recorded, indent=1))
 print(json.dumps(traffic, indent=1))
-for name in ("bench_c3_driver_1", "bench_c3_driver_2", "bench_c3_driver_3", "bench_c3", "bench_c3_one_tick_per_launch", "bench_c3_plain_loop",
+for name in ("bench_c3_driver_1", "bench_c3_driver_2", "bench_c3_driver_3", "bench_c3_driver_no_spinup", "bench_c3", "bench_c3_one_tick_per_launch", "bench_c3_plain_loop",
              "bench_c3_exchange_one_rank", "bench_c2", "bench_c5", "bench_c3x4", "bench_c4_1gpu"):
     rec = line(name)
     if rec:
