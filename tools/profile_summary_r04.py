@@ -120,6 +120,21 @@ if len(vals) == 2:
                          fetch_size_kb=vals["FETCH_SIZE"][0], write_size_kb=vals["WRITE_SIZE"][0], read_bytes=rd, write_bytes=wr,
                          traffic_bytes=rd + wr, algorithmic_bytes=alg, traffic_over_algorithmic=(rd + wr) / alg if alg else None)
     recorded["traffic_bytes_C3"] = rd + wr
+# ... and of the pair compaction beside it, from the same two passes
+cvals = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = newest(str(src / f"traffic_C3_{c}" / "*" / "*counter_collection.csv"))
+    if f:
+        rows = [r for r in csv.DictReader(open(f[0])) if "k_compact_pair" in r["Kernel_Name"] and r["Counter_Name"] == c][12:]
+        if rows:
+            cvals[c] = (sum(float(r["Counter_Value"]) for r in rows) / len(rows), len(rows))
+if len(cvals) == 2:
+    rd = cvals["FETCH_SIZE"][0] * 1024 * cal["read_factor"]
+    wr = cvals["WRITE_SIZE"][0] * 1024 * cal["write_factor"]
+    traffic["C3_k_compact_pair"] = dict(launches_averaged=cvals["FETCH_SIZE"][1], ticks_per_launch=2, fetch_size_kb=cvals["FETCH_SIZE"][0],
+                                        write_size_kb=cvals["WRITE_SIZE"][0], read_bytes=rd, write_bytes=wr, traffic_bytes=rd + wr,
+                                        what="the masks of both ticks read (4 B per slot), the lists of both ticks written (4 B per entry), the "
+                                             "detected slots' masks cleared")
 (dst / f"{tag}_pmc_traffic.json").write_text(json.dumps(dict(
     kernel="k_tick_sweep<true, true, true, true, true> (two ticks per launch)", calibration=cal, workloads=traffic,
     method="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of bench.py (MI355X_MICROARCH.md HBM section): "
