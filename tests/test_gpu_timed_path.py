@@ -265,6 +265,10 @@ def test_sweeps_time_themselves(monkeypatch):
     eng.run(13)                                                    # six pair launches and an odd tick
     us, ticks = eng.read_sweep_stamps()
     assert ticks.tolist() == [2] * 6 + [1] and ((us > 1.0) & (us < 2000.0)).all(), (us, ticks)
+    # ... and when they ran (zrk_last_sweep_stamp_times): one after the other on their stream, from the first one's first wave on
+    b, e = eng.sweep_stamp_times()
+    assert len(b) == len(us) and b[0] == 0.0 and np.allclose(e - b, us, atol=0.02)
+    assert (b[1:] >= e[:-1] - 0.02).all() and e[-1] < 5000.0, (b, e)
     for _ in range(3):                                             # the plain loop, one event pair per launch beside the stamps
         ms = np.zeros(1, np.float32)
         eng.run(1, sweep_ms=ms, prof_stride=1)
