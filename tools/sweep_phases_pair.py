@@ -79,12 +79,63 @@ cost_per = np.bincount(unit, weights=np.where(light, 0.0, cost), minlength=int(u
 used = np.bincount(unit, minlength=int(unit.max()) + 1) > 0
 print(f"{nu} SIMDs seen; heavy waves per SIMD: percentiles 0 10 50 90 100  {q(heavy_per[used])}")
 print(f"radar-loop time of the heavy waves summed per SIMD [us]:            {q(cost_per[used])}")
+# which SIMD a workgroup's wave w lands on (wave index within the workgroup = table wave % 4): a fixed assignment means that a
+# scheme which makes "wave w of every workgroup" the heavy one piles all of them onto one SIMD in four
+widx = np.arange(len(ok))[ok] % 4                  # the wave's place in its workgroup (a workgroup sweeps four consecutive table waves)
+tab = np.zeros((4, 4), dtype=np.int64)
+np.add.at(tab, (widx, simd), 1)
+print("wave-in-workgroup x SIMD (rows: wave 0..3, columns: SIMD 0..3):", " | ".join(" ".join(str(int(v)) for v in row) for row in tab))
+# ... and whether the first wave's SIMD is a property of the compute unit (a rotor that moves on by four per workgroup) or changes from
+# workgroup to workgroup: per unit, the share of its workgroups that start on its commonest SIMD
+cu_all = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+base = (simd - widx) % 4
+share = []
+for u in np.unique(cu_all):
+    b = np.bincount(base[(cu_all == u) & (widx == 0)], minlength=4)
+    if b.sum() >= 8:
+        share.append(b.max() / b.sum())
+print(f"per compute unit, share of workgroups whose wave 0 sits on the unit's commonest SIMD: percentiles {q(np.array(share))}")
+same = 0; tot = 0
+wv_ids = np.arange(len(ok))[ok]
+for u in np.unique(cu_all)[:64]:
+    sel_u = np.nonzero((cu_all == u) & (widx == 0))[0]
+    sel_u = sel_u[np.argsort(start[sel_u], kind="stable")]
+    bs = base[sel_u]
+    same += int((bs[1:] == bs[:-1]).sum()); tot += max(0, len(bs) - 1)
+print(f"consecutive workgroups of a unit (start order) with the same first SIMD: {same} of {tot}")
+wg = np.arange(len(ok))[ok] // 4                   # (the row block)
+# A finished wave's slot is not given out again before its whole workgroup has ended (tools/dispatch_rate_probe.hip): what the
+# waves of a workgroup hold beyond their own end
+wg_end = np.zeros(int(wg.max()) + 1); np.maximum.at(wg_end, wg, end)
+held = wg_end[wg] - end
+print(f"slot time held by finished waves until their workgroup ends: {float(held.sum()):.0f} us of {float((end - start).sum()):.0f} us lived "
+      f"(light {float(held[light].sum()):.0f}, heavy {float(held[~light].sum()):.0f}); per wave percentiles {q(held)}")
+hv_per_wg = np.bincount(wg[~light], minlength=int(wg.max()) + 1)
+print("workgroups by number of heavy waves (0..4):", np.bincount(hv_per_wg, minlength=5)[:5].tolist(),
+      "; heavy waves by place in the workgroup (0..3):", np.bincount(widx[~light], minlength=4).tolist())
+first_wg = np.zeros(int(wg.max()) + 1); np.maximum.at(first_wg, wg, -start); first_wg = -first_wg
+early = first_wg[wg] < 3.0
+print(f"workgroups that start in the first 3 us: {int((first_wg < 3.0).sum())}; their heavy waves: {int((~light & early).sum())}")
+# the placement of three compute units' workgroups, in start order: the SIMD of each of the four waves (heavy = *), and how many waves
+# the unit's SIMDs held when the workgroup's first wave started
+for u in np.unique(cu_all)[[3, 77, 200]]:
+    on_u = cu_all == u
+    wgs = np.unique(wg[on_u])
+    wgs = wgs[np.argsort([start[on_u & (wg == g)].min() for g in wgs])]
+    print(f"unit {int(u)}: workgroups in start order  [start us | SIMD of wave 0..3 | resident per SIMD before]")
+    for g in wgs[:24]:
+        sel_g = np.nonzero(on_u & (wg == g))[0]
+        sel_g = sel_g[np.argsort(widx[sel_g])]
+        t_g = start[sel_g].min()
+        res = [int(((start < t_g) & (end > t_g) & on_u & (simd == k)).sum()) for k in range(4)]
+        hv_res = [int(((start < t_g) & (end > t_g) & on_u & (simd == k) & ~light).sum()) for k in range(4)]
+        print(f"  {t_g:6.2f} | " + " ".join(f"{int(simd[i])}{'*' if not light[i] else ' '}" for i in sel_g) + f" | {res} heavy {hv_res}")
 first = start < 3.0
 print(f"of the waves that start in the first 3 us ({int(first.sum())}): {100 * float((~light)[first].mean()):.0f} % heavy; "
       f"heavy waves per SIMD among them {q(np.bincount(unit[first & ~light], minlength=int(unit.max()) + 1)[used])}")
 
 # the dispatcher's placement: the first workgroups of XCD 0 in start order (wave 0 of each workgroup), as (se, sh, cu)
-w0 = (np.arange(len(ok))[ok] % 4) == 0
+w0 = widx == 0
 sel = np.nonzero(w0 & (xcc == 0))[0]
 sel = sel[np.argsort(start[sel], kind="stable")][:96]
 print("XCD 0, workgroups in start order: se.sh.cu (heavy = *)")

@@ -1615,6 +1615,73 @@ struct CompactArgs {
     int32_t group;
 };
 
+// What a compaction workgroup needs only at its END -- where the lists go -- is read there, from the kernel-argument segment,
+// through an address the compiler cannot connect with the arguments it has seen (launder_kernarg): left to itself it fetches
+// both ticks' CompactArgs in sixteen-word bursts half-way through the kernel and keeps them in scalar registers across the
+// squeeze, the walks and the wait for the lower tickets -- 50-54 of them spilt into vector lanes in every k_compact_pair variant,
+// 30 in k_compact_side / k_compact_fused (profiles/r04: every compaction kernel at the 106-SGPR cap).  THE ADDRESS IS FORMED IN
+// THE __global__ BODY ONLY (see g_device_fault: outside an entry point the intrinsic is the constant 0).
+struct CompactLate {
+    int32_t *det_idx;
+    int64_t det_stride;
+    int32_t *det_cnt;
+    int64_t *packed;
+    int64_t packed_capacity, gid0;
+    UnionBits bits;
+    int32_t base_index;
+    int64_t seg_slots;
+};
+
+__device__ __forceinline__ const char *launder_kernarg(const char *p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// ... and what it needs between the squeeze and the scatter: where the records are, this launch's tag, how the sums are laid out
+struct CompactMid {
+    unsigned long long *agg;
+    int32_t *ctl;
+    uint32_t epoch;
+    int32_t lanes, group;
+};
+
+__device__ __forceinline__ CompactMid compact_mid(const char *kc)
+{
+    typedef const uint64_t __attribute__((address_space(4))) *Q;
+    typedef const uint32_t __attribute__((address_space(4))) *W;
+    const char *k = launder_kernarg(kc);
+    CompactMid M;
+    M.agg = (unsigned long long *)*(Q)(uint64_t)(k + offsetof(CompactArgs, agg));
+    M.ctl = (int32_t *)*(Q)(uint64_t)(k + offsetof(CompactArgs, ctl));
+    M.epoch = *(W)(uint64_t)(k + offsetof(CompactArgs, epoch));
+    M.lanes = (int32_t)*(W)(uint64_t)(k + offsetof(CompactArgs, lanes));
+    M.group = (int32_t)*(W)(uint64_t)(k + offsetof(CompactArgs, group));
+    return M;
+}
+
+// `kc`: where this workgroup's CompactArgs stand in the kernel-argument segment
+__device__ __forceinline__ CompactLate compact_late(const char *kc)
+{
+    typedef const uint64_t __attribute__((address_space(4))) *Q;
+    typedef const uint32_t __attribute__((address_space(4))) *W;
+    const char *k = launder_kernarg(kc);
+    CompactLate L;
+    L.det_idx = (int32_t *)*(Q)(uint64_t)(k + offsetof(CompactArgs, det_idx));
+    L.det_stride = (int64_t)*(Q)(uint64_t)(k + offsetof(CompactArgs, det_stride));
+    L.det_cnt = (int32_t *)*(Q)(uint64_t)(k + offsetof(CompactArgs, det_cnt));
+    L.packed = (int64_t *)*(Q)(uint64_t)(k + offsetof(CompactArgs, packed));
+    L.packed_capacity = (int64_t)*(Q)(uint64_t)(k + offsetof(CompactArgs, packed_capacity));
+    L.gid0 = (int64_t)*(Q)(uint64_t)(k + offsetof(CompactArgs, gid0));
+    L.bits.words = (int64_t)*(Q)(uint64_t)(k + offsetof(CompactArgs, bits) + offsetof(UnionBits, words));
+    L.bits.mask_cap = (int64_t)*(Q)(uint64_t)(k + offsetof(CompactArgs, bits) + offsetof(UnionBits, mask_cap));
+    L.bits.mask_bytes = (int32_t)*(W)(uint64_t)(k + offsetof(CompactArgs, bits) + offsetof(UnionBits, mask_bytes));
+    L.bits._pad = 0;
+    L.base_index = (int32_t)*(W)(uint64_t)(k + offsetof(CompactArgs, base_index));
+    L.seg_slots = (int64_t)*(Q)(uint64_t)(k + offsetof(CompactArgs, seg_slots));
+    return L;
+}
+
 template <int THREADS>
 struct CompactShared {
     int wcnt[kFusedMaxItems * (THREADS / 64)];
@@ -1629,7 +1696,7 @@ struct CompactShared {
 // One workgroup of the single-launch compaction (THREADS threads, C.items slots each).  Runs as the stand-alone
 // kernel below (1024 threads) and as the leading workgroups of the next tick's sweep (ZRK_BLOCK threads).
 template <int THREADS>
-__device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const CompactArgs &C, int by_ticket)
+__device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const CompactArgs &C, int by_ticket, const char *kc)
 {
     // (the wave's number as a scalar: what follows from it -- the radars it walks, their lists' bases -- then lives in SGPRs)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1644,7 +1711,6 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
     const int64_t blk0 = (int64_t)b * C.items * THREADS;
     const int seg = C.seg_blocks ? b / C.seg_blocks : 0;          // scenario of this workgroup
     const int first = seg * C.seg_blocks;                         // its first workgroup: nobody before it counts
-    const bool last_of_seg = C.seg_blocks ? (b == first + C.seg_blocks - 1) : (b == C.nb - 1);
     ZRK_PROBE(0);
     // (32-bit slot numbers against the block's own base address; a slot past the table's end reads the block's last one and
     // counts as empty: no load of the burst hangs on a branch -- see compact_block_pair)
@@ -1725,58 +1791,60 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
     if (tid == 0) S.cnt[C.R] = found;
     __syncthreads();
     ZRK_PROBE(3);
+    const CompactMid Q = compact_mid(kc);
     if (tid <= C.R)
-        __hip_atomic_store(&C.agg[(int64_t)b * kAggStride + tid], ((unsigned long long)C.epoch << 32) | (uint32_t)S.cnt[tid],
+        __hip_atomic_store(&Q.agg[(int64_t)b * kAggStride + tid], ((unsigned long long)Q.epoch << 32) | (uint32_t)S.cnt[tid],
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     {
-        // lower tickets: record p, counter c is word p * C.lanes + c of a (p, c) grid dealt out to the
-        // threads THREADS apart (C.lanes: a power of two >= C.R+1)
-        const int c = tid & (C.lanes - 1);
-        const int p_first = tid / C.lanes, p_step = THREADS / C.lanes;
-        const int G = C.group, g = G ? b / G : 0, gs = g * G;
-        const unsigned long long *gagg = C.agg + kGroupOffset;
+        // lower tickets: record p, counter c is word p * Q.lanes + c of a (p, c) grid dealt out to the
+        // threads THREADS apart (Q.lanes: a power of two >= C.R+1)
+        const int c = tid & (Q.lanes - 1);
+        const int p_first = tid / Q.lanes, p_step = THREADS / Q.lanes;
+        const int G = Q.group, g = G ? b / G : 0, gs = g * G;
+        const unsigned long long *gagg = Q.agg + kGroupOffset;
         bool timed_out = false;
         if (G && b - gs == G - 1) {                   // the group's last ticket: its totals first, they wait for nobody before the group
             if (c <= C.R) {
-                const int in = sum_epoch_records<kAggStride>(C.agg, gs, b, gagg, 0, 0, c, p_first, p_step, C.epoch, timed_out);
+                const int in = sum_epoch_records<kAggStride>(Q.agg, gs, b, gagg, 0, 0, c, p_first, p_step, Q.epoch, timed_out);
                 if (in) { atomicAdd(&S.grp[c], in); atomicAdd(&S.pre[c], in); }
             }
             __syncthreads();
             if (tid <= C.R)
                 __hip_atomic_store(const_cast<unsigned long long *>(gagg) + (int64_t)g * kAggStride + tid,
-                                   ((unsigned long long)C.epoch << 32) | (uint32_t)(S.grp[tid] + S.cnt[tid]), __ATOMIC_RELAXED,
+                                   ((unsigned long long)Q.epoch << 32) | (uint32_t)(S.grp[tid] + S.cnt[tid]), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             if (c <= C.R) {
-                const int acc = sum_epoch_records<kAggStride>(C.agg, 0, 0, gagg, 0, g, c, p_first, p_step, C.epoch, timed_out);
+                const int acc = sum_epoch_records<kAggStride>(Q.agg, 0, 0, gagg, 0, g, c, p_first, p_step, Q.epoch, timed_out);
                 if (acc) atomicAdd(&S.pre[c], acc);
             }
         } else if (c <= C.R) {
-            const int acc = G ? sum_epoch_records<kAggStride>(C.agg, gs, b, gagg, 0, g, c, p_first, p_step, C.epoch, timed_out)
-                              : sum_epoch_records<kAggStride>(C.agg, first, b, gagg, 0, 0, c, p_first, p_step, C.epoch, timed_out);
+            const int acc = G ? sum_epoch_records<kAggStride>(Q.agg, gs, b, gagg, 0, g, c, p_first, p_step, Q.epoch, timed_out)
+                              : sum_epoch_records<kAggStride>(Q.agg, first, b, gagg, 0, 0, c, p_first, p_step, Q.epoch, timed_out);
             if (acc) atomicAdd(&S.pre[c], acc);
         }
-        if (timed_out) atomicExch(&C.ctl[2], 2);
+        if (timed_out) atomicExch(&Q.ctl[2], 2);
     }
     __syncthreads();
     ZRK_PROBE(4);
-    if (C.packed) {
+    const CompactLate L = compact_late(kc);          // (where the lists go: asked for here, not carried through the kernel)
+    if (L.packed) {
         const int64_t ubase = S.pre[C.R];
         for (int k = tid; k < found; k += THREADS) {
             const int64_t dst = ubase + k;
-            if (C.bits.words) union_bits_mask(C.packed, C.bits, dst, S.msk[k]);
-            else if (dst + 1 < C.packed_capacity) C.packed[dst + 1] = ((C.gid0 + blk0 + S.idx[k]) << 32) | (int64_t)S.msk[k];
+            if (L.bits.words) union_bits_mask(L.packed, L.bits, dst, S.msk[k]);
+            else if (dst + 1 < L.packed_capacity) L.packed[dst + 1] = ((L.gid0 + blk0 + S.idx[k]) << 32) | (int64_t)S.msk[k];
         }
     }
-    if (C.det_idx) {
+    if (L.det_idx) {
         constexpr int WAVES = THREADS / 64;
-        const int limit = (int)(C.det_stride < 0x7FFFFFFF ? C.det_stride : 0x7FFFFFFF);
-        const int32_t slot0 = C.base_index + (int32_t)(blk0 - (int64_t)seg * C.seg_slots);
-        int32_t *seg_out = C.det_idx + (int64_t)seg * C.R * C.det_stride;
+        const int limit = (int)(L.det_stride < 0x7FFFFFFF ? L.det_stride : 0x7FFFFFFF);
+        const int32_t slot0 = L.base_index + (int32_t)(blk0 - (int64_t)seg * L.seg_slots);
+        int32_t *seg_out = L.det_idx + (int64_t)seg * C.R * L.det_stride;
         for (int rb = wave; rb < C.R; rb += 2 * WAVES) {
             const bool two = rb + WAVES < C.R;
             const uint32_t sel[2] = {1u << rb, two ? (1u << (rb + WAVES)) : 0u};
             int run[2] = {__builtin_amdgcn_readfirstlane(S.pre[rb]), two ? __builtin_amdgcn_readfirstlane(S.pre[rb + WAVES]) : 0};
-            int32_t *const out[2] = {seg_out + (int64_t)rb * C.det_stride, seg_out + (int64_t)(two ? rb + WAVES : rb) * C.det_stride};
+            int32_t *const out[2] = {seg_out + (int64_t)rb * L.det_stride, seg_out + (int64_t)(two ? rb + WAVES : rb) * L.det_stride};
             if (two) walk_scatter<2>(S.msk, S.idx, len_pad, sel, run, out, limit, slot0);
             else {
                 const uint32_t sel1[1] = {sel[0]}; int run1[1] = {run[0]}; int32_t *const out1[1] = {out[0]};
@@ -1784,19 +1852,25 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
             }
         }
     }
+    typedef const uint32_t __attribute__((address_space(4))) *LateWords;
+    const int late_seg_blocks = (int)*(LateWords)(uint64_t)(launder_kernarg(kc) + offsetof(CompactArgs, seg_blocks));
+    const int late_nb = (int)*(LateWords)(uint64_t)(launder_kernarg(kc) + offsetof(CompactArgs, nb));
+    const bool last_of_seg = late_seg_blocks ? (b == seg * late_seg_blocks + late_seg_blocks - 1) : (b == late_nb - 1);
     if (last_of_seg && tid <= C.R) {                   // the end of the (scenario's) list: totals
         const int tot = S.pre[tid] + S.cnt[tid];
-        if (C.det_cnt) C.det_cnt[(int64_t)seg * (C.R + 1) + tid] = tot;
-        if (C.packed && tid == C.R) {
-            C.packed[0] = tot;
-            if (C.bits.words) C.packed[1] = C.n;
+        if (L.det_cnt) L.det_cnt[(int64_t)seg * (C.R + 1) + tid] = tot;
+        if (L.packed && tid == C.R) {
+            L.packed[0] = tot;
+            if (L.bits.words) L.packed[1] = C.n;
         }
     }
     ZRK_PROBE(5);
-    if (by_ticket && tid == 0) {
-        if (atomicAdd(&C.ctl[1], 1) == C.nb - 1) {     // everybody holds a ticket and is done with it
-            atomicExch(&C.ctl[0], 0);
-            atomicExch(&C.ctl[1], 0);
+    // (by_ticket: the kernels' second argument, right behind C)
+    if (*(LateWords)(uint64_t)(launder_kernarg(kc) + sizeof(CompactArgs)) != 0u && tid == 0) {
+        int32_t *ctl = compact_mid(kc).ctl;
+        if (atomicAdd(&ctl[1], 1) == late_nb - 1) {    // everybody holds a ticket and is done with it
+            atomicExch(&ctl[0], 0);
+            atomicExch(&ctl[1], 0);
         }
     }
 }
@@ -1867,7 +1941,7 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_fused(const CompactArgs 
         if (U.dst) put_radar_block(U);              // one scenario: the next tick's records, derived by the host
         return;
     }
-    compact_block<kCompBlock>(S, C, by_ticket);
+    compact_block<kCompBlock>(S, C, by_ticket, (const char *)__builtin_amdgcn_kernarg_segment_ptr());      // (C: the first argument)
 }
 
 // The side stream's compactions tell the HOST which of them are over through a word in pinned memory: the first thread of
@@ -1899,7 +1973,7 @@ __global__ __launch_bounds__(kCompBlock) void k_compact_side(const CompactArgs C
         if (M.m > 0 && (int)blockIdx.x == C.nb) missile_finish_entry(s_wave, M);
         return;
     }
-    compact_block<kCompBlock>(S, C, by_ticket);
+    compact_block<kCompBlock>(S, C, by_ticket, (const char *)__builtin_amdgcn_kernarg_segment_ptr());      // (C: the first argument)
 }
 
 // The ordered event list of a tick from the per-row codes, by ONE workgroup of any size (each thread owns a run of
@@ -1992,7 +2066,7 @@ struct CompactSharedPair {
 
 template <int THREADS>
 __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const CompactArgs &C0, const CompactArgs &C1, const int32_t *rm,
-                                                   int rm_cap)
+                                                   int rm_cap, const char *kc0)
 {
     constexpr int WAVES = THREADS / 64, kItems = kPairSlots / THREADS;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2116,23 +2190,24 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
     }
     if (tid < 2) S.cnt[tid][R] = S.found[tid];
     __syncthreads();
+    const CompactMid Q = compact_mid(kc0);
     const int nctr = 2 * (R + 1);                    // counter c: tick c / (R + 1), radar (or R: the union) c % (R + 1)
     if (tid < nctr)
-        __hip_atomic_store(&C0.agg[(int64_t)b * kPairAggStride + tid],
-                           ((unsigned long long)C0.epoch << 32) | (uint32_t)S.cnt[tid / (R + 1)][tid % (R + 1)], __ATOMIC_RELAXED,
+        __hip_atomic_store(&Q.agg[(int64_t)b * kPairAggStride + tid],
+                           ((unsigned long long)Q.epoch << 32) | (uint32_t)S.cnt[tid / (R + 1)][tid % (R + 1)], __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     {
         // lower tickets: record p, counter c is word p * lanes + c of a (p, c) grid dealt out to the threads
-        const int lanes = C0.lanes;                  // a power of two >= nctr
+        const int lanes = Q.lanes;                  // a power of two >= nctr
         const int c = tid & (lanes - 1);
         const int p_first = tid / lanes, p_step = THREADS / lanes;
-        const int G = C0.group, g = G ? b / G : 0, gs = g * G;
-        const unsigned long long *gagg = C0.agg + kGroupOffset;
-        const uint32_t epoch = C0.epoch;
+        const int G = Q.group, g = G ? b / G : 0, gs = g * G;
+        const unsigned long long *gagg = Q.agg + kGroupOffset;
+        const uint32_t epoch = Q.epoch;
         bool timed_out = false;
         if (G && b - gs == G - 1) {                   // the group's last ticket: its totals first (see compact_block)
             if (c < nctr) {
-                const int in = sum_epoch_records<kPairAggStride>(C0.agg, gs, b, gagg, 0, 0, c, p_first, p_step, epoch, timed_out);
+                const int in = sum_epoch_records<kPairAggStride>(Q.agg, gs, b, gagg, 0, 0, c, p_first, p_step, epoch, timed_out);
                 if (in) { atomicAdd(&S.grp[c], in); atomicAdd(&S.pre[c], in); }
             }
             __syncthreads();
@@ -2141,20 +2216,22 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
                                    ((unsigned long long)epoch << 32) | (uint32_t)(S.grp[tid] + S.cnt[tid / (R + 1)][tid % (R + 1)]),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (c < nctr) {
-                const int acc = sum_epoch_records<kPairAggStride>(C0.agg, 0, 0, gagg, 0, g, c, p_first, p_step, epoch, timed_out);
+                const int acc = sum_epoch_records<kPairAggStride>(Q.agg, 0, 0, gagg, 0, g, c, p_first, p_step, epoch, timed_out);
                 if (acc) atomicAdd(&S.pre[c], acc);
             }
         } else if (c < nctr) {
-            const int acc = G ? sum_epoch_records<kPairAggStride>(C0.agg, gs, b, gagg, 0, g, c, p_first, p_step, epoch, timed_out)
-                              : sum_epoch_records<kPairAggStride>(C0.agg, 0, b, gagg, 0, 0, c, p_first, p_step, epoch, timed_out);
+            const int acc = G ? sum_epoch_records<kPairAggStride>(Q.agg, gs, b, gagg, 0, g, c, p_first, p_step, epoch, timed_out)
+                              : sum_epoch_records<kPairAggStride>(Q.agg, 0, b, gagg, 0, 0, c, p_first, p_step, epoch, timed_out);
             if (acc) atomicAdd(&S.pre[c], acc);
         }
-        if (timed_out) atomicExch(&C0.ctl[2], 2);
+        if (timed_out) atomicExch(&Q.ctl[2], 2);
     }
     __syncthreads();
+    const int64_t n_rows = C0.n;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const CompactArgs &C = s ? C1 : C0;
+        // (where this tick's lists go: asked for here, see CompactLate; C1 stands right behind C0 in the argument segment)
+        const CompactLate C = compact_late(kc0 + (s ? sizeof(CompactArgs) : 0));
         const int found = S.found[s];
         const int *pre = S.pre + s * (R + 1);
         if (C.packed) {
@@ -2170,12 +2247,12 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
             if (C.det_cnt) C.det_cnt[tid] = tot;
             if (C.packed && tid == R) {
                 C.packed[0] = tot;
-                if (C.bits.words) C.packed[1] = C.n;
+                if (C.bits.words) C.packed[1] = n_rows;
             }
         }
     }
-    if (C0.det_idx) {
-        const CompactArgs &C = ws ? C1 : C0;
+    const CompactLate C = compact_late(kc0 + (ws ? sizeof(CompactArgs) : 0));     // (this half of the waves: its tick's lists)
+    if (C.det_idx) {
         const int limit = (int)(C.det_stride < 0x7FFFFFFF ? C.det_stride : 0x7FFFFFFF);
         const int32_t slot0 = C.base_index + (int32_t)blk0;
         for (int rb = wv; rb < R; rb += 2 * WPT) {
@@ -2192,10 +2269,16 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
         }
     }
     if (tid == 0) {
-        if (atomicAdd(&C0.ctl[1], 1) == C0.nb - 1) {     // everybody holds a ticket and is done with it
-            atomicExch(&C0.ctl[0], 0);
-            atomicExch(&C0.ctl[1], 0);
-            if (rm) __hip_atomic_store((int32_t *)rm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the list is this launch's to clear)
+        int32_t *ctl = compact_mid(kc0).ctl;
+        if (atomicAdd(&ctl[1], 1) == C0.nb - 1) {        // everybody holds a ticket and is done with it
+            atomicExch(&ctl[0], 0);
+            atomicExch(&ctl[1], 0);
+            // (the list is this launch's to clear; its address once more from the argument segment -- k_compact_pair's fifth
+            // argument, behind the two CompactArgs and the two MissileArgs -- instead of two scalar registers held from the first line on)
+            static_assert(sizeof(CompactArgs) % 8 == 0 && sizeof(MissileArgs) % 8 == 0, "k_compact_pair's arguments stand back to back");
+            typedef const uint64_t __attribute__((address_space(4))) *Q;
+            int32_t *rm_late = (int32_t *)*(Q)(uint64_t)(launder_kernarg(kc0) + 2 * sizeof(CompactArgs) + 2 * sizeof(MissileArgs));
+            if (rm_late) __hip_atomic_store(rm_late, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -2214,7 +2297,8 @@ __global__ __launch_bounds__(THREADS) void k_compact_pair(const CompactArgs C0, 
         }
         return;
     }
-    compact_block_pair<THREADS>(S, C0, C1, rm, rm_cap);
+    static_assert(sizeof(CompactArgs) % 8 == 0, "C1 stands right behind C0 in the argument segment");
+    compact_block_pair<THREADS>(S, C0, C1, rm, rm_cap, (const char *)__builtin_amdgcn_kernarg_segment_ptr());    // (C0: the first argument)
 }
 
 // Overlapped loop of an ENSEMBLE: what the next sweep needs of a tick's second launch -- the tombstones, every
