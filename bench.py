@@ -63,8 +63,9 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_ACHIEVABLE_GBS = 6300.0    # what a pure streaming kernel reaches on this part (the same guide, HBM section)
 SPINUP_MS = float(os.environ.get("ZRK_BENCH_SPINUP_MS", "100"))   # (0: none -- what the spin-up is worth: profiles/r04_bench_c3_driver_no_spinup.json)
-PROFILE_TAG = "r04"            # profiles/<tag>_* hold the recorded figures echoed in the line
+PROFILE_TAG = "r05"            # profiles/<tag>_* hold the recorded figures echoed in the line
 
 
 def parse_args():
@@ -73,9 +74,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C3x4", "C4", "C5", "tiny", "tiny4", "tiny5"])
-    ap.add_argument("--wire", default="union", choices=["union", "masks"],
-                    help="N > 1: what a rank's per-tick list carries -- the bitmap of the slots seen by any radar (default), or the "
-                         "bitmap and the radar masks of the seen slots")
+    ap.add_argument("--wire", default="masks", choices=["union", "masks"],
+                    help="N > 1: what a rank's per-tick list carries -- the bitmap of the slots seen by any radar and the radar masks of "
+                         "the seen slots (default: what a replicated command post needs, modules/CCP.py:409-417 keeps radar_id per "
+                         "message), or the bitmap alone (a fifth of the bytes).  A default multi-rank run times BOTH: the line's "
+                         "value is the `masks` figure, the bitmap-only figure stands beside it as `union_wire`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true",
                     help="skip the strong-scaling sub-record (configs[3], one population of 1e7) a default C3 run adds to its line")
@@ -322,6 +325,10 @@ def main():
         return
     os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")       # kernel arguments in device memory (PyTorch's default too)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the library's helper threads stay runnable for this long after their last item (default 5 ms: an embedding application
+    # should not find cores held between its calls); here the warm-up call, the spin-up and the timed call are tens of
+    # milliseconds apart, and a helper woken from its sleep at the timed call's entry can cost that call milliseconds
+    os.environ.setdefault("ZRK_HELPER_YIELD_MS", "250")
 
     import numpy as np
     import torch
@@ -344,8 +351,9 @@ def main():
 
     from zrk_modulation_amd import scenario as S
 
-    def measure(workload, steps, warmup, cpu_base):
+    def measure(workload, steps, warmup, cpu_base, wire=None):
         """One workload, set up, warmed up and timed as the docstring says; rank 0 gets the line's dictionary."""
+        wire = wire or args.wire
         from zrk_modulation_amd import scenario as S
         ensemble = workload in S.ENSEMBLES
         strong = workload in S.STRONG
@@ -375,7 +383,7 @@ def main():
             from zrk_modulation_amd.exchange import DetectionExchange, RcclExchange, union_bits_words
             n_slots = coll_device(torch.tensor([int(eng.store.cap)], dtype=torch.int64))
             all_reduce(n_slots, dist.ReduceOp.MAX)
-            words = union_bits_words(int(n_slots.item()), info["R"], 0 if args.wire == "union" else entries)
+            words = union_bits_words(int(n_slots.item()), info["R"], 0 if wire == "union" else entries)
             offsets = [g * info["stride"] for g in range(world)]
             made = False
             if state["c_side"] and xchg["x"] is not None:
@@ -384,7 +392,7 @@ def main():
                 made = True
             elif state["c_side"]:
                 try:
-                    xchg["x"] = RcclExchange(words, device, info["R"], offsets=offsets, ev_capacity=ev_cap, wire=args.wire)
+                    xchg["x"] = RcclExchange(words, device, info["R"], offsets=offsets, ev_capacity=ev_cap, wire=wire)
                     made = True
                 except Exception as exc:                     # the library's own communicator could not be set up here
                     print(f"[bench rank {rank}] C-side exchange unavailable ({exc}); falling back to torch.distributed", file=sys.stderr)
@@ -397,7 +405,7 @@ def main():
                         xchg["x"] = None
                     state["c_side"] = False
             if not state["c_side"]:
-                xchg["ex"] = [DetectionExchange(words, device, fmt="bits", offsets=offsets, R=info["R"], union_only=args.wire == "union")
+                xchg["ex"] = [DetectionExchange(words, device, fmt="bits", offsets=offsets, R=info["R"], union_only=wire == "union")
                               for _ in range(2)]
                 xchg["buf"] = [torch.zeros(words, dtype=torch.int64, device=device) for _ in range(2)]
                 xchg["work"] = [None, None]
@@ -524,6 +532,8 @@ def main():
         # arguments) and the release behind -- is what a profiler's begin / end stamps of the same launch add to the launch's own:
         # measured behind the region on stand-alone launches (calls of one tick, device otherwise idle), each timed both ways
         overhead_us = []
+        # (the exchange's own counters as the timed call left them: the calibration calls below post collectives of their own)
+        xinfo_timed = xchg["x"].info() if (exchanging and state["c_side"] and xchg["x"] is not None) else None
         if stamping and deferred:
             for _ in range(10):
                 run_ticks(1, np.zeros(1, np.float32), every=1)
@@ -533,6 +543,7 @@ def main():
                     overhead_us.append(ev_us - float(st_us[0]))
             if exchanging:
                 drain_exchange()
+            eng.store.compact_status()       # (the calibration calls' compactions as well)
             overhead_us = sorted(overhead_us)[1:-1]             # (without the two extremes)
         dispatch_overhead_us = float(np.mean(overhead_us)) if len(overhead_us) else 0.0
 
@@ -599,10 +610,14 @@ def main():
                            "loop": loop_mode},
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                             # (what a pure streaming kernel reaches on this part, and the launch's bytes against that)
+                             "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
                              "traffic_recorded": recorded(f"traffic_bytes_{workload}") if world == 1 else None,
                              "kernel": "k_tick_sweep", "avg_kernel_us": sweep_avg_us, "samples": int(len(good)),
                              "min_kernel_us": float(good.min()) if len(good) else None,
                              "max_kernel_us": float(good.max()) if len(good) else None, "timed_by": timing,
+                             # the MEASURED quantity: every sweep launch of the timed call, by its own stamps.  avg_kernel_us adds
+                             # dispatch_overhead_us to it, which is measured on another launch shape (one tick, device idle, behind the region)
                              "first_wave_in_to_last_wave_out_us": float(wave_us.mean()) if len(wave_us) else None,
                              "dispatch_overhead_us": dispatch_overhead_us,
                              "first_wave_in_to_last_wave_out_us_per_launch": [round(float(v), 2) for v in stamp_us] if 0 < len(stamp_us) <= 16 else None,
@@ -628,10 +643,18 @@ def main():
                 out["config"]["exchange_entries_per_rank"] = xchg["entries"]
                 out["config"]["exchange_bytes_per_rank"] = 8 * (xchg["words"] + (1 + ev_cap if state["c_side"] else 0))
                 out["config"]["exchange_overflow"] = bool(overflow)
-                out["config"]["exchange_wire"] = ("bitmap of the slots seen by any radar" if args.wire == "union" else
+                out["config"]["exchange_wire"] = ("bitmap of the slots seen by any radar" if wire == "union" else
                                                   "bitmap + radar masks of the seen slots") + " + detonation events"
+                # host threads a rank keeps busy inside a call: the caller + the library's helpers (zrk_exchange_plan_helpers: one where
+                # the rank has fewer than three usable cores to itself -- the side stream's thread then issues the collectives too)
+                helpers = xchg["x"].info()["helper_threads"] if state["c_side"] else int(eng.store.lib.zrk_exchange_plan_helpers(world))
+                out["config"]["helpers_mode"] = (("one helper: the side stream's thread issues the collectives as well" if helpers == 1 else
+                                                  "two helpers: the side stream's thread and a poster of the collectives") +
+                                                 ("" if state["c_side"] else " (planned for this world size on this host; the rehearsal backend posts from Python)"))
+                out["config"]["host_threads_per_rank"] = 1 + helpers
+                out["config"]["usable_host_cores"] = usable_cores()
                 if state["c_side"]:
-                    xi = xchg["x"].info()
+                    xi = xinfo_timed or xchg["x"].info()
                     # the first multi-rank record checks itself: RCCL's own count of the communicator's ranks, and how long
                     # the calling thread waited for collectives (per tick of the timed call and the calibration ticks behind it)
                     out["config"]["rccl_ranks_seen"] = xi["rccl_ranks_seen"]
@@ -649,6 +672,16 @@ def main():
         return out if rank == 0 else None
 
     out = measure(args.workload, args.steps, args.warmup, not args.no_cpu_baseline)
+    # N > 1: the line's value is measured with the wire the command line names (default: bitmap + radar masks, what a replicated
+    # command post consumes); the other wire is timed behind it on the same ranks, so that both stand side by side in one record
+    if world > 1 and args.workload not in S.ENSEMBLES:
+        other = "union" if args.wire == "masks" else "masks"
+        sub = measure(args.workload, min(args.steps, 200), min(max(args.warmup, 4), 50), False, wire=other)
+        if rank == 0:
+            out[f"{other}_wire"] = {k: sub[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")}
+            out[f"{other}_wire"]["exchange_wire"] = sub["config"]["exchange_wire"]
+            out[f"{other}_wire"]["exchange_bytes_per_rank"] = sub["config"]["exchange_bytes_per_rank"]
+            out["config"]["headline_wire"] = args.wire
     # The scaling curve north_star names is on the ONE-population 1e7-target scenario (configs[3], strong scaling): the
     # default run (C3 per GPU, weak scaling -- the roofline configuration) measures it as well, behind the main timing, so
     # that `python bench.py --gpus N` for N = 1, 2, 4, 8 yields both curves (--no-c4 skips it).

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ZRK_ABI_VERSION 10
+#define ZRK_ABI_VERSION 11
 #define ZRK_MAX_RADARS 32           /* one bit per radar in the visibility mask */
 #define ZRK_BLOCK 256               /* table rows per sweep workgroup */
 
@@ -484,6 +484,11 @@ typedef struct zrk_exchange_stats {
     double host_wait_us;
 } zrk_exchange_stats;
 int zrk_exchange_info(zrk_exchange *x, zrk_exchange_stats *out /* HOST */);
+/* (ABI 11) The helper threads per rank an exchange of `world` ranks on this host would start: 2 where the rank has three usable host
+ * cores or more to itself (affinity mask, capped by the cgroup CPU quota), else 1 -- the side stream's thread then issues the
+ * collectives as well; ZRK_HELPERS=1|2 forces either.  Touches no device: a launcher can say how many host threads its ranks
+ * will keep busy (1 + this) before it starts them. */
+int zrk_exchange_plan_helpers(int world);
 
 /* What zrk_run_ticks_x sends each tick: this rank's list in the wire format of zrk_compact_bits, followed -- when
  * ev_capacity > 0 -- by the tick's detonations, so that MissileDetonateMessage (modules/Missile.py:138-146) reaches

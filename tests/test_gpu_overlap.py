@@ -340,7 +340,7 @@ def _state_table(eng):
                 status=st.dm_status[:m].cpu().numpy(), radar=np.array(eng.radar_state()))
 
 
-@pytest.mark.parametrize("tail", ["compute", "side"])
+@pytest.mark.parametrize("tail", ["compute", "side", "compute-behind-the-side-stream"])
 def test_calls_on_alternating_streams(tail, monkeypatch):
     """A call's last compaction runs on the caller's stream (ZRK_TAIL_COMPUTE=0: on the side stream, taken in through an
     event), and the next call may come on ANOTHER stream that the caller has ordered behind the first: short calls (two
@@ -348,7 +348,10 @@ def test_calls_on_alternating_streams(tail, monkeypatch):
     from tests.test_gpu_engine import _engine
     monkeypatch.setenv("ZRK_OVERLAP_MIN_ROWS", "0")
     monkeypatch.setenv("ZRK_OVERLAP", "1")
-    monkeypatch.setenv("ZRK_TAIL_COMPUTE", "1" if tail == "compute" else "0")
+    monkeypatch.setenv("ZRK_TAIL_COMPUTE", "0" if tail == "side" else "1")
+    # (ZRK_TAIL_FREE=0: the call's last compaction, on the compute stream, takes the side stream's launch before it in through an
+    # event instead of standing alone with control words of its own -- calls of two launches (K = 4) and of more)
+    monkeypatch.setenv("ZRK_TAIL_FREE", "0" if tail == "compute-behind-the-side-stream" else "1")
     one, _, launched = _engine(120_000, 6, 400, seed=33, noise="philox")
     two, _, _ = _engine(120_000, 6, 400, seed=33, noise="philox")
     assert launched > 50

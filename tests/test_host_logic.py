@@ -286,3 +286,35 @@ def test_poisoned_lists_are_rejected_by_every_decoder():
             X.decode_union_bits(g, R, [0, 1000], ev)
         with pytest.raises(X.PoisonedList):
             X.decode_events(g, ev)
+
+
+def test_helper_threads_planned_from_the_cores_a_rank_has_to_itself():
+    """zrk_exchange_plan_helpers (ABI 11): two helper threads per rank where the rank has three usable cores or more to itself,
+    one below that (the side stream's thread then issues the collectives too) -- eight ranks under a 16-thread quota take the
+    two-thread-per-rank path.  Checked in a child process whose affinity mask this test sets; no GPU is touched."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from zrk_modulation_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "cores = sorted(os.sched_getaffinity(0))\n"
+        "out = []\n"
+        "for mask, world in ((cores[:8], 8), (cores[:8], 2), (cores[:6], 2), (cores[:5], 2), (cores[:3], 1), (cores[:2], 1)):\n"
+        "    os.sched_setaffinity(0, mask)\n"
+        "    out.append((len(mask), world, lib.zrk_exchange_plan_helpers(world)))\n"
+        "os.environ['ZRK_HELPERS'] = '2'\n"
+        "out.append((len(mask), 8, lib.zrk_exchange_plan_helpers(8)))\n"
+        "print(out)\n" % str(ROOT))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    got = eval(res.stdout.strip().splitlines()[-1])
+    for cores, world, helpers in got[:-1]:
+        # (the cgroup quota may cap the cores below the mask: then fewer helpers, never more)
+        assert helpers in (1, 2) and (helpers == 1 or cores // world >= 3), (cores, world, helpers)
+    by = {(c, w): h for c, w, h in got[:-1]}
+    if len(os.sched_getaffinity(0)) >= 8:
+        assert by[(8, 8)] == 1 and by[(5, 2)] == 1 and by[(2, 1)] == 1
+    assert got[-1][2] == 2                                   # ZRK_HELPERS forces

@@ -15,7 +15,7 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 # (ZRK_HOT_LIB: another build of the same ABI, for A/B runs on one box)
 LIB_PATH = Path(os.environ["ZRK_HOT_LIB"]) if os.environ.get("ZRK_HOT_LIB") else CSRC / "libzrk_hot.so"
 
-ZRK_ABI_VERSION = 10
+ZRK_ABI_VERSION = 11
 EXCHANGE_SLOTS = 8          # ZRK_EXCHANGE_SLOTS
 ZRK_MAX_RADARS = 32
 ZRK_BLOCK = 256
@@ -212,6 +212,7 @@ _PROTOTYPES = {
     "zrk_exchange_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "zrk_exchange_sync": (C.c_int, [C.c_void_p]),
     "zrk_exchange_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "zrk_exchange_plan_helpers": (C.c_int, [C.c_int]),
     "zrk_last_run_overlapped": (C.c_int, [C.c_void_p]),
     "zrk_read_sweep_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "zrk_noise_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p,

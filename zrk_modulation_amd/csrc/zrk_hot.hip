@@ -877,6 +877,9 @@ __device__ __noinline__ Vec3d replay_row_radar_phase(const char *rbp, int R, boo
     for (int r = 0; r < R; ++r) {
         const double *hot = (const double *)(rbp + offsetof(RadarBlock, hotw) + (size_t)r * sizeof(RadarHot));   // px, py, pz
         const double dx = x - hot[0], dy = y - hot[1], dz = z - hot[2];
+        // (the out-of-line function, not its body: this callee that calls keeps a frame -- its return address in a saved register, 16 bytes
+        // per lane, the pair kernel's only scratch memory -- but with the body inlined here the register allocator gives THIS function
+        // 196 vector registers, which become the kernel's: two waves per SIMD instead of seven)
         if (!visible_exact((uint64_t)(rbp + offsetof(RadarBlock, cold) + (size_t)r * sizeof(RadarCold)), dx, dy, dz)) continue;
         if (philox) {
             if (!seeded) { ns = noise_init(seed, tick, key); seeded = true; }
@@ -4741,14 +4744,16 @@ std::chrono::milliseconds helper_idle()
     return std::chrono::milliseconds(ms);
 }
 // ... and between the two a phase in which they stay runnable but give their core to whoever wants it (sched_yield between
-// looks): ZRK_HELPER_YIELD_MS, default 250.  A thread that sleeps on its condition variable is woken at the next call's entry,
+// looks): ZRK_HELPER_YIELD_MS, default 5 (bench.py asks for 250: its warm-up and timed call are tens of milliseconds apart; an
+// application that calls a few times a second would otherwise keep one or two cores per context at 100 % between its calls --
+// eight ranks per node sixteen and more).  A thread that sleeps on its condition variable is woken at the next call's entry,
 // and three times in some 150 runs of the driver's 20-tick command that took 3-12 ms instead of 50 us (the scheduler's
 // slice: the calling thread, which spins while it waits for this one, had the core the wakee was put on): a 20-tick call
 // of 0.45 ms then took 3-13.  Calls less than a quarter of a second apart -- bench.py's warm-up and timed call, any loop of
 // calls -- now find the threads awake; spin_until yields as well once a wait has lasted 50 us.
 std::chrono::milliseconds helper_yield()
 {
-    static const int ms = [] { const char *v = std::getenv("ZRK_HELPER_YIELD_MS"); return v ? std::max(0, std::atoi(v)) : 250; }();
+    static const int ms = [] { const char *v = std::getenv("ZRK_HELPER_YIELD_MS"); return v ? std::max(0, std::atoi(v)) : 5; }();
     return std::chrono::milliseconds(ms);
 }
 
@@ -4870,12 +4875,20 @@ ZRK_API int zrk_exchange_create(const char *rccl_path, const zrk_rccl_id *id, in
     // Helper threads.  By default the collectives are issued by a thread of the exchange's own (the side stream of the
     // overlapped loop has another); where the rank has fewer than three host cores to itself the side stream's thread
     // issues them too (ZRK_HELPERS=1 / 2 forces either), and a rank alone on less than two cores ... still works, slower.
-    int helpers = usable_host_cores() / std::max(1, world) < 3 ? 1 : 2;
-    if (const char *v = std::getenv("ZRK_HELPERS")) helpers = std::atoi(v) <= 1 ? 1 : 2;
-    x->one_helper = helpers == 1;
+    x->one_helper = zrk_exchange_plan_helpers(world) == 1;
     const char *no_thread = std::getenv("ZRK_EXCHANGE_THREAD");
     if (x->flag && !x->one_helper && !(no_thread && no_thread[0] == '0')) x->poster = std::thread(exchange_poster_main, x);
     return 0;
+}
+
+// How many helper threads an exchange of `world` ranks on this host starts per rank (what zrk_exchange_create decides): 2 where
+// the rank has three host cores or more to itself (the side stream's thread and a poster of the collectives), else 1 (the side
+// stream's thread issues the collectives too); ZRK_HELPERS=1|2 forces either.  No device is touched.
+ZRK_API int zrk_exchange_plan_helpers(int world)
+{
+    int helpers = usable_host_cores() / std::max(1, world) < 3 ? 1 : 2;
+    if (const char *v = std::getenv("ZRK_HELPERS")) helpers = std::atoi(v) <= 1 ? 1 : 2;
+    return helpers;
 }
 
 ZRK_API void zrk_exchange_destroy(zrk_exchange *x)

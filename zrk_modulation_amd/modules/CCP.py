@@ -69,6 +69,7 @@ class CombatControlPoint(BaseModel):
         self.host_ticks = {}            # ... and why the others went through the host loop: reason -> ticks
         self._post = None               # the dictionaries' mirror on the device (association.DeviceCommandPost), made on first use
         self._post_stale = True         # the host changed a dictionary behind its back: rebuilt from the dictionaries
+        self._post_store, self._post_rows_version = None, -1    # the table the mirror was built from, and its rows_version then
 
     # bookkeeping -------------------------------------------------------------------------------
     def add_target(self, target_ccp: TargetCCP):
@@ -117,7 +118,8 @@ class CombatControlPoint(BaseModel):
             # MissileLauncher.py:103-124) has no row: the mirror is rebuilt from the dictionaries then
             post, m = self._post, msg.missile
             if (post is not None and not self._post_stale and getattr(m, "_store", None) is not None and m._slot >= 0
-                    and getattr(m, "_frozen", None) is None and m._store.device == post.dev):
+                    and getattr(m, "_frozen", None) is None and m._store is getattr(self, "_post_store", None)
+                    and m._store.rows_version == getattr(self, "_post_rows_version", -1)):
                 post.add_missile(m._slot, self._now_s())
             else:
                 self._post_stale = True
@@ -235,6 +237,13 @@ class CombatControlPoint(BaseModel):
             self._post_speed_dev = torch.zeros(store.cap, dtype=torch.float64, device=store.device)
             self._post_speed_known = np.zeros(store.cap, bool)
             self._post_stale = True
+            self._post_store, self._post_rows_version = store, store.rows_version
+        if self._post_store is not store or self._post_rows_version != store.rows_version:
+            # rows were given out again (a salvo's dead rows dropped, padding rows revived): what the device column holds
+            # for them is the old occupant's speed
+            self._post_speed_known[:] = False
+            self._post_stale = True
+            self._post_store, self._post_rows_version = store, store.rows_version
         post = self._post
         # speed_mod is a column of the device post, written once per row when the row is first detected
         fresh = [o for o, _ in dets if not self._post_speed_known[o._slot]]

@@ -70,6 +70,7 @@ class EntityStore:
         self.cur = 0
         self.time_ms = None        # time of the last advance
         self.version = 0           # bumped whenever device positions change
+        self.rows_version = 0      # bumped whenever table rows are given out again (drop_tail_rows, overwrite_rows): per-row caches start afresh
         self._snap = {}
         # host mirrors of the immutable columns (what the handles expose as .trajectory etc.)
         self.h_ids = np.zeros(0, np.int64)
@@ -278,6 +279,7 @@ class EntityStore:
         self.n_uploaded -= j
         self.n_stepped = min(self.n_stepped, self.n_uploaded)
         self.lib.zrk_ctx_invalidate_boxes(self.ctx.handle)
+        self.rows_version += 1
         self._bump()
 
     def adopt_device_missile_rows(self, slots, target_slots):
@@ -297,6 +299,7 @@ class EntityStore:
         self.flush()
         self.h_sp[rows] = sp; self.h_vel[rows] = vel; self.h_t0[rows] = t0; self.h_pos0[rows] = sp
         self.h_kind[rows] = kind; self.h_alive[rows] = 1
+        self.rows_version += 1
         dev = self.device
         r = torch.as_tensor(rows, device=dev)
         dsp = torch.from_numpy(np.ascontiguousarray(sp.T)).to(dev)
