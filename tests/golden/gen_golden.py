@@ -19,6 +19,7 @@ Per fixture (see `capture`):
     found_ids / found_off        ids per (tick, radar) in FoundObjectsMessage order, ragged
     radar_state[T,R,2]           (current_azimuth, current_elevation) after the tick
     detonations[k,4]             (t_ms, missile_id, target_id | -1, self_detonation)
+    launch_req[k,4]              (t_ms, launcher_id, target_id, radar_id)         LAUNCH_COMMAND (the command post's requests, in order)
     launch_cmd[k,4]              (t_ms, launcher_id, missile_id, target_id)      LAUNCH_MISSILE
     launch_ok[k,3] + launch_traj[k,7]   (t_ms, missile_id, target_id), (V, start_pos, start_time)
     launch_cancel[k,2] + reasons (t_ms, missile_id), str
@@ -122,7 +123,7 @@ def capture(scene, sample_every=1):
         T = 0
         rec = dict(tick_ms=[], act_ids=[], act_off=[0], pos=[], prev=[], prev_valid=[], samp_tick=[],
                    samp_off=[0], pos_digest=[], found_ids=[], found_off=[0], radar_state=[], detonations=[],
-                   launch_cmd=[], launch_ok=[], launch_traj=[], launch_cancel=[], reasons=[], new_missile=[],
+                   launch_req=[], launch_cmd=[], launch_ok=[], launch_traj=[], launch_cancel=[], reasons=[], new_missile=[],
                    draw_ids=[], draw_off=[0], draw_vis=[], draw_pos=[], draw_type=[])
         draw_types = []
         hist = {}
@@ -155,6 +156,8 @@ def capture(scene, sample_every=1):
                 if m.type == MessageType.MISSILE_DETONATE:
                     rec["detonations"].append([t, m.missile_id, -1 if m.target_id is None else m.target_id,
                                                int(m.self_detonation)])
+                elif m.type == MessageType.LAUNCH_COMMAND:
+                    rec["launch_req"].append([t, m.receiver_id, m.target.id, m.radar_id])
                 elif m.type == MessageType.LAUNCH_MISSILE:
                     rec["launch_cmd"].append([t, m.sender_id, m.receiver_id, m.target.id])
                 elif m.type == MessageType.LAUNCH_SUCCESSFUL:
@@ -189,6 +192,7 @@ def capture(scene, sample_every=1):
         found_ids=np.array(rec["found_ids"], np.int64), found_off=np.array(rec["found_off"], np.int64),
         radar_state=np.array(rec["radar_state"], np.float64).reshape(T, R, 2),
         detonations=np.array(rec["detonations"], np.int64).reshape(-1, 4),
+        launch_req=np.array(rec["launch_req"], np.int64).reshape(-1, 4),
         launch_cmd=np.array(rec["launch_cmd"], np.int64).reshape(-1, 4),
         launch_ok=np.array(rec["launch_ok"], np.int64).reshape(-1, 3),
         launch_traj=np.array(rec["launch_traj"], np.float64).reshape(-1, 7),
@@ -338,6 +342,34 @@ def bulk_scene(seed, n=1000, n_radars=4, ticks=300, dt=100):
     return dict(name="bulk_n1000_r4", config=cfg, script=script, seed=seed, zero_noise=False)
 
 
+def battery_scene(zero_noise, seed, n=160, ticks=150, dt=200):
+    """The CLOSED loop with the reference's own command post and launchers (no script): a spread-out raid flies at a site with
+    two all-round radars and three launchers; the command post asks for the missile count on tick 0, learns it on tick 1,
+    requests launches as it links detections to tracks; launchers solve a tick later, missiles enter the air two ticks
+    after that, hit, miss, time out, and some launches are cancelled (a short-lived magazine) and their missiles re-used.
+    Pins the latencies and the order of everything the device-side battery loop composes."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    ang = g.uniform(0, 2 * np.pi, n)
+    rad = g.uniform(9e3, 26e3, n)
+    P = np.stack([rad * np.cos(ang), rad * np.sin(ang), g.uniform(800, 6000, n)], 1)
+    spd = g.uniform(140, 320, n)
+    heading = ang + np.pi + g.normal(0, 0.35, n)                   # roughly at the site
+    V = np.stack([spd * np.cos(heading), spd * np.sin(heading), g.normal(0, 8, n)], 1)
+    T = [target(1000 + i, P[i], V[i]) for i in range(n)]
+    R = [radar(10, (0, 0, 10), 0, 0, 30e3, 360, 180, 0, 0), radar(11, (1000, 1000, 10), 0, 0, 18e3, 360, 180, 0, 0)]
+    L = [launcher(3, (0, 0, 0), [(30000 + k, 1000, 150, 60) for k in range(10)]),
+         launcher(4, (2000, -1000, 0), [(40000 + k, 1200, 120, 45 if k % 3 else 6.0) for k in range(8)]),
+         # (no tight fuses here: a missile that flies past its target is linked to the target's track, and the reference's
+         # command post then raises in send_objects_to_GUI -- modules/CCP.py:259 reads `.type` of a Missile; timeouts and chases of
+         # removed targets are pinned at the L1 boundary by the `missiles` fixture)
+         launcher(5, (-1500, 2500, 5), [(50000 + k, 900, 200, 40) for k in range(12)])]
+    cfg = dict(simulation=dict(time_step=dt, duration=ticks * dt),
+               air_environment=dict(id=999, position=[0.0, 0.0, 0.0], targets=T),
+               radars=R, missile_launchers=L,
+               combat_control_point=dict(id=0, missile_launcher_ids=[3, 4, 5], radar_ids=[10, 11]))
+    return dict(name="battery_zero_noise" if zero_noise else "battery", config=cfg, script=None, seed=seed, zero_noise=zero_noise)
+
+
 def main():
     os.chdir(REF)        # the reference opens its YAML by relative path
     jobs = []
@@ -350,6 +382,8 @@ def main():
     jobs.append((missile_scene(11), 1))
     jobs.append((solve_branch_scene(5), 1))
     jobs.append((bulk_scene(1239, ticks=400), 50))
+    jobs.append((battery_scene(True, 21), 25))
+    jobs.append((battery_scene(False, 21), 25))
     for scene, every in jobs:
         out = capture(scene, sample_every=every)
         path = OUT / f"{scene['name']}.npz"
