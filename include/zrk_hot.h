@@ -289,6 +289,9 @@ typedef struct {
      * the handle's row in pos[cur ^ 1].  For tracks whose object has left the air: the reference's handle keeps the
      * prev_pos of its last step, the table keeps only the object's last position (in both buffers). */
     const double *tt_ref_fixed, *tm_ref_fixed;
+    /* (ABI 11) DEVICE [ents->capacity][3] or NULL: the same per table ROW -- where set (not NaN), what a handle of that row holds as
+     * prev_pos, whichever track holds it: the buffer zrk_ctx_keep_prev has the loop fill when a row leaves the air. */
+    const double *row_ref_fixed;
 } zrk_ccp_tracks;
 typedef struct {
     int32_t L, _pad;
@@ -324,6 +327,76 @@ int zrk_ccp_requests(zrk_ctx *ctx, const zrk_ccp_out *out /* HOST */, int64_t dm
 /* check_if_missiles_launched -> add_missile (modules/CCP.py:160-169, :102-108): the missile in table row `row` enters the
  * missile dictionary (or replaces the entry of its key), updated "now". */
 int zrk_ccp_add_missile(zrk_ctx *ctx, const zrk_ccp_tracks *tracks /* HOST */, int32_t row, double now_s, void *stream);
+
+/*
+ * (ABI 11) The battery's CLOSED loop without the host: launchers with their magazines, the two-tick way of a missile from the
+ * command post's request into the air, on the device -- what lets sweep -> lists -> zrk_ccp_step -> launches -> rows in the air
+ * run tick after tick with nothing read back.
+ *   replaces: MissileLauncher.step (modules/MissileLauncher.py:82-138: the launcher's inbox of the tick before -- cancelled
+ *             missiles back to the END of its list, launched ones announced, every request served by the missile popped from the
+ *             END of the list, :58-80), Missile.step 'ready' -> _launch (modules/Missile.py:153-160, :104-133),
+ *             check_if_missiles_launched (modules/CCP.py:160-169) and AirEnv taking a missile in (modules/AirEnv.py:42-43).
+ * Latencies as in the reference: a request the command post makes in tick b (zrk_battery_requests) is solved in
+ * tick b + 1 against the target's position after that tick's radars (zrk_battery_launchers), announced in tick b + 2 (the
+ * launcher re-uses a cancelled missile from then on; the command post takes a launched one into its missile dictionary:
+ * zrk_battery_announce) and flies from tick b + 3 (zrk_battery_activate, before that tick's sweep; its fuse timer starts there).
+ *   The magazine is part of the table from the start: table rows row0 .. row0 + n_missiles - 1 and missile-table rows
+ * 0 .. n_missiles - 1 are RESERVED (dead, status 0); the j-th missile that gets a trajectory takes table row row0 + j and
+ * missile row j -- AirEnv's list order: launcher after launcher (module order), each in the order it served its requests --
+ * so the table never grows and no count ever has to come back to the host.  A salvo lives in slot (build tick % 3) of the ring.
+ */
+typedef struct {
+    int32_t L, k_max;               /* launchers (<= 64, the command post's order = module order); requests per tick at most */
+    int32_t n_missiles, row0;
+    const double *mi_pos;           /* DEVICE [n_missiles][3]  where missile q stands: its launcher's position (Missile.pos) */
+    const double *mi_speed, *mi_period, *mi_radius;   /* DEVICE [n_missiles]  velocity_module, detonate_period, detonate_radius */
+    int32_t *stack;                 /* DEVICE [L][n_missiles]  each launcher's list of missile numbers; it pops from the end */
+    int32_t *top;                   /* DEVICE [L]              entries in each list */
+    int32_t *sal_row, *sal_launcher, *sal_missile, *sal_rc, *sal_air;   /* DEVICE [3][k_max]: target row, launcher, missile served
+                                     * (-1: none left), zrk_launch_res rc (7: no missile), air ordinal j of a launch (else -1) */
+    double *sal_V;                  /* DEVICE [3][k_max][3] */
+    int32_t *sal_count;             /* DEVICE [3][2]: requests, launches */
+    int32_t *air_count;             /* DEVICE [1]: missiles that have a trajectory (rows given out) */
+    int32_t *air_missile;           /* DEVICE [n_missiles]: missile number of air ordinal j */
+    double *speed_mod;              /* DEVICE [ents->capacity]: the command post's obj.speed_mod column; rows that get a trajectory
+                                     * are written (Missile.speed_mod = velocity_module, modules/Missile.py:28) */
+    /* logs for the host, read after the loop: every solve in order -- {tick, missile, target row, rc, air ordinal} and V -- and
+     * every detonation -- {tick, missile's table row, target's table row or -1}; log_count = {solves, detonations} */
+    int32_t *log_solve;             /* DEVICE [log_cap][5] */
+    double *log_V;                  /* DEVICE [log_cap][3] */
+    int32_t *log_event;             /* DEVICE [log_cap][3] */
+    int32_t *log_count;             /* DEVICE [2] */
+    int32_t log_cap, _pad;
+} zrk_battery;
+
+/* obj.speed_mod of the first n rows (targets): |velocity| rounded as numpy's norm rounds it (modules/AirObject.py:35-36). */
+int zrk_battery_speed_column(zrk_ctx *ctx, const zrk_entities *ents, int64_t n, double *speed_mod /* DEVICE */, void *stream);
+/* Before the sweep of tick `tick`: the launches solved in tick - 2 enter the air (flag up, missile status 1; the loop's box records
+ * of their row blocks start afresh). */
+int zrk_battery_activate(zrk_ctx *ctx, const zrk_battery *bat, const zrk_entities *ents, const zrk_missiles *mis, int64_t tick,
+                         void *workspace, void *stream);
+/* After the sweep of tick `tick`: every launcher's step -- the salvo of tick - 2: cancelled missiles back on the lists; the salvo
+ * of tick - 1: a missile popped per request, solved against pos[cur], the launches given their rows (trajectory written, still
+ * dead) in AirEnv's order. */
+int zrk_battery_launchers(zrk_ctx *ctx, const zrk_battery *bat, const zrk_entities *ents, int cur, const zrk_missiles *mis,
+                          int64_t tick, int64_t time_ms, void *stream);
+/* The command post's check_if_missiles_launched of tick `tick`: the launches solved in tick - 1, in order, into its missile
+ * dictionary. */
+int zrk_battery_announce(zrk_ctx *ctx, const zrk_battery *bat, const zrk_ccp_tracks *tracks, int64_t tick, double now_s, void *stream);
+/* The detections of a tick in FoundObjectsMessage order, every object once (modules/CCP.py:406-417), as table rows: from the R
+ * lists of zrk_run_ticks (det_idx / det_cnt, list indices) and the tick's masks (indexed by list index): an entry belongs to the
+ * first radar that saw it.  row_of_list (DEVICE, may be NULL: the table is in list order) maps list indices to rows. */
+int zrk_battery_sequence(zrk_ctx *ctx, const int32_t *det_idx, int64_t det_stride, const int32_t *det_cnt, int R, int32_t base_index,
+                         const uint32_t *vis_mask, const int32_t *row_of_list, int32_t *seq /* DEVICE [seq_cap] out */,
+                         int32_t *seq_count /* DEVICE [1] out */, int64_t seq_cap, void *stream);
+/* The launch decisions of the zrk_ccp_step of tick `tick` as that tick's salvo: per launcher (module order), each in request order --
+ * the order the launchers will serve them in -- with the command post's own view of who asked for what. */
+int zrk_battery_requests(zrk_ctx *ctx, const zrk_battery *bat, const zrk_ccp_out *out, int64_t dmax, int64_t tick, void *stream);
+/* The tick's detonations (zrk_missiles::ev_*) appended to the log. */
+int zrk_battery_log_events(zrk_ctx *ctx, const zrk_battery *bat, const zrk_missiles *mis, int64_t tick, void *stream);
+/* Rows that leave the air keep the prev_pos their handle held in buf ([capacity][3], DEVICE, the caller fills it with NaN; NULL:
+ * off) -- for zrk_ccp_tracks::row_ref_fixed.  Plain loop only (calls of fewer than four ticks). */
+int zrk_ctx_keep_prev(zrk_ctx *ctx, double *buf);
 
 /* Static scan parameters of one radar (modules/Radar.py:13-42): what
  * move_to_next_sector_circular reads besides the current angles. */

@@ -30,7 +30,19 @@ class HotPathUnavailable(RuntimeError):
 class ZrkCcpTracks(C.Structure):
     _fields_ = [("capacity", C.c_int64), ("tt_key", C.c_void_p), ("tt_obj", C.c_void_p), ("tt_upd", C.c_void_p),
                 ("tt_follow", C.c_void_p), ("tm_key", C.c_void_p), ("tm_obj", C.c_void_p), ("tm_upd", C.c_void_p),
-                ("counts", C.c_void_p), ("key_tt", C.c_void_p), ("tt_ref_fixed", C.c_void_p), ("tm_ref_fixed", C.c_void_p)]
+                ("counts", C.c_void_p), ("key_tt", C.c_void_p), ("tt_ref_fixed", C.c_void_p), ("tm_ref_fixed", C.c_void_p),
+                ("row_ref_fixed", C.c_void_p)]
+
+
+class ZrkBattery(C.Structure):
+    """include/zrk_hot.h: zrk_battery"""
+    _fields_ = [("L", C.c_int32), ("k_max", C.c_int32), ("n_missiles", C.c_int32), ("row0", C.c_int32),
+                ("mi_pos", C.c_void_p), ("mi_speed", C.c_void_p), ("mi_period", C.c_void_p), ("mi_radius", C.c_void_p),
+                ("stack", C.c_void_p), ("top", C.c_void_p),
+                ("sal_row", C.c_void_p), ("sal_launcher", C.c_void_p), ("sal_missile", C.c_void_p), ("sal_rc", C.c_void_p), ("sal_air", C.c_void_p),
+                ("sal_V", C.c_void_p), ("sal_count", C.c_void_p), ("air_count", C.c_void_p), ("air_missile", C.c_void_p), ("speed_mod", C.c_void_p),
+                ("log_solve", C.c_void_p), ("log_V", C.c_void_p), ("log_event", C.c_void_p), ("log_count", C.c_void_p),
+                ("log_cap", C.c_int32), ("_pad", C.c_int32)]
 
 
 class ZrkCcpLaunchers(C.Structure):
@@ -213,6 +225,17 @@ _PROTOTYPES = {
     "zrk_exchange_sync": (C.c_int, [C.c_void_p]),
     "zrk_exchange_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "zrk_exchange_plan_helpers": (C.c_int, [C.c_int]),
+    "zrk_ctx_keep_prev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "zrk_battery_speed_column": (C.c_int, [C.c_void_p, C.POINTER(ZrkEntities), C.c_int64, C.c_void_p, C.c_void_p]),
+    "zrk_battery_activate": (C.c_int, [C.c_void_p, C.POINTER(ZrkBattery), C.POINTER(ZrkEntities), C.POINTER(ZrkMissiles), C.c_int64, C.c_void_p,
+                                       C.c_void_p]),
+    "zrk_battery_launchers": (C.c_int, [C.c_void_p, C.POINTER(ZrkBattery), C.POINTER(ZrkEntities), C.c_int, C.POINTER(ZrkMissiles), C.c_int64,
+                                        C.c_int64, C.c_void_p]),
+    "zrk_battery_announce": (C.c_int, [C.c_void_p, C.POINTER(ZrkBattery), C.POINTER(ZrkCcpTracks), C.c_int64, C.c_double, C.c_void_p]),
+    "zrk_battery_sequence": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int64, C.c_void_p]),
+    "zrk_battery_requests": (C.c_int, [C.c_void_p, C.POINTER(ZrkBattery), C.POINTER(ZrkCcpOut), C.c_int64, C.c_int64, C.c_void_p]),
+    "zrk_battery_log_events": (C.c_int, [C.c_void_p, C.POINTER(ZrkBattery), C.POINTER(ZrkMissiles), C.c_int64, C.c_void_p]),
     "zrk_last_run_overlapped": (C.c_int, [C.c_void_p]),
     "zrk_read_sweep_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "zrk_noise_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p,

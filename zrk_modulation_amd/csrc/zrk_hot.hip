@@ -223,6 +223,10 @@ struct MissileArgs {
     // removed rows' list indices to as they decide the first tick's events: rm[0] = entries, rm_cap of them fit
     int32_t *rm;
     int32_t rm_cap, _pad4;
+    // where a row that leaves the air keeps the prev_pos its handle held (zrk_ctx_keep_prev: [capacity][3], NaN = still in the air):
+    // the tombstone below makes both position buffers the row's last position; the reference's handle keeps pos AND prev_pos of
+    // its last step, and the command post's link_object reads the latter of every track it ever made (modules/CCP.py:196)
+    double *frozen_prev;
 };
 
 // Dispatch order of the next sweep.  The sweep's duration is set by the expensive waves (rows inside some
@@ -2446,7 +2450,8 @@ __device__ __forceinline__ void missile_finish_block(int *s_wave, const uint8_t 
                                                      int32_t *__restrict__ ev_count, int apply, uint8_t *alive,
                                                      const double *pos_cur, double *pos_prev, int64_t cap,
                                                      int64_t *ev_wire = nullptr, int ev_wire_cap = 0, int64_t gid0 = 0,
-                                                     const int32_t *__restrict__ lidx = nullptr, uint32_t *clear_vis = nullptr)
+                                                     const int32_t *__restrict__ lidx = nullptr, uint32_t *clear_vis = nullptr,
+                                                     double *frozen_prev = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (int)((m + 1023) / 1024);                 // consecutive rows per thread (<= kMissileItems)
@@ -2458,6 +2463,19 @@ __device__ __forceinline__ void missile_finish_block(int *s_wave, const uint8_t 
         const int64_t row = row0 + k;
         codes[k] = (k < per && row < m) ? ev_code[row] : 0;
         cnt += codes[k] != 0;
+    }
+    // (zrk_ctx_keep_prev) what the rows this tick removes held as prev_pos, BEFORE any tombstone overwrites that buffer: two
+    // missiles may remove one target in the same tick, from different threads -- both then keep the same value; the barrier of
+    // the scan below stands between this and the tombstones
+    if (frozen_prev && apply) {
+#pragma unroll
+        for (int k = 0; k < kMissileItems; ++k)
+            if (codes[k]) {
+                const int64_t row = row0 + k;
+                const int32_t ms = m_slot[row], ts = (codes[k] == 1) ? m_tgt[row] : -1;
+                if (alive[ms]) for (int c = 0; c < 3; ++c) frozen_prev[3 * (int64_t)ms + c] = pos_prev[c * cap + ms];
+                if (ts >= 0 && alive[ts]) for (int c = 0; c < 3; ++c) frozen_prev[3 * (int64_t)ts + c] = pos_prev[c * cap + ts];
+            }
     }
     int incl = cnt;
 #pragma unroll
@@ -2525,7 +2543,7 @@ __device__ void missile_kills(const MissileArgs &M, int part)
 __device__ void missile_finish_entry(int *s_wave, const MissileArgs &M)
 {
     missile_finish_block(s_wave, M.ev_code, M.m_slot, M.m_tgt, M.m, M.ev_missile, M.ev_target, M.ev_count, M.apply, M.alive,
-                         M.pos_cur, M.pos_prev, M.cap, M.ev_wire, M.ev_wire_cap, M.gid0, M.lidx, M.clear_vis);
+                         M.pos_cur, M.pos_prev, M.cap, M.ev_wire, M.ev_wire_cap, M.gid0, M.lidx, M.clear_vis, M.frozen_prev);
 }
 
 // Ordered event list from ev_code: one workgroup walks the (short) missile table in row order.
@@ -2618,21 +2636,16 @@ __global__ void k_apply_events(uint8_t *alive, const double *src, double *dst, i
     }
 }
 
-// Missile._calculate_trajectory_params, one thread per request (modules/Missile.py:35-102).
-__global__ void k_launch_solve(const double *__restrict__ vel, const uint8_t *__restrict__ kind,
-                               const double *__restrict__ pos, int64_t cap, const zrk_launch_req *__restrict__ req,
-                               zrk_launch_res *__restrict__ res, int64_t k)
+// Missile._calculate_trajectory_params for one request (modules/Missile.py:35-102).
+__device__ __forceinline__ zrk_launch_res launch_solve_one(const double *__restrict__ vel, const uint8_t *__restrict__ kind,
+                                                           const double *__restrict__ pos, int64_t cap, const zrk_launch_req &rq)
 {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= k) return;
-    const zrk_launch_req rq = req[q];
     const int32_t j = rq.target_slot;
     zrk_launch_res out;
     out.rc = 0; out._pad = 0; out.velocity[0] = out.velocity[1] = out.velocity[2] = 0.0; out.t_hit = 0.0;
     if (j < 0 || j >= cap) {                       // no such row (the padding behind a device-built request list): a failed request
         out.rc = 6;
-        res[q] = out;
-        return;
+        return out;
     }
     // target.velocity (unit) * target.speed_mod, modules/AirObject.py:35-36, modules/Missile.py:58.
     // A missile used as a target has velocity NaN forever (Missile.py:26-27).
@@ -2679,7 +2692,17 @@ __global__ void k_launch_solve(const double *__restrict__ vel, const uint8_t *__
         out.velocity[0] = w0 / nrm * v0; out.velocity[1] = w1 / nrm * v0; out.velocity[2] = w2 / nrm * v0;
         out.t_hit = t;
     }
-    res[q] = out;
+    return out;
+}
+
+// ... one thread per request
+__global__ void k_launch_solve(const double *__restrict__ vel, const uint8_t *__restrict__ kind,
+                               const double *__restrict__ pos, int64_t cap, const zrk_launch_req *__restrict__ req,
+                               zrk_launch_res *__restrict__ res, int64_t k)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= k) return;
+    res[q] = launch_solve_one(vel, kind, pos, cap, req[q]);
 }
 
 // The successful launches of a salvo enter the air (Missile._launch, modules/Missile.py:104-133; MissileLauncher
@@ -3214,8 +3237,12 @@ __global__ void k_ccp_gather(const CcpStepArgs A)
         // position, in both buffers -- the caller supplies what the handle held: zrk_ccp_tracks::ref_fixed)
         const double *fixed = missile ? A.trk.tm_ref_fixed : A.trk.tt_ref_fixed;
         const int t = missile ? (int)(g - Tt) : (int)g;
+        // ... or, per ROW, what the loop itself kept when the row left the air (zrk_ctx_keep_prev)
+        const double *rowfix = A.trk.row_ref_fixed;
         if (fixed && fixed[3 * t] == fixed[3 * t]) {                 // (not NaN: set)
             A.trk_ref[3 * g] = fixed[3 * t]; A.trk_ref[3 * g + 1] = fixed[3 * t + 1]; A.trk_ref[3 * g + 2] = fixed[3 * t + 2];
+        } else if (rowfix && rowfix[3 * (int64_t)h] == rowfix[3 * (int64_t)h]) {
+            A.trk_ref[3 * g] = rowfix[3 * (int64_t)h]; A.trk_ref[3 * g + 1] = rowfix[3 * (int64_t)h + 1]; A.trk_ref[3 * g + 2] = rowfix[3 * (int64_t)h + 2];
         } else {
             const bool none = A.t0[h] == A.now_s;                    // AirObject.py:41: prev_pos is None in the object's first tick
             // a missile track falls back to pos (:211-213); for a target track the reference raises (None - array): status 2
@@ -3486,6 +3513,229 @@ __global__ void k_ccp_add_missile(const zrk_ccp_tracks trk, int32_t row, double 
         }
         trk.tm_obj[t] = row; trk.tm_upd[t] = now_s;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The battery's closed loop on the device (include/zrk_hot.h: zrk_battery): launchers, magazines and the two-tick way of a
+// missile from the command post's request into the air, with the reference's latencies and orders.  Everything here is
+// event-rate work on a few thousand requests at most: one workgroup per step, ordered by ballot scans.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_battery_speed(const double *__restrict__ vel, int64_t cap, int64_t n, double *__restrict__ speed)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double vx = vel[i], vy = vel[cap + i], vz = vel[2 * cap + i];
+    speed[i] = sqrt(dot3(vx, vy, vz, vx, vy, vz));            // np.linalg.norm of a 3-vector (modules/AirObject.py:36)
+}
+
+__device__ __forceinline__ int battery_requests_of(const zrk_battery &B, int slot)
+{
+    const int n = B.sal_count[2 * slot];
+    return n < B.k_max ? n : B.k_max;
+}
+
+// AirEnv takes the launched missiles in (modules/AirEnv.py:42-43): their rows have held their trajectories since the solve
+__global__ void k_battery_activate(const zrk_battery B, int slot, uint8_t *alive, uint8_t *m_status, WaveBox *boxes)
+{
+    const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (q >= battery_requests_of(B, slot)) return;
+    const int j = B.sal_air[(int64_t)slot * B.k_max + q];
+    if (j < 0) return;
+    const int64_t row = (int64_t)B.row0 + j;
+    alive[row] = 1;
+    m_status[j] = 1;
+    // (a row block that held nobody is on record as empty for good: its record starts afresh)
+    if (boxes) boxes[row / ZRK_BLOCK].state = 0u;
+}
+
+// MissileLauncher.step of every launcher (one thread each): last tick's cancelled missiles go back to the end of the list
+// (MissileLauncher.py:126-129) -- before this tick's requests, whose messages were posted later (the command post steps after
+// the launchers) --, then every request is served by the missile popped from the end (:58-80)
+__global__ void k_battery_launchers(const zrk_battery B, int slot_back, int slot_serve)
+{
+    const int l = (int)threadIdx.x;
+    if (l >= B.L) return;
+    int32_t *stack = B.stack + (int64_t)l * B.n_missiles;
+    int top = B.top[l];
+    if (slot_back >= 0) {
+        const int nb = battery_requests_of(B, slot_back);
+        const int64_t o = (int64_t)slot_back * B.k_max;
+        for (int q = 0; q < nb; ++q)
+            if (B.sal_launcher[o + q] == l && B.sal_rc[o + q] != 0 && B.sal_missile[o + q] >= 0 && top < B.n_missiles) stack[top++] = B.sal_missile[o + q];
+    }
+    if (slot_serve >= 0) {
+        const int ns = battery_requests_of(B, slot_serve);
+        const int64_t o = (int64_t)slot_serve * B.k_max;
+        for (int q = 0; q < ns; ++q)
+            if (B.sal_launcher[o + q] == l) B.sal_missile[o + q] = top > 0 ? stack[--top] : -1;
+    }
+    B.top[l] = top;
+}
+
+// Missile._launch of every served request (modules/Missile.py:104-133): against the target's position as it stands now
+__global__ void k_battery_solve(const zrk_battery B, int slot, const double *__restrict__ vel, const uint8_t *__restrict__ kind,
+                                const double *__restrict__ pos, int64_t cap)
+{
+    const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (q >= battery_requests_of(B, slot)) return;
+    const int64_t o = (int64_t)slot * B.k_max + q;
+    const int m = B.sal_missile[o];
+    zrk_launch_res res;
+    res.rc = 7; res._pad = 0; res.velocity[0] = res.velocity[1] = res.velocity[2] = 0.0; res.t_hit = 0.0;    // 7: the launcher had no missile left
+    if (m >= 0) {
+        zrk_launch_req rq;
+        rq.target_slot = B.sal_row[o]; rq._pad = 0;
+        rq.missile_pos[0] = B.mi_pos[3 * m]; rq.missile_pos[1] = B.mi_pos[3 * m + 1]; rq.missile_pos[2] = B.mi_pos[3 * m + 2];
+        rq.speed = B.mi_speed[m]; rq.period = B.mi_period[m]; rq.radius = B.mi_radius[m];
+        res = launch_solve_one(vel, kind, pos, cap, rq);
+    }
+    B.sal_rc[o] = res.rc;
+    B.sal_V[3 * o] = res.velocity[0]; B.sal_V[3 * o + 1] = res.velocity[1]; B.sal_V[3 * o + 2] = res.velocity[2];
+}
+
+// exclusive ranks of the set flags over [0, n), in order, by ONE workgroup of 1024 threads: rank (or -1) per thread and step
+// through `visit(q, rank)`; returns the number of set flags
+template <class Flag, class Visit>
+__device__ __forceinline__ int ordered_ranks_1024(int n, int *s_w /* [16] */, int *s_carry, Flag flag, Visit visit)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) *s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int q = base + tid;
+        const bool f = q < n && flag(q);
+        const unsigned long long b = __ballot(f);
+        if (lane == 0) s_w[wave] = (int)__popcll(b);
+        __syncthreads();
+        int off = *s_carry, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) off += s_w[w]; tot += s_w[w]; }
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        if (q < n) visit(q, f ? off + (int)__popcll(b & below) : -1);
+        __syncthreads();
+        if (tid == 0) *s_carry += tot;
+        __syncthreads();
+    }
+    const int total = *s_carry;
+    __syncthreads();                                  // (the next call clears the word)
+    return total;
+}
+
+// The launches get their rows, in AirEnv's order: the requests stand launcher after launcher, each in the order it was served, and
+// that is the order the launchers announce their missiles in a tick later (MissileLauncher.py:103-124 -> AirEnv.py:42-43)
+__global__ __launch_bounds__(1024) void k_battery_assign(const zrk_battery B, int slot, int tick, double now_s, double *sp, double *vel,
+                                                         double *t0, uint8_t *alive, uint8_t *kind, double *pos0, double *pos1, int64_t cap,
+                                                         int32_t *m_slot, int32_t *m_tgt, double *m_radius, double *m_period, uint8_t *m_status)
+{
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const int n = battery_requests_of(B, slot);
+    const int64_t o = (int64_t)slot * B.k_max;
+    const int base_air = *B.air_count, base_log = B.log_count[0];
+    const int total = ordered_ranks_1024(n, s_w, &s_carry, [&](int q) { return B.sal_rc[o + q] == 0; }, [&](int q, int rank) {
+        const int m = B.sal_missile[o + q];
+        int j = rank >= 0 ? base_air + rank : -1;
+        if (j >= B.n_missiles) j = -1;                       // (cannot happen: every launch is a missile of the magazine)
+        B.sal_air[o + q] = j;
+        if (j >= 0) {
+            const int64_t row = (int64_t)B.row0 + j;
+            for (int c = 0; c < 3; ++c) {
+                sp[c * cap + row] = B.mi_pos[3 * m + c]; vel[c * cap + row] = B.sal_V[3 * (o + q) + c];
+                pos0[c * cap + row] = B.mi_pos[3 * m + c]; pos1[c * cap + row] = B.mi_pos[3 * m + c];
+            }
+            t0[row] = now_s; alive[row] = 0; kind[row] = 1;
+            m_slot[j] = (int32_t)row; m_tgt[j] = B.sal_row[o + q]; m_radius[j] = B.mi_radius[m]; m_period[j] = B.mi_period[m]; m_status[j] = 0;
+            B.speed_mod[row] = B.mi_speed[m];               // Missile.speed_mod = velocity_module (modules/Missile.py:28)
+            B.air_missile[j] = m;
+        }
+        const int64_t lg = (int64_t)base_log + q;
+        if (lg < B.log_cap) {
+            B.log_solve[5 * lg] = tick; B.log_solve[5 * lg + 1] = m; B.log_solve[5 * lg + 2] = B.sal_row[o + q];
+            B.log_solve[5 * lg + 3] = B.sal_rc[o + q]; B.log_solve[5 * lg + 4] = j;
+            for (int c = 0; c < 3; ++c) B.log_V[3 * lg + c] = B.sal_V[3 * (o + q) + c];
+        }
+    });
+    if (threadIdx.x == 0) {
+        *B.air_count = base_air + total < B.n_missiles ? base_air + total : B.n_missiles;
+        B.sal_count[2 * slot + 1] = total;
+        B.log_count[0] = base_log + n;
+    }
+}
+
+// check_if_missiles_launched (modules/CCP.py:160-169): the launches of the salvo, in order, into the missile dictionary
+__global__ __launch_bounds__(1024) void k_battery_announce(const zrk_battery B, int slot, const zrk_ccp_tracks trk, double now_s)
+{
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const int n = battery_requests_of(B, slot);
+    const int64_t o = (int64_t)slot * B.k_max;
+    const int base = trk.counts[1];
+    const int total = ordered_ranks_1024(n, s_w, &s_carry, [&](int q) { return B.sal_air[o + q] >= 0; }, [&](int q, int rank) {
+        const int t = rank >= 0 ? base + rank : -1;
+        if (t >= 0 && t < trk.capacity) {
+            const int32_t row = B.row0 + B.sal_air[o + q];
+            trk.tm_key[t] = row; trk.tm_obj[t] = row; trk.tm_upd[t] = now_s;
+        }
+    });
+    if (threadIdx.x == 0) trk.counts[1] = base + total < (int)trk.capacity ? base + total : (int)trk.capacity;
+}
+
+// FoundObjectsMessage after FoundObjectsMessage, every object at its first mention (modules/CCP.py:406-417): an entry of radar r's
+// list is a first mention when r is the lowest radar that saw the row
+__global__ __launch_bounds__(1024) void k_battery_sequence(const int32_t *__restrict__ det_idx, int64_t det_stride, const int32_t *__restrict__ det_cnt,
+                                                           int R, int32_t base_index, const uint32_t *__restrict__ vis,
+                                                           const int32_t *__restrict__ row_of_list, int32_t *__restrict__ seq, int32_t *seq_count,
+                                                           int64_t seq_cap)
+{
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    int run = 0;
+    for (int r = 0; r < R; ++r) {
+        const int cnt = det_cnt[r] < det_stride ? det_cnt[r] : (int)det_stride;
+        const int32_t *list = det_idx + (int64_t)r * det_stride;
+        const int run0 = run;
+        run += ordered_ranks_1024(cnt, s_w, &s_carry, [&](int k) { const uint32_t m = vis[list[k] - base_index]; return (m & (0u - m)) == (1u << r); },
+                                  [&](int k, int rank) {
+            if (rank >= 0 && run0 + rank < seq_cap) { const int32_t li = list[k] - base_index; seq[run0 + rank] = row_of_list ? row_of_list[li] : li; }
+        });
+    }
+    if (threadIdx.x == 0) *seq_count = run < seq_cap ? run : (int32_t)seq_cap;
+}
+
+// The command post's requests of the tick as the salvo the launchers will serve: launcher after launcher (module order), each in
+// request order.  The requesters are first squeezed, in order, into the slot's own (still unused) missile / air columns.
+__global__ __launch_bounds__(1024) void k_battery_requests(const zrk_battery B, int slot, const zrk_ccp_out out, int64_t dmax)
+{
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    int D = out.count[0];
+    D = D < (int)dmax ? D : (int)dmax;
+    const int64_t o = (int64_t)slot * B.k_max;
+    int32_t *tmp_obj = B.sal_missile + o, *tmp_l = B.sal_air + o;
+    int asked = ordered_ranks_1024(D, s_w, &s_carry, [&](int d) { return out.launcher[d] >= 0; }, [&](int d, int rank) {
+        if (rank >= 0 && rank < B.k_max) { tmp_obj[rank] = out.obj[d]; tmp_l[rank] = out.launcher[d]; }
+    });
+    asked = asked < B.k_max ? asked : B.k_max;
+    __syncthreads();
+    int run = 0;
+    for (int l = 0; l < B.L; ++l) {
+        const int run0 = run;
+        run += ordered_ranks_1024(asked, s_w, &s_carry, [&](int q) { return tmp_l[q] == l; }, [&](int q, int rank) {
+            if (rank >= 0) { B.sal_row[o + run0 + rank] = tmp_obj[q]; B.sal_launcher[o + run0 + rank] = l; }
+        });
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < B.k_max; q += 1024) { B.sal_missile[o + q] = -1; B.sal_air[o + q] = -1; B.sal_rc[o + q] = (q < run) ? 7 : 6; }
+    if (threadIdx.x == 0) { B.sal_count[2 * slot] = run; B.sal_count[2 * slot + 1] = 0; }
+}
+
+__global__ void k_battery_log_events(const zrk_battery B, const int32_t *__restrict__ ev_missile, const int32_t *__restrict__ ev_target,
+                                     const int32_t *ev_count, int tick)
+{
+    const int n = *ev_count, base = B.log_count[1];
+    for (int j = threadIdx.x; j < n; j += blockDim.x)
+        if (base + j < B.log_cap) { B.log_event[3 * (int64_t)(base + j)] = tick; B.log_event[3 * (int64_t)(base + j) + 1] = ev_missile[j]; B.log_event[3 * (int64_t)(base + j) + 2] = ev_target[j]; }
+    __syncthreads();
+    if (threadIdx.x == 0) B.log_count[1] = base + n;
 }
 
 __global__ void k_selftest_math(int op, const double *a, const double *b, double *y, int64_t n)
@@ -3805,6 +4055,7 @@ struct zrk_ctx {
     bool tail_by_event = false;        // ZRK_TAIL_EVENT=1: the last compaction of a call is released by an event recorded behind the last sweep, not by
                                        // a launch that raises the host word (medians equal, 24.6 / 24.7 us per tick in 20-step runs; the event has the worse tail)
     bool tail_free = true;             // ... without waiting for the side stream's launch before it (Side::tail_ws; ZRK_TAIL_FREE=0: an event)
+    double *frozen_prev = nullptr;     // zrk_ctx_keep_prev: where rows that leave the air keep their handle's prev_pos (plain loop)
     bool tail_on_compute = true;       // the last compaction of a call goes to the compute stream, behind the last sweep (SideItem::on_compute);
                                        // ZRK_TAIL_COMPUTE=0: to the side stream like the others, released as above.  Calls with an exchange: always the latter
 };
@@ -3978,6 +4229,7 @@ MissileArgs missile_args(const zrk_entities *e, int cur, const zrk_missiles *mis
     M.pos_abs[0] = e->pos[0]; M.pos_abs[1] = e->pos[1];
     M.ev_code2 = nullptr; M.mark2 = 0; M.bar_target = 0; M.bar = nullptr; M.t2 = M.t; M.clear_vis = nullptr;
     M.rm = nullptr; M.rm_cap = 0; M._pad4 = 0;
+    M.frozen_prev = nullptr;
     return M;
 }
 
@@ -4576,6 +4828,102 @@ ZRK_API int zrk_ccp_add_missile(zrk_ctx *ctx, const zrk_ccp_tracks *trk, int32_t
 
 // What every bounded host wait of the library does when its condition never comes: `what` 0 the spin helper itself, 1 a
 // ring the helper thread never empties.  No device needed (tests/test_host_logic.py).
+// ---- the battery's closed loop (include/zrk_hot.h: zrk_battery) ----
+namespace {
+int battery_check(zrk_ctx *ctx, const zrk_battery *b, const char *who)
+{
+    if (!ctx || !b) return fail(ctx, ZRK_E_INVALID, std::string(who) + ": null argument");
+    if (b->L < 0 || b->L > 64 || b->k_max < 1 || b->n_missiles < 0 || b->row0 < 0 || b->log_cap < 0 || !b->sal_row || !b->sal_launcher ||
+        !b->sal_missile || !b->sal_rc || !b->sal_air || !b->sal_V || !b->sal_count || !b->air_count || !b->air_missile || !b->stack ||
+        !b->top || !b->mi_pos || !b->mi_speed || !b->mi_period || !b->mi_radius || !b->speed_mod || !b->log_solve || !b->log_V ||
+        !b->log_event || !b->log_count)
+        return fail(ctx, ZRK_E_INVALID, std::string(who) + ": incomplete battery description");
+    return 0;
+}
+inline int battery_slot(int64_t build_tick) { return build_tick < 0 ? -1 : (int)(build_tick % 3); }
+}  // namespace
+
+ZRK_API int zrk_ctx_keep_prev(zrk_ctx *ctx, double *buf)
+{
+    if (!ctx) return ZRK_E_INVALID;
+    ctx->frozen_prev = buf;
+    return 0;
+}
+
+ZRK_API int zrk_battery_speed_column(zrk_ctx *ctx, const zrk_entities *e, int64_t n, double *speed_mod, void *stream)
+{
+    if (!ctx || !e || !speed_mod || n < 0 || n > e->capacity) return fail(ctx, ZRK_E_INVALID, "zrk_battery_speed_column: bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_battery_speed, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, e->velocity, e->capacity, n, speed_mod);
+    return check_launch(ctx, "k_battery_speed");
+}
+
+ZRK_API int zrk_battery_activate(zrk_ctx *ctx, const zrk_battery *b, const zrk_entities *e, const zrk_missiles *mis, int64_t tick,
+                                 void *workspace, void *stream)
+{
+    if (int rc = battery_check(ctx, b, "zrk_battery_activate")) return rc;
+    if (!e || !mis) return fail(ctx, ZRK_E_INVALID, "zrk_battery_activate: null argument");
+    if (tick < 3) return 0;                                   // (the first requests are made in tick 0 at the earliest)
+    if ((int64_t)b->row0 + b->n_missiles > e->capacity) return fail(ctx, ZRK_E_INVALID, "zrk_battery_activate: the magazine's rows are not in the table");
+    WaveBox *boxes = workspace ? carve(workspace, 0, e->capacity).boxes : nullptr;
+    hipLaunchKernelGGL(k_battery_activate, dim3(nblocks(b->k_max, 256)), dim3(256), 0, (hipStream_t)stream, *b, battery_slot(tick - 3), e->alive,
+                       mis->status, boxes);
+    return check_launch(ctx, "k_battery_activate");
+}
+
+ZRK_API int zrk_battery_launchers(zrk_ctx *ctx, const zrk_battery *b, const zrk_entities *e, int cur, const zrk_missiles *mis, int64_t tick,
+                                  int64_t time_ms, void *stream)
+{
+    if (int rc = battery_check(ctx, b, "zrk_battery_launchers")) return rc;
+    if (!e || !mis || (cur != 0 && cur != 1)) return fail(ctx, ZRK_E_INVALID, "zrk_battery_launchers: bad argument");
+    if (tick < 1) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int serve = battery_slot(tick - 1), back = battery_slot(tick - 2);
+    hipLaunchKernelGGL(k_battery_launchers, dim3(1), dim3(64), 0, s, *b, back, serve);
+    hipLaunchKernelGGL(k_battery_solve, dim3(nblocks(b->k_max, 64)), dim3(64), 0, s, *b, serve, e->velocity, e->kind, e->pos[cur], e->capacity);
+    hipLaunchKernelGGL(k_battery_assign, dim3(1), dim3(1024), 0, s, *b, serve, (int)tick, (double)time_ms / 1000.0, const_cast<double *>(e->start_pos),
+                       const_cast<double *>(e->velocity), const_cast<double *>(e->start_time), e->alive, const_cast<uint8_t *>(e->kind), e->pos[0],
+                       e->pos[1], e->capacity, const_cast<int32_t *>(mis->slot), const_cast<int32_t *>(mis->target),
+                       const_cast<double *>(mis->radius), mis->period, mis->status);
+    return check_launch(ctx, "zrk_battery_launchers");
+}
+
+ZRK_API int zrk_battery_announce(zrk_ctx *ctx, const zrk_battery *b, const zrk_ccp_tracks *trk, int64_t tick, double now_s, void *stream)
+{
+    if (int rc = battery_check(ctx, b, "zrk_battery_announce")) return rc;
+    if (!trk) return fail(ctx, ZRK_E_INVALID, "zrk_battery_announce: null argument");
+    if (tick < 2) return 0;
+    hipLaunchKernelGGL(k_battery_announce, dim3(1), dim3(1024), 0, (hipStream_t)stream, *b, battery_slot(tick - 2), *trk, now_s);
+    return check_launch(ctx, "k_battery_announce");
+}
+
+ZRK_API int zrk_battery_sequence(zrk_ctx *ctx, const int32_t *det_idx, int64_t det_stride, const int32_t *det_cnt, int R, int32_t base_index,
+                                 const uint32_t *vis_mask, const int32_t *row_of_list, int32_t *seq, int32_t *seq_count, int64_t seq_cap,
+                                 void *stream)
+{
+    if (!ctx || !det_idx || !det_cnt || !vis_mask || !seq || !seq_count || R < 0 || R > ZRK_MAX_RADARS || det_stride < 0 || seq_cap < 0)
+        return fail(ctx, ZRK_E_INVALID, "zrk_battery_sequence: bad argument");
+    hipLaunchKernelGGL(k_battery_sequence, dim3(1), dim3(1024), 0, (hipStream_t)stream, det_idx, det_stride, det_cnt, R, base_index, vis_mask,
+                       row_of_list, seq, seq_count, seq_cap);
+    return check_launch(ctx, "k_battery_sequence");
+}
+
+ZRK_API int zrk_battery_requests(zrk_ctx *ctx, const zrk_battery *b, const zrk_ccp_out *out, int64_t dmax, int64_t tick, void *stream)
+{
+    if (int rc = battery_check(ctx, b, "zrk_battery_requests")) return rc;
+    if (!out || tick < 0) return fail(ctx, ZRK_E_INVALID, "zrk_battery_requests: bad argument");
+    hipLaunchKernelGGL(k_battery_requests, dim3(1), dim3(1024), 0, (hipStream_t)stream, *b, battery_slot(tick), *out, dmax);
+    return check_launch(ctx, "k_battery_requests");
+}
+
+ZRK_API int zrk_battery_log_events(zrk_ctx *ctx, const zrk_battery *b, const zrk_missiles *mis, int64_t tick, void *stream)
+{
+    if (int rc = battery_check(ctx, b, "zrk_battery_log_events")) return rc;
+    if (!mis) return fail(ctx, ZRK_E_INVALID, "zrk_battery_log_events: null argument");
+    hipLaunchKernelGGL(k_battery_log_events, dim3(1), dim3(256), 0, (hipStream_t)stream, *b, mis->ev_missile, mis->ev_target, mis->ev_count, (int)tick);
+    return check_launch(ctx, "k_battery_log_events");
+}
+
 ZRK_API int zrk_selftest_host_wait(int what, int limit_ms)
 {
     const auto limit = std::chrono::milliseconds(std::max(1, limit_ms));
@@ -5913,6 +6261,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         const bool fused = m > 0 && m <= 1024 * (int64_t)kMissileItems && (det_idx || list) && st->n > 0 && R > 0;
         MissileArgs M = fused ? missile_args(e, st->cur, mis, m, st->time_ms, st->dt_ms, 1) : no_missiles();
         if (fused) M.grec = grec;
+        if (fused && !sd) M.frozen_prev = ctx->frozen_prev;                   // (zrk_ctx_keep_prev: the plain loop's tombstones)
         if (fused && ev_words) { M.ev_wire = list + list_words; M.ev_wire_cap = xio->ev_capacity; M.gid0 = st->gid0; }
         // two mask buffers: tick t writes only its detections into one (cleared by the previous tick's
         // scatter) while its own scatter clears the other for tick t+1.  The first tick on a pair of buffers
