@@ -17,7 +17,11 @@ Workloads (BASELINE.json `configs`):
   C4            configs[3]: ONE seeded population of 1e7, rank g owns [g*1e7/N, (g+1)*1e7/N) (strong scaling).
   C5            configs[4]: Monte-Carlo ensemble, 128 independent scenarios x 1e4 targets per GPU in one batched table
                 (no exchange; weak scaling).
-  tiny, tiny4, tiny5: the same mechanics at test size.
+  C2-battery    configs[1]'s table with the battery's CLOSED loop around it (zrk_modulation_amd.battery.DeviceBattery): four
+                launchers with 250 missiles each and the command post on the device -- every tick: sweep + missile step +
+                lists, the launchers' step (magazines, launch solves), zrk_ccp_step over the tick's detections, the next
+                salvo's requests -- with the reference's latencies and nothing read back inside the loop (one GPU).
+  tiny, tiny4, tiny5, tiny-battery: the same mechanics at test size.
 With N > 1 (C2 / C3 / C4) each tick ends with an RCCL all-gather of the rank's compacted detection list (bitmap wire
 format) and its detonation events, issued from the C side (zrk_run_ticks_x) on RCCL's own stream so that it
 overlaps the next tick's sweep.  ZRK_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs
@@ -73,7 +77,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C3x4", "C4", "C5", "tiny", "tiny4", "tiny5"])
+    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C3x4", "C4", "C5", "tiny", "tiny4", "tiny5", "C2-battery", "tiny-battery"])
     ap.add_argument("--wire", default="masks", choices=["union", "masks"],
                     help="N > 1: what a rank's per-tick list carries -- the bitmap of the slots seen by any radar and the radar masks of "
                          "the seen slots (default: what a replicated command post needs, modules/CCP.py:409-417 keeps radar_id per "
@@ -253,6 +257,98 @@ def cpu_baseline(info, eng, budget_s=15.0):
                                      "1.6 us/entity + 4.3 us/(radar x entity), 1 thread (BASELINE.md section 2)"}
 
 
+def battery_config(workload, S):
+    """The closed-loop workloads' scene as the YAML-schema dictionary the reference loads (main.py:35-149): configs[1]'s targets
+    and radars, four launchers with a quarter of its missiles each, the command post over all of them."""
+    n, R, m = S.WORKLOADS[workload.replace("-battery", "")]
+    ids, sp, vel, _t0 = S.synthetic_targets(n, S.SEEDS[workload.replace("-battery", "")])
+    radars = S.synthetic_radars(R)
+    for k, rd in enumerate(radars):
+        rd["id"] = 10 + k
+    per = max(1, m // 4)
+    launchers = [dict(id=100 + l, position=[float(x), float(y), 0.0], max_missiles=per,
+                      missiles=[dict(id=10_000_000 * (1 + l) + k, velocity=1000.0, explosion_radius=150.0, life_time=60.0) for k in range(per)])
+                 for l, (x, y) in enumerate([(0.0, 0.0), (3000.0, 1500.0), (-2000.0, 4000.0), (5000.0, -500.0)])]
+    return dict(simulation=dict(time_step=10, duration=0),
+                air_environment=dict(id=999, position=[0.0, 0.0, 0.0],
+                                     targets=[dict(id=int(ids[i]), type="AIR_PLANE", position=sp[i].tolist(), velocity=vel[i].tolist()) for i in range(n)]),
+                radars=radars, missile_launchers=launchers,
+                combat_control_point=dict(id=0, missile_launcher_ids=[l["id"] for l in launchers], radar_ids=[r["id"] for r in radars]))
+
+
+def measure_battery(args, device):
+    """--workload C2-battery: a step is one tick of the CLOSED loop.  The sweep's duration: HIP events on every 16th tick of the
+    timed region (that tick synchronises; the others are enqueued back to back)."""
+    import numpy as np
+    import torch
+    from zrk_modulation_amd import scenario as S
+    from zrk_modulation_amd.battery import DeviceBattery
+    from zrk_modulation_amd.engine import HotPathEngine
+    cfg = battery_config(args.workload, S)
+    T = cfg["air_environment"]["targets"]
+    n = len(T)
+    ids = np.array([t["id"] for t in T], np.int64); sp = np.array([t["position"] for t in T]); vel = np.array([t["velocity"] for t in T])
+    nm = sum(len(l["missiles"]) for l in cfg["missile_launchers"])
+    eng = HotPathEngine(device=device, dt_ms=10, seed=S.SEEDS[args.workload.replace("-battery", "")], noise="philox")
+    eng.load(ids, sp, vel, 0.0, cfg["radars"], missile_capacity=nm).enable_lists()
+    bat = DeviceBattery(eng, cfg["missile_launchers"])
+    steps, warmup = args.steps, args.warmup
+    bat.run(warmup)
+    torch.cuda.synchronize(device)
+    live0 = eng.alive_count()
+    samples = []
+    t0 = time.perf_counter()
+    for k in range(steps):
+        if k % 16 == 15:
+            one = np.zeros(1, np.float32)
+            bat.run(1, sweep_ms=one)
+            samples.append(float(one[0]) * 1e3)
+        else:
+            bat.run(1)
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    live1 = eng.alive_count()
+    res = bat.results()                      # (raises if the command post's step did not go through)
+    eng.store.compact_status()
+    sweep_us = float(np.mean(samples)) if samples else float("nan")
+    live_avg = 0.5 * (live0 + live1)
+    alg_bytes = 85.0 * live_avg + 1.0 * (eng.store.n_uploaded - live_avg)
+    achieved = alg_bytes / (sweep_us * 1e-6) / 1e9
+    R = len(cfg["radars"])
+    out = {
+        "metric": "entity-timesteps/sec (targets+missiles)", "value": float(min(live0, live1)) * steps / elapsed, "unit": "entity-timesteps/s",
+        "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {n} AirObjects, {R} SectorRadars, {len(cfg['missile_launchers'])} launchers with {nm} missiles, the command "
+                               "post and the launchers on the device (closed loop: sweep + missile step + lists, launchers' step, zrk_ccp_step, next salvo), "
+                               "dt=10 ms, Philox measurement noise, the reference's message latencies, nothing read back inside the loop",
+                   "entities_per_gpu": eng.store.n_uploaded, "live_per_gpu": int(live1), "parallelism": "shard1",
+                   "loop": "closed loop, one tick per call of the plain two-launch loop + nine event-rate launches",
+                   "launch_solves": len(res["solves"]), "launches": len(res["new_missile"]), "detonations": len(res["detonations"]),
+                   "ticks_run": bat.tick},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS, "kernel": "k_tick_sweep",
+                     "avg_kernel_us": sweep_us, "samples": len(samples), "timed_by": "HIP events riding on the dispatch, every 16th tick of the timed region",
+                     "algorithmic_bytes_per_launch": alg_bytes, "ticks_per_launch": 1,
+                     "whole_tick": {"achieved": alg_bytes / (elapsed / steps) / 1e9, "frac": alg_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS}},
+        "cpu_baseline": None,
+    }
+    if not args.no_cpu_baseline:
+        from oracle.battery import OracleBattery
+        ob = OracleBattery(cfg, None)
+        t_a = time.perf_counter()
+        ticks = 0
+        while ticks < 3 or (time.perf_counter() - t_a < args.cpu_budget and ticks < 200):
+            ob.tick()
+            ticks += 1
+        t_cpu = time.perf_counter() - t_a
+        out["cpu_baseline"] = {"value": float(len(ob.sim.active_slots())) * ticks / t_cpu, "unit": "entity-timesteps/s", "cores": 1, "cpu_model": cpu_model(),
+                               "kind": "port", "sample": f"the same scene, the first {ticks} ticks of the closed loop through oracle/battery.py (AirEnv step, "
+                                                          "radars one after the other, launchers, the command post's sequential loop; no measurement noise) on one thread"}
+    bat.close()
+    return out
+
+
 def cpu_baseline_ensemble(self, budget_s, cores, cpu_model):
     """The oracle (oracle/, test infrastructure) timed on scenario 0 of the batch: the reported CPU baseline."""
     import time
@@ -350,6 +446,12 @@ def main():
     torch.cuda.set_device(device)
 
     from zrk_modulation_amd import scenario as S
+
+    if args.workload.endswith("-battery"):
+        if world != 1:
+            sys.exit("bench.py: the closed-loop workloads run on one GPU")
+        print(json.dumps(measure_battery(args, device)), flush=True)
+        return
 
     def measure(workload, steps, warmup, cpu_base, wire=None):
         """One workload, set up, warmed up and timed as the docstring says; rank 0 gets the line's dictionary."""

@@ -340,7 +340,9 @@ class OracleSim:
         cnt = self.L.zo_radar_sweep(self.n, self.cap, dptr(self.pos), u8ptr(self.alive), arr, i32ptr(out))
         found = out[:cnt].copy()
         if noise_fn is not None and cnt:
-            nz = np.ascontiguousarray(noise_fn(cnt), dtype=np.float64).reshape(cnt, 3)
+            # (a stream keyed by entity -- the device's counter-based one -- wants to know whose draws these are)
+            nz = noise_fn(found, k) if getattr(noise_fn, "by_slot", False) else noise_fn(cnt)
+            nz = np.ascontiguousarray(nz, dtype=np.float64).reshape(cnt, 3)
             self.L.zo_noise_apply(cnt, i32ptr(found), dptr(nz), self.cap, dptr(self.pos))
         caz = C.c_double(rd["caz"]); cel = C.c_double(rd["cel"])
         self.L.zo_scan_next(rd["mode"], rd["az_range"], rd["az_speed"], rd["el_speed"], rd["el_start"],

@@ -74,3 +74,12 @@ def test_exchange_control_flow_on_one_rank_with_real_rccl():
     assert rec["config"]["rccl_ranks_seen"] in (1, -1) and rec["config"]["exchange_pattern"].startswith("ncclAllGather")
     assert rec["config"]["exchange_host_wait_us_per_tick"] >= 0 and "bitmap" in rec["config"]["exchange_wire"]
     assert rec["value"] > 0
+
+
+def test_closed_loop_workload_line():
+    """--workload tiny-battery: the C2-battery line's mechanics at test size -- the battery's closed loop as the step."""
+    rec = _bench(["--workload", "tiny-battery", "--steps", "40", "--warmup", "8", "--cpu-budget", "1"])
+    assert rec["n_gpus"] == 1 and "closed loop" in rec["config"]["workload"] and rec["config"]["ticks_run"] == 48
+    assert rec["config"]["launch_solves"] > 0 and rec["config"]["launches"] > 0
+    assert rec["roofline"]["samples"] == 2 and rec["roofline"]["achieved"] > 0 and rec["value"] > 0
+    assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cores"] == 1
