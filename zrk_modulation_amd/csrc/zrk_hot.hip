@@ -3395,15 +3395,40 @@ __global__ void k_ccp_count_new(const CcpStepArgs A)
 // the scan over the tracks spread over its threads -- the strictly nearest free track in the annulus, the earlier track
 // among equals.  What the rounds gave away stays given (nobody earlier could have claimed it).  Bounded and exact, so the
 // step never ends undecided; the rounds are what makes the common case parallel.
-__global__ __launch_bounds__(1024) void k_ccp_tail(const CcpStepArgs A, uint8_t *taken, int32_t *match, uint8_t *state, int32_t *counters)
+__global__ __launch_bounds__(1024) void k_ccp_tail(const CcpStepArgs A, uint8_t *taken, int32_t *match, uint8_t *state, int32_t *counters,
+                                                   const CcpCand *__restrict__ cand)
 {
     __shared__ double s_dist[16];
     __shared__ int s_trk[16];
+    __shared__ int s_pick;
     if (counters[3] != 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = A.sizes[0], T = A.sizes[1];
     for (int d = 0; d < D; ++d) {
         if (state[d] == 1) continue;
+        // The detection's kept list first: the nearest in-gate tracks that were free when the list was made, nearest first (the
+        // order the sequential scan's strict < produces).  Tracks are only ever taken, so the first entry that is still free IS
+        // the scan's answer; a complete list with no free entry means "no track".  Only a truncated list whose every entry has
+        // been taken since -- the middle of a salvo that flies in a cluster -- sends the detection through the scan of all tracks
+        // (a salvo of a thousand missiles two ticks off the rails made this workgroup scan 10^5 tracks a thousand times: 25 ms a tick).
+        if (wave == 0) {
+            const int n = cand[d].n, total = cand[d].total;
+            const bool free_k = lane < n && lane < kCcpK && taken[cand[d].idx[lane < kCcpK ? lane : 0]] == 0;
+            const unsigned long long b = __ballot(free_k);
+            if (lane == 0) s_pick = b ? cand[d].idx[__builtin_ctzll(b)] : (total <= n ? -1 : -2);
+        }
+        __syncthreads();
+        const int pick = s_pick;
+        if (pick != -2) {                            // (the same for every thread)
+            if (tid == 0) {
+                const int32_t kx = A.kill[d];
+                if (pick >= 0) { match[d] = pick; taken[pick] = 1; }
+                else { match[d] = -1; if (kx >= 0) taken[kx] = 1; }
+                state[d] = 1;
+            }
+            __syncthreads();
+            continue;
+        }
         const double px = A.det_pos[3 * d], py = A.det_pos[3 * d + 1], pz = A.det_pos[3 * d + 2], sp = A.det_speed[d];
         double best = __builtin_inf();
         int who = 0x7FFFFFFF;
@@ -4799,7 +4824,7 @@ ZRK_API int zrk_ccp_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const dou
         hipLaunchKernelGGL(k_ccp_candidates, dim3(gd), dim3(256), 0, s, A.det_pos, A.det_speed, dmax, A.trk_ref, A.trk_upd, T, now_s, slack_s,
                            (const uint8_t *)taken, (const uint8_t *)only, cand, (const int32_t *)A.sizes, (const int32_t *)(counters + 4));
     }
-    hipLaunchKernelGGL(k_ccp_tail, dim3(1), dim3(1024), 0, s, A, taken, match, state, counters);
+    hipLaunchKernelGGL(k_ccp_tail, dim3(1), dim3(1024), 0, s, A, taken, match, state, counters, (const CcpCand *)cand);
     hipLaunchKernelGGL(k_ccp_finish, dim3(1), dim3(1), 0, s, counters, out->status);
     hipLaunchKernelGGL(k_ccp_scan, dim3(1), dim3(1024), 0, s, A, (const int32_t *)match);
     hipLaunchKernelGGL(k_ccp_launch, dim3(1), dim3(64), 0, s, A);
