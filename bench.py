@@ -83,6 +83,10 @@ def parse_args():
                          "the seen slots (default: what a replicated command post needs, modules/CCP.py:409-417 keeps radar_id per "
                          "message), or the bitmap alone (a fifth of the bytes).  A default multi-rank run times BOTH: the line's "
                          "value is the `masks` figure, the bitmap-only figure stands beside it as `union_wire`")
+    ap.add_argument("--interest", default="",
+                    help="N > 1, C-side exchange: comma-separated radar indices the consumers on other ranks listen to (the reference's "
+                         "command post reads one FoundObjectsMessage per radar of its radar_ids): the exchanged list is then the union "
+                         "list of these radars alone.  Default: all radars")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true",
                     help="skip the strong-scaling sub-record (configs[3], one population of 1e7) a default C3 run adds to its line")
@@ -494,7 +498,10 @@ def main():
                 made = True
             elif state["c_side"]:
                 try:
-                    xchg["x"] = RcclExchange(words, device, info["R"], offsets=offsets, ev_capacity=ev_cap, wire=wire)
+                    if args.interest:
+                        eng.det_idx = None           # (the exchanged list is shaped for the remote consumers; no local per-radar lists beside it)
+                    xchg["x"] = RcclExchange(words, device, info["R"], offsets=offsets, ev_capacity=ev_cap, wire=wire,
+                                             interest=[int(r) for r in args.interest.split(",") if r.strip()] or None)
                     made = True
                 except Exception as exc:                     # the library's own communicator could not be set up here
                     print(f"[bench rank {rank}] C-side exchange unavailable ({exc}); falling back to torch.distributed", file=sys.stderr)
@@ -754,6 +761,8 @@ def main():
                                                   "two helpers: the side stream's thread and a poster of the collectives") +
                                                  ("" if state["c_side"] else " (planned for this world size on this host; the rehearsal backend posts from Python)"))
                 out["config"]["host_threads_per_rank"] = 1 + helpers
+                if args.interest and state["c_side"]:
+                    out["config"]["exchange_radars_of_interest"] = [int(r) for r in args.interest.split(",") if r.strip()]
                 out["config"]["usable_host_cores"] = usable_cores()
                 if state["c_side"]:
                     xi = xinfo_timed or xchg["x"].info()

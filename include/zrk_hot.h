@@ -574,7 +574,12 @@ typedef struct {
     int64_t *recv[ZRK_EXCHANGE_SLOTS];   /* DEVICE [world][words] */
     int64_t words;                  /* zrk_union_bits_words(capacity, R, entries) + (ev_capacity ? 1 + ev_capacity : 0) */
     int32_t ev_capacity;
-    int32_t _pad;
+    /* (ABI 11) radars of interest, one bit per radar; 0: all of them.  What a consumer on another rank reads is one
+     * FoundObjectsMessage per radar IT listens to (modules/CCP.py:409-417 keeps radar_id = msg.sender_id): with a mask here the list
+     * that crosses the links is the union list of these radars alone -- a slot is on it when one of them saw it, its mask carries
+     * their bits -- instead of everything or nothing (zrk_union_bits_words(n, R, entries) with room for masks, or (n, R, 0) for the
+     * bitmap of the slots any of THEM saw).  The rank's own per-radar lists are not available beside it (det_idx must be NULL). */
+    uint32_t interest;
 } zrk_exchange_io;
 
 /* zrk_run_ticks with the per-tick exchange: `packed` must be NULL when xio is given (the list goes to xio->send),

@@ -148,3 +148,42 @@ def test_union_only_wire_and_the_direct_pattern_on_one_rank(algo, monkeypatch):
     assert info["world"] == 1 and info["rccl_ranks_seen"] in (1, -1) and info["collectives"] == tick
     assert info["pattern"] == ("direct send/recv" if algo == "direct" else "ncclAllGather") and info["grouped_pairs"] == grouped
     x.close()
+
+
+@pytest.mark.parametrize("wire", ["masks", "union"])
+def test_radars_of_interest_shape_the_exchanged_list(wire):
+    """zrk_exchange_io::interest: the list that travels is the union list of the radars a remote consumer listens to (the
+    reference's command post reads one FoundObjectsMessage per radar of its radar_ids, modules/CCP.py:409-417) -- a slot is on it
+    when one of THEM saw it, its mask carries their bits; the loop's own mask buffers are still cleared by what ANY radar saw
+    (the next ticks' lists would otherwise carry stale bits), and events travel as before.  Overlapped two-tick launches and
+    calls of one tick."""
+    from zrk_modulation_amd.exchange import RcclExchange, union_bits_words
+    n, R, m = 60_000, 6, 300
+    eng_a, _, launched = _engines(n, R, m, 21)
+    eng_b, _, _ = _engines(n, R, m, 21)
+    for eng in (eng_a, eng_b):                       # (the rank's own per-radar lists are not available beside an interest mask)
+        eng.det_idx = None
+    eng_b.gid0 = eng_b.loop.gid0 = 0
+    interest = [1, 4]
+    sel = sum(1 << r for r in interest)
+    x = RcclExchange(union_bits_words(eng_b.store.cap, R, 0 if wire == "union" else eng_b.store.cap), eng_b.store.device, R, offsets=[0],
+                     ev_capacity=256, wire=wire, interest=interest)
+    st = eng_a.store
+    tick = 0
+    for K in (1, 8, 1, 9, 6):
+        eng_b.run(K, exchange=x)
+        x.sync()
+        for j in range(K):                           # the plain loop tick by tick: what every tick's masks were
+            eng_a.run(1)
+            vis = st.vis()[:st.n_uploaded].cpu().numpy().view(np.uint32)
+            slot = (tick + j) % x.slots
+            if K - j <= x.slots:                     # (the slots hold the call's last ticks)
+                idx, msk = x.merged(slot)
+                want = np.nonzero(vis & sel)[0]
+                assert np.array_equal(idx.cpu().numpy(), want), f"tick {tick + j}: the list of the radars of interest differs"
+                if wire == "masks":
+                    assert np.array_equal(msk.cpu().numpy().astype(np.uint32), vis[want] & sel), f"tick {tick + j}: masks differ"
+        tick += K
+        assert np.array_equal(st.vis()[:st.n_uploaded].cpu().numpy(), eng_b.store.vis()[:st.n_uploaded].cpu().numpy())
+    assert not x.overflowed()
+    x.close()

@@ -167,7 +167,7 @@ class ZrkExchangeIo(C.Structure):
         ("recv", C.c_void_p * EXCHANGE_SLOTS),
         ("words", C.c_int64),
         ("ev_capacity", C.c_int32),
-        ("_pad", C.c_int32),
+        ("interest", C.c_uint32),
     ]
 
 

@@ -1620,6 +1620,9 @@ struct CompactArgs {
     // publishes the group's totals (behind the records, at agg + kGroupOffset), and a workgroup adds up the
     // lower records of its own group and the totals of the groups before it: group + nb / group words instead of nb
     int32_t group;
+    // radars of interest (zrk_exchange_io::interest; 0: all): the union list is that of these radars alone -- a slot counts as
+    // seen when one of THEM saw it, its mask carries their bits.  Lists only for the wire (det_idx == NULL)
+    uint32_t select;
 };
 
 // What a compaction workgroup needs only at its END -- where the lists go -- is read there, from the kernel-argument segment,
@@ -1741,6 +1744,7 @@ __device__ __forceinline__ void compact_block(CompactShared<THREADS> &S, const C
             // next tick's (other) mask buffer, cleared in passing; the overlapped loop clears the buffer it has just read,
             // where only the detections are not zero already
             if (zb && (own ? mk[it] != 0u : slot < rem)) zb[slot] = 0u;
+            if (C.select) mk[it] &= C.select;        // (radars of interest: behind the clearing, which goes by what any radar saw)
             const unsigned long long bu = __ballot(mk[it] != 0u);
             if (lane == 0) {
                 S.wcnt[it * (THREADS / 64) + wave] = (int)__popcll(bu);
@@ -2118,6 +2122,7 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
             mk[s][it] = slot < rem ? mk[s][it] : 0u;
             // (the loop's own mask buffers are cleared by the compaction that reads them: only the detections are not zero)
             if (zb && (own ? mk[s][it] != 0u : slot < rem)) zb[slot] = 0u;
+            if (C.select) mk[s][it] &= C.select;      // (radars of interest: behind the clearing, which goes by what any radar saw)
         }
     }
     for (int q = 0; q < rmn; ++q) {                  // (wave-uniform trip count; every thread compares its own slots)
@@ -4420,7 +4425,7 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
                    int32_t *det_idx, int64_t det_stride, int32_t *det_cnt, int64_t *packed, int64_t packed_capacity,
                    int64_t gid0, void *stream, const MissileArgs &M, uint32_t *zero_next,
                    bool union_bits = false, const EnsLaunch *ens = nullptr, const PutArgs *put = nullptr,
-                   SideItem *defer = nullptr, int force_items = 0)
+                   SideItem *defer = nullptr, int force_items = 0, uint32_t select = 0)
 {
     if (!ctx || !vis_mask || !workspace) return fail(ctx, ZRK_E_INVALID, "zrk_compact: null argument");
     if ((det_idx && !det_cnt) || (!det_idx && !packed)) return fail(ctx, ZRK_E_INVALID, "zrk_compact: no output requested");
@@ -4475,6 +4480,8 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         C.group = (!ens && nbf > 64) ? 32 : 0;
         if (!ens && ctx->env_group >= 0) C.group = ctx->env_group;
         C.seg_slots = ens ? ens->rows_ps : 0;
+        C.select = select;
+        if (select && (det_idx || !packed || ens)) return fail(ctx, ZRK_E_INVALID, "zrk_compact: radars of interest apply to the union list alone (no per-radar lists, one scenario)");
         EnsembleArgs E;
         std::memset(&E, 0, sizeof(E));
         if (ens) E = ens->next;
@@ -4492,6 +4499,7 @@ int launch_compact(zrk_ctx *ctx, const uint32_t *vis_mask, int64_t n, int R, int
         return check_launch(ctx, "k_compact_fused");
     }
     if (defer) return fail(ctx, ZRK_E_INVALID, "zrk_compact: overlap mode needs the single-launch compaction");
+    if (select) return fail(ctx, ZRK_E_INVALID, "zrk_compact: radars of interest need the single-launch compaction");
     const int nb = nblocks(n, kCompBlock);
     Workspace w = carve(workspace, nb, n);
     hipLaunchKernelGGL(k_count_blocks, dim3(nb), dim3(kCompBlock), 0, s, vis_mask, n, R, nb, w.counts);
@@ -5824,6 +5832,9 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     hipEvent_t *ev = n_prof ? ctx->tev.data() : nullptr;
     // the tail of an exchanged list carries this tick's detonations: [count, rows ...]
     const int64_t ev_words = (xio && xio->ev_capacity > 0) ? 1 + (int64_t)xio->ev_capacity : 0;
+    // radars of interest: what the other ranks' consumers read (zrk_exchange_io::interest; 0: every radar)
+    const uint32_t wire_select = xio ? xio->interest : 0u;
+    if (wire_select && det_idx) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: radars of interest shape the exchanged list; per-radar lists (det_idx) are not available beside them");
     // hand-over of a tick's list to the exchange stream: by the flag the next tick's sweep raises (no packet of its own on
     // the compute stream), the last tick of the call -- which has no next sweep -- by an event
     // Overlap mode: the lists of tick t are compacted on a side stream beside the sweep of tick t + 1, and the compute
@@ -6148,14 +6159,14 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             if (rc == 0)
                 rc = launch_compact(ctx, vis_t[0], st->n, R, st->base_index, workspace, det_idx ? sd->scratch_det : nullptr, det_stride,
                                     det_idx ? sd->scratch_cnt : nullptr, xio ? list_t[0] : (packed ? sd->scratch_packed : nullptr), list_words,
-                                    st->gid0, stream, no_missiles(), vis_t[0], (st->flags & ZRK_F_UNION_BITS) != 0, nullptr, nullptr, &a, items);
+                                    st->gid0, stream, no_missiles(), vis_t[0], (st->flags & ZRK_F_UNION_BITS) != 0, nullptr, nullptr, &a, items, wire_select);
             // (the second tick's lists: the caller's -- of the call's last launch only, where its last compaction stands alone)
             const bool spare = spare_outputs && !last_launch;
             if (rc == 0)
                 rc = launch_compact(ctx, vis_t[1], st->n, R, st->base_index, workspace, (det_idx && spare) ? sd->scratch_det : det_idx, det_stride,
                                     (det_idx && spare) ? sd->scratch_cnt : det_cnt, (spare && packed) ? sd->scratch_packed : list_t[1], list_words,
                                     st->gid0, stream, no_missiles(), (slot_t[1] < Side::kMasks) ? vis_t[1] : nullptr,
-                                    (st->flags & ZRK_F_UNION_BITS) != 0, nullptr, nullptr, &b, items);
+                                    (st->flags & ZRK_F_UNION_BITS) != 0, nullptr, nullptr, &b, items, wire_select);
             for (int j = 0; j < 2 && rc == 0 && ev_words && !fused; ++j)     // (no missiles: an empty event list behind each list)
                 if (hipMemsetAsync(list_t[j] + list_words, 0, sizeof(int64_t), s) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "memset events");
             if (rc == 0) {
@@ -6228,7 +6239,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             if (xio) { if (int rcw = zrk_exchange_wait(xio->x, xslot[j], stream)) { rc = fail(ctx, rcw, zrk_exchange_last_error(xio->x)); break; } }
             rc = launch_compact(ctx, vis_t[j], st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, list_t[j], list_words,
                                 st->gid0, stream, no_missiles(), (slot_t[j] < Side::kMasks) ? vis_t[j] : nullptr,
-                                (st->flags & ZRK_F_UNION_BITS) != 0, nullptr, nullptr, &it);
+                                (st->flags & ZRK_F_UNION_BITS) != 0, nullptr, nullptr, &it, 0, wire_select);
             if (rc != 0) break;
             if (ev_words && !fused && hipMemsetAsync(list_t[j] + list_words, 0, sizeof(int64_t), s) != hipSuccess) { rc = fail(ctx, ZRK_E_HIP, "memset events"); break; }
             it.stream = tail_here ? s : side_stream; it.on_compute = tail_here ? 1 : 0;
@@ -6389,7 +6400,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             // (the single-launch workspace's first-use clearing, if any, goes to the compute stream, ahead of the flag)
             rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, list, list_words,
                                 st->gid0, stream, no_missiles(), (side_slot < Side::kMasks) ? vis_now : nullptr,
-                                (st->flags & ZRK_F_UNION_BITS) != 0, ens ? &EL : nullptr, nullptr, &it);
+                                (st->flags & ZRK_F_UNION_BITS) != 0, ens ? &EL : nullptr, nullptr, &it, 0, wire_select);
             if (rc != 0) break;
             const uint32_t v = ++sd->seq;
             if (ens) {
@@ -6430,7 +6441,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (rc == 0 && (det_idx || list))
             rc = launch_compact(ctx, vis_now, st->n, R, st->base_index, workspace, det_idx, det_stride, det_cnt, list,
                                 list_words, st->gid0, stream, M, vis_next,
-                                (st->flags & ZRK_F_UNION_BITS) != 0, ens ? &EL : nullptr, rb_through_memory ? &put : nullptr);
+                                (st->flags & ZRK_F_UNION_BITS) != 0, ens ? &EL : nullptr, rb_through_memory ? &put : nullptr, nullptr, 0, wire_select);
         if (rc == 0 && m > 0 && !fused) rc = zrk_missile_step(ctx, e, st->cur, mis, m, st->time_ms, st->dt_ms, 1, stream);
         if (rc == 0 && ev_words && !fused) {
             if (m > 0) {

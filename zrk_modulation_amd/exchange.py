@@ -112,10 +112,13 @@ class RcclExchange:
     stream; zrk_run_ticks_x posts one all-gather per tick behind that tick's compaction, so no Python runs between a
     tick and its collective.  torch.distributed is used once, to hand rank 0's communicator id to the others."""
 
-    def __init__(self, words, device, R, offsets=None, ev_capacity=0, group=None, wire="masks"):
+    def __init__(self, words, device, R, offsets=None, ev_capacity=0, group=None, wire="masks", interest=None):
         """wire "masks": count, n, one bit per slot, the 16- or 32-bit radar masks of the seen slots (`words` from
         union_bits_words(n, R, entries)); wire "union": the bitmap alone (union_bits_words(n, R, 0)): who was seen by
-        any radar, a fifth of the bytes -- what crosses xGMI when no consumer on another rank asks which radar saw it."""
+        any radar, a fifth of the bytes -- what crosses xGMI when no consumer on another rank asks which radar saw it.
+        interest: the radars (indices) consumers on other ranks listen to -- the reference's command post reads one
+        FoundObjectsMessage per radar in its radar_ids (modules/CCP.py:409-417); the list that travels is then the union list
+        of THESE radars (a slot is on it when one of them saw it, its mask carries their bits); None: all radars."""
         import ctypes as C
         from . import _lib
         self._C, self.lib = C, _lib.load()
@@ -124,6 +127,10 @@ class RcclExchange:
         self.device = torch.device(device)
         self.R, self.ev_capacity = int(R), int(ev_capacity)
         self.union_only = wire == "union"
+        self.interest = 0
+        for r in (interest or []):
+            assert 0 <= int(r) < self.R, "interest: radar indices"
+            self.interest |= 1 << int(r)
         self.words = int(words) + (1 + self.ev_capacity if self.ev_capacity else 0)
         self.offsets = list(offsets) if offsets is not None else [0] * self.world
         path = rccl_library_path()
@@ -162,6 +169,7 @@ class RcclExchange:
         for k in range(self.slots):
             io.send[k], io.recv[k] = self.send[k].data_ptr(), self.recv[k].data_ptr()
         io.words, io.ev_capacity = self.words, self.ev_capacity
+        io.interest = self.interest
         self.io = io
 
     def resize(self, words):
