@@ -2,12 +2,14 @@
 probe`): when each wave starts, how long it waits for its rows, how long the two radar loops take, when it ends -- with
 the previous pair's compaction running beside it, as in the loop bench.py times.  usage: sweep_phases_pair.py [n] [R] [m]"""
 import ctypes as C
+import os
 import sys
 from pathlib import Path
 
 import numpy as np
 import torch
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")        # (as bench.py runs: the sweep's 20 KB of arguments in device memory)
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from zrk_modulation_amd import _lib  # noqa: E402

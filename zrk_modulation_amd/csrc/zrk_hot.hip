@@ -46,8 +46,10 @@ __device__ long long *g_wave_probe;
     do {                                                                                                   \
         if ((threadIdx.x & 63) == 0 && g_wave_probe) g_wave_probe[(int64_t)(wave) * 8 + (slot)] = (value);  \
     } while (0)
+#define ZRK_PROBE_ENTRY() const long long probe_entry = wall_clock64()      // (a wave's first instruction: slot 0)
 #else
 #define ZRK_WAVE_PROBE(wave, slot, value)
+#define ZRK_PROBE_ENTRY()
 #endif
 
 constexpr double kRad2Deg = 180.0 / 3.14159265358979323846;   // numpy.degrees factor
@@ -1038,6 +1040,7 @@ template <bool PHILOX, bool ADVANCE, bool LIDX, bool MARKS = false, bool PAIR = 
 __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) void k_tick_sweep(const std::conditional_t<PAIR, SweepParamsPair, SweepParams> P, const MissileArgs M)
 {
     static_assert(!PAIR || (MARKS && ADVANCE), "a pair launch advances and carries removals as marks");
+    ZRK_PROBE_ENTRY();
     // one scenario: the radar records travel in this launch's kernel-argument segment (THE ONLY PLACE where that address is
     // formed: see g_device_fault); a batched ensemble: a table in device memory, indexed below
     const char *const kernarg = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1119,7 +1122,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) voi
     uint4 pre_piece = pre_table_fetch(rbp);
     uint4 pre_piece2 = pre_piece;
     if (PAIR) pre_piece2 = pre_table_fetch(rbp2);
-    ZRK_WAVE_PROBE(wave, 0, wall_clock64());
+    ZRK_WAVE_PROBE(wave, 0, probe_entry);
     // where the wave runs: HW_REG_HW_ID (wave / simd / cu / sh / se) and HW_REG_XCC_ID
     // (bits 40 up: the workgroup's place in the dispatch)
     ZRK_WAVE_PROBE(wave, 6, (long long)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
@@ -3816,10 +3819,11 @@ double d2_threshold(double m)
 }  // namespace
 
 // Diagnostics (ZRK_TRACE=1): host time stamps of one zrk_run_ticks call -- the calling thread's and the side stream's
-// thread's -- printed to stderr when the call returns.  Off: one predictable branch per stamp.
+// thread's -- printed to stderr when the call returns (=2: when the next call starts, so that the printing -- 40 to 100 us
+// for a 20-tick call -- is not part of what a caller times around the call).  Off: one predictable branch per stamp.
 namespace {
 struct HostTrace {
-    bool on = false;
+    bool on = false, deferred = false;     // deferred (ZRK_TRACE=2): printed when the NEXT call starts, not inside the call it describes
     std::mutex mu;
     std::vector<std::pair<const char *, int64_t>> marks;
     static int64_t now() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -4164,7 +4168,7 @@ ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
 {
     if (!c) return;
     host_wait_reload();
-    { const char *v = std::getenv("ZRK_TRACE"); g_trace.on = v && v[0] == '1'; }
+    { const char *v = std::getenv("ZRK_TRACE"); g_trace.on = v && (v[0] == '1' || v[0] == '2'); g_trace.deferred = v && v[0] == '2'; }
     c->order_enabled = true; c->diag = 0; c->env_items = 0; c->env_order = -1;
     if (const char *v = std::getenv("ZRK_SWEEP_ORDER")) c->order_enabled = std::atoi(v) != 0;
     if (const char *v = std::getenv("ZRK_DIAG")) c->diag = (uint32_t)std::strtoul(v, nullptr, 0);
@@ -5764,6 +5768,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (!(st->flags & ZRK_F_UNION_BITS)) return fail(ctx, ZRK_E_INVALID, "zrk_run_ticks: the exchange carries the wire format (ZRK_F_UNION_BITS)");
     }
     hipStream_t s = (hipStream_t)stream;
+    if (g_trace.deferred) g_trace.dump();
     g_trace.mark("run_ticks: entry");
     // a batched ensemble: S scenarios of rows_per_scenario rows each, radars and scan state on the device
     EnsLaunch EL;
@@ -6500,7 +6505,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         }
     }
     g_trace.mark("run_ticks: exit");
-    g_trace.dump();
+    if (!g_trace.deferred) g_trace.dump();
     // a collective whose hand-over never came went out poisoned (k_wait_flag): the host knows without a synchronisation
     if (rc == 0 && xio && exchange_gave_up(xio->x) != 0) rc = fail(ctx, ZRK_E_STATE, zrk_exchange_last_error(xio->x));
     if (n_prof && !deferred) {
