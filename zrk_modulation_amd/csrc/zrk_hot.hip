@@ -163,6 +163,9 @@ struct SweepParams : SweepHead {
     uint32_t *vis2;
     uint32_t *order_ctr;        // kOrderRegions pairs (expensive / cheap row blocks recorded so far), kOrderCtrStride words apart
     uint32_t *order_ctr_next;   // the next tick's set, cleared here
+    // the mask buffer the CALL's last tick will write (the caller's), zeroed in passing by the call's first launch so that the
+    // last one writes its detections only (a dense write of a million words made a call's last launch 40-42 us instead of ~33)
+    uint32_t *vis_clear;
     double t;
     uint64_t tick;
     int64_t gid0;
@@ -1274,6 +1277,7 @@ __global__ __launch_bounds__(ZRK_BLOCK) __attribute__((amdgpu_num_sgpr(96))) voi
     // sparse mode: the buffer is known to be all zero (the previous tick's compaction cleared it), so only
     // detections are written -- list-indexed stores are scattered when the table is spatially sorted
     if (i < P.n && (mask || !(P.flags & kSparseVis))) P.vis[(int64_t)scen * P.rows_ps + li] = mask;
+    if (P.vis_clear && i < P.n) P.vis_clear[i] = 0u;         // (word i, not the row's list index: the same words in all, written side by side)
     if (PAIR) {
         // the second tick: same rows, the next radar records, the next noise key.  (A row that tick t's missile phase removes
         // is swept here all the same -- its thread cannot know; see SweepParams::t2 for who puts that right.)
@@ -2298,18 +2302,48 @@ __device__ __forceinline__ void compact_block_pair(CompactSharedPair &S, const C
     }
 }
 
+// A call's removal marks carried out and cleared (k_apply_marks) by extra workgroups of the call's LAST compaction launch: a
+// launch of its own between the last sweep and that compaction was 6 us of every call (16 rows per thread: one 16-byte load
+// of marks, all zero but for a handful).
+__device__ __forceinline__ void kill_one(uint8_t *alive, const double *src, double *dst, int64_t cap, int32_t s);
+struct MarksArgs {
+    uint8_t *pend, *alive;
+    double *pos0, *pos1;
+    int64_t cap, n;
+    int32_t blocks, _pad;
+};
+
+template <int THREADS>
+__device__ __forceinline__ void apply_marks_block(const MarksArgs &A, int part)
+{
+    const int64_t r0 = ((int64_t)part * THREADS + threadIdx.x) * 16;
+    if (r0 >= A.n) return;
+    const uint4 w = *(const uint4 *)(A.pend + r0);          // (pend holds at least `cap` bytes, a multiple of 16 past n)
+    if ((w.x | w.y | w.z | w.w) == 0u) return;
+    for (int64_t i = r0; i < r0 + 16 && i < A.n; ++i) {
+        const uint8_t pk = A.pend[i];
+        if (pk == 0) continue;
+        // (the mark's low bit: the buffer that was current in the removal tick, i.e. the one that holds the frozen position)
+        if (A.alive[i]) { if (pk & 1u) kill_one(A.alive, A.pos1, A.pos0, A.cap, (int32_t)i); else kill_one(A.alive, A.pos0, A.pos1, A.cap, (int32_t)i); }
+        A.pend[i] = 0;
+    }
+}
+
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_compact_pair(const CompactArgs C0, const CompactArgs C1, const MissileArgs M0,
-                                                          const MissileArgs M1, const int32_t *rm, int rm_cap, const DoneWord dw)
+                                                          const MissileArgs M1, const int32_t *rm, int rm_cap, const DoneWord dw,
+                                                          const MarksArgs marks)
 {
     __shared__ int s_wave[16];
     __shared__ CompactSharedPair S;
     previous_launch_is_over(dw);
-    if ((int)blockIdx.x >= C0.nb) {                  // two extra workgroups: the ticks' ordered event lists
-        if (M0.m > 0) {
-            if ((int)blockIdx.x == C0.nb) missile_events_any(s_wave, M0);
+    if ((int)blockIdx.x >= C0.nb) {                  // extra workgroups: the ticks' ordered event lists (two), a call's marks
+        const int extra = (int)blockIdx.x - C0.nb, lists = M0.m > 0 ? 2 : 0;
+        if (extra < lists) {
+            if (extra == 0) missile_events_any(s_wave, M0);
             else missile_events_any(s_wave, M1);
         }
+        else apply_marks_block<THREADS>(marks, extra - lists);
         return;
     }
     static_assert(sizeof(CompactArgs) % 8 == 0, "C1 stands right behind C0 in the argument segment");
@@ -3944,6 +3978,7 @@ struct SideItem {
     MissileArgs M2;
     const int32_t *rm;
     int rm_cap;
+    MarksArgs marks;                // blocks > 0: the call's removal marks are carried out by this (pair) launch
     zrk_exchange *post_x;
     int post_slot;
     const int64_t *post_send;
@@ -4090,6 +4125,7 @@ struct zrk_ctx {
                                        // a launch that raises the host word (medians equal, 24.6 / 24.7 us per tick in 20-step runs; the event has the worse tail)
     bool tail_free = true;             // ... without waiting for the side stream's launch before it (Side::tail_ws; ZRK_TAIL_FREE=0: an event)
     double *frozen_prev = nullptr;     // zrk_ctx_keep_prev: where rows that leave the air keep their handle's prev_pos (plain loop)
+    bool marks_in_tail = true;         // ZRK_MARKS_IN_TAIL=0: a launch of its own (k_apply_marks) between the call's last sweep and its last compaction
     bool tail_on_compute = true;       // the last compaction of a call goes to the compute stream, behind the last sweep (SideItem::on_compute);
                                        // ZRK_TAIL_COMPUTE=0: to the side stream like the others, released as above.  Calls with an exchange: always the latter
 };
@@ -4179,6 +4215,7 @@ ZRK_API void zrk_ctx_reload_env(zrk_ctx *c)
     { const char *v = std::getenv("ZRK_GATHER_RECORDS"); c->grec_enabled = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_TAIL_EVENT"); c->tail_by_event = v && v[0] == '1'; }
     { const char *v = std::getenv("ZRK_TAIL_FREE"); c->tail_free = !(v && v[0] == '0'); }
+    { const char *v = std::getenv("ZRK_MARKS_IN_TAIL"); c->marks_in_tail = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_TAIL_COMPUTE"); c->tail_on_compute = !(v && v[0] == '0') && !c->tail_by_event; }
     { const char *v = std::getenv("ZRK_PAIR"); c->pair_enabled = !(v && v[0] == '0'); }
     { const char *v = std::getenv("ZRK_PAIR_COMPACT"); c->pair_compact = !(v && v[0] == '0'); }
@@ -4331,7 +4368,7 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
                  WaveBox *boxes = nullptr, const EnsLaunch *ens = nullptr, const RadarBlock *rb_device = nullptr,
                  uint32_t *flag = nullptr, uint32_t flag_value = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
                  uint32_t *order_ctr = nullptr, uint32_t *order_ctr_next = nullptr, uint8_t *pend = nullptr, uint32_t mark = 0,
-                 const PairLaunch *pair = nullptr, unsigned long long *stamps = nullptr)
+                 const PairLaunch *pair = nullptr, unsigned long long *stamps = nullptr, uint32_t *vis_clear = nullptr)
 {
     if (!ctx || !e || !workspace || (R > 0 && !radars && !ens && !rb_device)) return fail(ctx, ZRK_E_INVALID, "zrk_tick_sweep: null argument");
     if (R < 0 || R > ZRK_MAX_RADARS)
@@ -4346,6 +4383,7 @@ int launch_sweep(zrk_ctx *ctx, const zrk_entities *e, int64_t n, int cur, int64_
     P.sp = e->start_pos; P.vel = e->velocity; P.t0 = e->start_time; P.alive = e->alive; P.lidx = e->list_index;
     P.pos = e->pos[cur]; P.vis = vis ? vis : e->vis_mask;
     P.order = order; P.order_next = order_next; P.order_ctr = order_ctr; P.order_ctr_next = order_ctr_next;
+    P.vis_clear = vis_clear;
     P.n = n; P.cap = e->capacity;
     P.t = (double)time_ms / 1000.0;                 // to_seconds, modules/AirObject.py:5-7
     P.seed = seed; P.tick = tick; P.gid0 = gid0;
@@ -5523,13 +5561,16 @@ int side_issue(Side *sd, const SideItem &it)
     // (a launch that waited for nobody cannot say that the one before it is over)
     const DoneWord dw{it.on_compute == 2 ? nullptr : sd->hdone_dev, it.done_value - 1u};
     if (it.pair) {
-        const dim3 grid(it.C.nb + (it.M.m > 0 ? 2 : 0));
-        if (it.pair_threads == 256)
-            hipLaunchKernelGGL(k_compact_pair<256>, grid, dim3(256), 0, it.stream, it.C, it.C2, it.M, it.M2, it.rm, it.rm_cap, dw);
-        else if (it.pair_threads == 512)
-            hipLaunchKernelGGL(k_compact_pair<512>, grid, dim3(512), 0, it.stream, it.C, it.C2, it.M, it.M2, it.rm, it.rm_cap, dw);
+        const int threads = it.pair_threads == 256 ? 256 : (it.pair_threads == 512 ? 512 : 1024);
+        MarksArgs mk = it.marks;
+        mk.blocks = mk.pend ? (int)((mk.n + (int64_t)threads * 16 - 1) / ((int64_t)threads * 16)) : 0;
+        const dim3 grid(it.C.nb + (it.M.m > 0 ? 2 : 0) + mk.blocks);
+        if (threads == 256)
+            hipLaunchKernelGGL(k_compact_pair<256>, grid, dim3(256), 0, it.stream, it.C, it.C2, it.M, it.M2, it.rm, it.rm_cap, dw, mk);
+        else if (threads == 512)
+            hipLaunchKernelGGL(k_compact_pair<512>, grid, dim3(512), 0, it.stream, it.C, it.C2, it.M, it.M2, it.rm, it.rm_cap, dw, mk);
         else
-            hipLaunchKernelGGL(k_compact_pair<1024>, grid, dim3(1024), 0, it.stream, it.C, it.C2, it.M, it.M2, it.rm, it.rm_cap, dw);
+            hipLaunchKernelGGL(k_compact_pair<1024>, grid, dim3(1024), 0, it.stream, it.C, it.C2, it.M, it.M2, it.rm, it.rm_cap, dw, mk);
     }
     else
         hipLaunchKernelGGL(k_compact_side, dim3(it.C.nb + (it.M.m > 0 ? 1 : 0)), dim3(kCompBlock), 0, it.stream, it.C, it.by_ticket, it.M, dw);
@@ -5944,6 +5985,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
     int side_last = -1;
     bool tail_on_s = false;                              // the call's last compaction went to the compute stream (SideItem::on_compute)
     bool tail_alone = false;                             // ... and waited for nobody (on_compute == 2)
+    bool marks_in_tail = false;                          // ... and carries out the call's removal marks (MarksArgs)
     zrk_exchange *fx = (xio && xio->x->flag) ? xio->x : nullptr;
     if (fx && fx->seq > 0x7FFF0000u) {                   // far from wrapping: the comparison is on 32 bits
         if (hipStreamSynchronize(fx->cstream) != hipSuccess) return fail(ctx, ZRK_E_HIP, "hipStreamSynchronize");
@@ -6027,6 +6069,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         ctx->stamp_waves[slot] = ((int64_t)nblocks(st->n, ZRK_BLOCK) + nblocks(missile_rows, ZRK_BLOCK)) * (ZRK_BLOCK / 64);
         return ctx->stamp_ring + (int64_t)slot * ctx->stamp_slot_words;
     };
+    const int vis_cur_call = st->vis_cur;               // (which of the caller's two mask buffers is current as the call starts)
     for (int k = 0; pairing && k < K && rc == 0;) {
         const int nt = (k + 1 < K) ? 2 : 1;
         const int32_t cur_before = st->cur, vis_cur_before = st->vis_cur;
@@ -6121,6 +6164,10 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         const bool on_dispatch = prof_idx >= 0;
         if (k == 0) g_trace.mark("run_ticks: first launch prepared");
         const auto t_launch = std::chrono::steady_clock::now();
+        // the call's first launch zeroes the caller's buffer that its last tick will write (SweepParams::vis_clear)
+        uint32_t *vis_clear = nullptr;
+        const int last_buf = vis_cur_call ^ (K & 1);
+        if (k == 0 && two_vis && K > nt && !ctx->ring_clean[last_buf]) vis_clear = last_buf ? e->vis_mask_alt : e->vis_mask;
         const int rc_sweep =
             launch_sweep(ctx, e, st->n, cur_a, st->time_ms, radars, R, st->flags | ZRK_F_ADVANCE | sparse_t[0] | (nt == 2 ? sparse_t[1] : 0u),
                          st->seed, st->tick, st->gid0, workspace, stream, M, vis_t[0], ordering ? w.order[oph ^ 1] : nullptr,
@@ -6128,8 +6175,9 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                          k > 0 ? sd->hflag_dev : nullptr, sd->seq,
                          on_dispatch ? ev[2 * prof_idx] : nullptr, on_dispatch ? ev[2 * prof_idx + 1] : nullptr,
                          w.order_ctr + kOrderCtrSet * (oph ^ 1), w.order_ctr + kOrderCtrSet * oph, sd->pend, mark_a, nt == 2 ? &pl : nullptr,
-                         next_stamps(nt, M.m));
+                         next_stamps(nt, M.m), vis_clear);
         rc = rc_sweep;
+        if (rc_sweep == 0 && vis_clear) ctx->ring_clean[last_buf] = true;
         if (stall_us() > 0) stall_report(t_launch, __LINE__, "launch_sweep");
         g_trace.mark(nt == 2 ? "run_ticks: pair launched" : "run_ticks: sweep launched");
         if (rc_sweep != 0) { st->vis_cur = vis_cur_before; break; }
@@ -6185,6 +6233,13 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
                 a.C.group = a.C.nb > 512 ? 32 : (a.C.nb > 32 ? 16 : 0);   // (half as many records per batch of loads as the single compaction)
                 if (ctx->env_group >= 0) a.C.group = ctx->env_group;
                 a.stream = tail_here ? s : side_stream; a.on_compute = tail_here ? (tail_free ? 2 : 1) : 0;
+                std::memset(&a.marks, 0, sizeof(a.marks));
+                if (tail_here && ctx->marks_in_tail && sd->pend && sd->pend_rows >= e->capacity) {
+                    // (the call's last launch, in order behind its last sweep: the marks are carried out here, MarksArgs)
+                    a.marks.pend = sd->pend; a.marks.alive = e->alive; a.marks.pos0 = e->pos[0]; a.marks.pos1 = e->pos[1];
+                    a.marks.cap = e->capacity; a.marks.n = st->n;
+                    marks_in_tail = true;
+                }
                 if (tail_free) {                           // control words and records of its own
                     const Workspace tw = carve(sd->tail_ws, 0, 0);
                     a.C.ctl = a.C2.ctl = tw.ctl; a.C.agg = a.C2.agg = tw.agg;
@@ -6473,7 +6528,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
             hipLaunchKernelGGL(k_raise_flag_system, dim3(1), dim3(1), 0, s, sd->hflag_dev, sd->seq);
             rc = check_launch(ctx, "k_raise_flag");
         }
-        if (marks_used && sd->pend && sd->pend_rows >= e->capacity) {
+        if (marks_used && sd->pend && sd->pend_rows >= e->capacity && !(marks_in_tail && rc == 0)) {
             // the last tick's removals are still marks: tombstones now, and the call's marks cleared -- also when the call
             // has failed (a helper that gave up, a wait that ran out): the table then stands as after the st->tick ticks
             // that were swept, only the lists of this call are not valid
@@ -6492,7 +6547,7 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (rc == 0) rc = rc_side;
         g_trace.mark("run_ticks: side drained");
         if (xio) xio->x->via_side = nullptr;                 // (everything it carried has been issued, or has failed with it)
-        if (rc != 0) { sd->masks_dirty = true; sd->pend_rows = 0; }  // (marks: allocated and cleared anew)
+        if (rc != 0) { sd->masks_dirty = true; sd->pend_rows = 0; ctx->ring_clean[0] = ctx->ring_clean[1] = false; }  // (marks: allocated and cleared anew)
         if (rc == 0 && side_last >= 0 && sd->posted[side_last]) {
             // (a last item on the compute stream is in it already; the event behind it is for a later call on ANOTHER stream)
             if (!tail_on_s && hipStreamWaitEvent(s, sd->done_of[side_last], 0) != hipSuccess) rc = fail(ctx, ZRK_E_HIP, "hipStreamWaitEvent");
