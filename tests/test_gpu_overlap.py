@@ -368,3 +368,26 @@ def test_calls_on_alternating_streams(tail, monkeypatch):
             _same(_state(one), _state(two), f"after call {calls} of {K} ticks on stream {calls % 2}")
     torch.cuda.synchronize()
     _same(_state(one), _state(two), "at the end")
+
+
+def test_marks_carried_out_by_the_last_compaction_or_by_a_launch_of_their_own(monkeypatch):
+    """A call's removal marks become tombstones in extra workgroups of the call's last compaction launch (MarksArgs); with
+    ZRK_MARKS_IN_TAIL=0 in a launch of their own between the last sweep and that compaction, as before round 5.  Calls of even
+    and odd length with missiles that hit inside them must leave the same table, masks, lists and events either way -- and the
+    first launch of a call zeroes the caller's mask buffer that its last tick writes (SweepParams::vis_clear): the masks read
+    after every call are compared too."""
+    from tests.test_gpu_engine import _engine
+    monkeypatch.setenv("ZRK_OVERLAP_MIN_ROWS", "0")
+    monkeypatch.setenv("ZRK_OVERLAP", "1")
+    monkeypatch.setenv("ZRK_MARKS_IN_TAIL", "0")
+    one, _, launched = _engine(90_000, 6, 500, seed=41, noise="philox")
+    monkeypatch.setenv("ZRK_MARKS_IN_TAIL", "1")
+    two, _, _ = _engine(90_000, 6, 500, seed=41, noise="philox")
+    assert launched > 50
+    dead0 = int((one.store.d_alive[:one.store.n_uploaded] == 0).sum().item())
+    for calls, K in enumerate([4, 7, 12, 5, 4, 20, 9, 6]):
+        one.run(K)
+        two.run(K)
+        assert two.store.lib.zrk_last_run_overlapped(two.store.ctx.handle) == 1
+        _same(_state(one), _state(two), f"after call {calls} of {K} ticks")
+    assert int((one.store.d_alive[:one.store.n_uploaded] == 0).sum().item()) > dead0, "no removal inside the calls: the test is empty"

@@ -7,6 +7,10 @@ out=$R/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py"
+# (the wave timeline needs the diagnostics build of the SAME source: make -C zrk_modulation_amd/csrc probe, before the call)
+if [ ! -f $R/zrk_modulation_amd/csrc/libzrk_hot_probe.so ] || [ $R/zrk_modulation_amd/csrc/libzrk_hot_probe.so -ot $R/zrk_modulation_amd/csrc/zrk_hot.hip ]; then
+  echo "libzrk_hot_probe.so is missing or older than zrk_hot.hip: run  make -C zrk_modulation_amd/csrc probe  first" >&2; exit 1
+fi
 echo "== bench lines"
 for i in 1 2 3; do $B --steps 20 --warmup 5 > $out/bench_c3_driver_$i.json 2> $out/bench_c3_driver_$i.err; done
 ZRK_BENCH_SPINUP_MS=0 $B --steps 20 --warmup 5 --no-c4 --no-cpu-baseline > $out/bench_c3_driver_no_spinup.json 2>> $out/bench_c3.err
@@ -15,6 +19,7 @@ ZRK_PAIR=0 $B --steps 1000 --warmup 50 --no-cpu-baseline --no-c4 > $out/bench_c3
 ZRK_OVERLAP=0 $B --steps 1000 --warmup 50 --no-cpu-baseline --no-c4 > $out/bench_c3_plain_loop.json 2>> $out/bench_c3.err
 ZRK_BENCH_FORCE_EXCHANGE=1 $B --steps 1000 --warmup 50 --no-cpu-baseline > $out/bench_c3_exchange_one_rank.json 2>> $out/bench_c3.err
 $B --workload C2 --steps 2000 --warmup 100 --no-cpu-baseline > $out/bench_c2.json 2>> $out/bench_c3.err
+ZRK_PAIR=0 $B --workload C2 --steps 2000 --warmup 100 --no-cpu-baseline > $out/bench_c2_one_tick_per_launch.json 2>> $out/bench_c3.err
 $B --workload C5 --steps 500 --warmup 50 --cpu-budget 5 > $out/bench_c5.json 2>> $out/bench_c3.err
 $B --workload C3x4 --steps 200 --warmup 30 --no-cpu-baseline > $out/bench_c3x4.json 2>> $out/bench_c3.err
 $B --workload C4 --steps 100 --warmup 30 --no-cpu-baseline > $out/bench_c4_1gpu.json 2>> $out/bench_c3.err
