@@ -184,7 +184,7 @@ if sq["k_tick_sweep"]:
                         o.write(f"{k + ' / wave cycles':32s} {q[k] / q['SQ_WAVE_CYCLES']:8.3f}\n")
 
 for name in ("bench_c3_driver_1", "bench_c3_driver_2", "bench_c3_driver_3", "bench_c3_driver_no_spinup", "bench_c3", "bench_c3_one_tick_per_launch", "bench_c3_plain_loop",
-             "bench_c3_exchange_one_rank", "bench_c2", "bench_c5", "bench_c3x4", "bench_c4_1gpu", "bench_c2_battery"):
+             "bench_c3_exchange_one_rank", "bench_c2", "bench_c2_one_tick_per_launch", "bench_c5", "bench_c3x4", "bench_c4_1gpu", "bench_c2_battery"):
     rec = line(name)
     if rec:
         (dst / f"{tag}_{name}.json").write_text(json.dumps(rec, indent=1) + "\n")
@@ -202,7 +202,7 @@ if drv and recorded.get("sweep_us_C3_driver_run"):
 print(json.dumps(recorded, indent=1))
 print(json.dumps(traffic, indent=1))
 for name in ("bench_c3_driver_1", "bench_c3_driver_2", "bench_c3_driver_3", "bench_c3_driver_no_spinup", "bench_c3", "bench_c3_one_tick_per_launch", "bench_c3_plain_loop",
-             "bench_c3_exchange_one_rank", "bench_c2", "bench_c5", "bench_c3x4", "bench_c4_1gpu", "bench_c2_battery"):
+             "bench_c3_exchange_one_rank", "bench_c2", "bench_c2_one_tick_per_launch", "bench_c5", "bench_c3x4", "bench_c4_1gpu", "bench_c2_battery"):
     rec = line(name)
     if rec:
         r = rec["roofline"]
