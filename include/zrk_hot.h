@@ -471,14 +471,16 @@ typedef struct {
  * columns instead of the 64-byte records the loop keeps per row (64 B x capacity of device memory, the context's);
  * ZRK_SWEEP_ORDER=0 sweep in table order; ZRK_COMPACT_ORDER=block|ticket; ZRK_TIME_BY_RECORDS=1 time between two
  * recorded events; ZRK_HELPER_IDLE_MS how long the library's threads spin after their last item (default 1) and
- * ZRK_HELPER_YIELD_MS how long they then stay runnable, yielding their core between looks (default 250), before they sleep --
- * calls less than that apart find them awake; ZRK_STALL_US=n reports on stderr every host-side wait of the library longer
+ * ZRK_HELPER_YIELD_MS how long they then stay runnable, yielding their core between looks (default 5; bench.py asks for 250),
+ * before they sleep -- calls less than that apart find them awake; ZRK_STALL_US=n reports on stderr every host-side wait of the library longer
  * than n microseconds with the line it stands in; tuning / diagnostics, defaults chosen by measurement:
  * ZRK_PAIR_THREADS=256|512|1024 and ZRK_PAIR_COMPACT_BLOCKS (workgroup size of the pair compaction, and up to how many
  * workgroups a pair's compactions are one launch), ZRK_COMPACT_GROUP=0|4|8|16|32 (two-level sums of the workgroup records),
  * ZRK_COMPACT_ITEMS, ZRK_COMPACT_FUSED_MAX_BLOCKS, ZRK_SIDE_CUS=n[,first] / ZRK_SIDE_PRIORITY=high|low (the side stream's
  * place on the device), ZRK_TAIL_COMPUTE=0 / ZRK_TAIL_EVENT=1 (the call's last compaction on the side stream, released by a launch / an event), ZRK_CCP_GRID=0|1 (zrk_ccp_step's
- * candidate pass: all pairs / spatial index), ZRK_TRACE=1 (host time stamps of a call on stderr).
+ * candidate pass: all pairs / spatial index), ZRK_MARKS_IN_TAIL=0 (a call's removal marks are carried out by a launch of
+ * their own behind the last sweep instead of by extra workgroups of the call's last pair compaction), ZRK_TRACE=1 (host time
+ * stamps of a call on stderr as it returns; =2: as the next call starts, outside what a caller times).
  * Every host-side wait is bounded by ZRK_HOST_WAIT_MS (default 30000): if the
  * side stream's thread waits that long for the compute stream to reach the next sweep (the caller had queued more work in
  * front of the loop than that, or the device is gone) it gives up, THAT call returns ZRK_E_STATE (its lists are not
