@@ -3096,21 +3096,73 @@ __global__ __launch_bounds__(256) void k_ccp_grid_scatter(const CcpGridArgs G)
 }
 
 // One thread per detection, through the bins its annuli can reach.  Same outputs as k_ccp_candidates.
+// The kCcpK nearest (nearer first, the earlier track first among equals) of the n <= kCandBuf (distance, track) pairs a wave has
+// collected, left sorted in the buffer's first min(n, kCcpK) places.  The whole wave; the buffer is the wave's own.
+constexpr int kCandBuf = 256;
+__device__ __forceinline__ void wave_select_nearest(double *bd, int *bi, int n)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    constexpr int kPer = kCandBuf / 64;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double ed[kPer];
+    int ei[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int e = k * 64 + lane;
+        ed[k] = e < n ? bd[e] : __builtin_inf();
+        ei[k] = e < n ? bi[e] : 0x7FFFFFFF;
+    }
+    double rd = __builtin_inf();
+    int ri = -1;
+    const int keep = n < kCcpK ? n : kCcpK;
+    for (int r = 0; r < keep; ++r) {
+        double md = ed[0];
+        int mi = ei[0];
+#pragma unroll
+        for (int k = 1; k < kPer; ++k)
+            if (ed[k] < md || (ed[k] == md && ei[k] < mi)) { md = ed[k]; mi = ei[k]; }
+        double wd = md;
+        int wi = mi;
+#pragma unroll
+        for (int off = 32; off; off >>= 1) {
+            const double od = __shfl_xor(wd, off);
+            const int oi = __shfl_xor(wi, off);
+            if (od < wd || (od == wd && oi < wi)) { wd = od; wi = oi; }
+        }
+        if (lane == r) { rd = wd; ri = wi; }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k)
+            if (ei[k] == wi && ed[k] == wd) { ed[k] = __builtin_inf(); ei[k] = 0x7FFFFFFF; }      // (a track stands in the buffer once)
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < keep) { bd[lane] = rd; bi[lane] = ri; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The candidate pass over the spatial index: ONE WAVE per detection -- its lanes take the tracks of the cells its gate can reach
+// side by side, what is in gate goes into the wave's buffer in LDS, and the nearest kCcpK are picked out of it (whenever it
+// fills up, and at the end).  A thread per detection, walking those cells alone and keeping its sixteen in registers, was
+// 1.5 ms of a C2-battery tick: fifteen thousand detections are 58 workgroups, one wave per SIMD on a fifth of the device, each
+// a chain of a few thousand dependent loads.
 __global__ __launch_bounds__(256) void k_ccp_candidates_grid(const CcpGridArgs G, const uint8_t *__restrict__ taken,
                                                              const uint8_t *__restrict__ only, CcpCand *__restrict__ out,
                                                              const int32_t *__restrict__ gate)
 {
+    __shared__ double s_bd[4][kCandBuf];
+    __shared__ int s_bi[4][kCandBuf];
     if (gate && *gate == 0) return;
     const int D = (int)(G.sizes[0] < G.dmax ? G.sizes[0] : G.dmax);
-    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (d >= D || (only && !only[d])) return;
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int64_t d = (int64_t)blockIdx.x * 4 + wave;
+    if (d >= D || (only && !only[d])) return;                       // (wave-uniform)
+    double *bd = s_bd[wave];
+    int *bi = s_bi[wave];
     const CcpGrid &g = *G.grid;
     const double px = G.det_pos[3 * d], py = G.det_pos[3 * d + 1], pz = G.det_pos[3 * d + 2], sp = G.det_speed[d];
     const double now_s = G.now_s, slack_s = G.slack_s;
-    CcpCand c;
-    c.n = 0; c.total = 0;
-#pragma unroll
-    for (int k = 0; k < kCcpK; ++k) { c.dist[k] = __builtin_inf(); c.idx[k] = -1; }
+    int nbuf = 0, total = 0;
     if (sp == sp) {                                                // (a NaN speed: every gate fails)
         for (int cl = 0; cl < kGridClasses; ++cl) {
             const int nx = g.nx[cl], ny = g.ny[cl];
@@ -3127,37 +3179,43 @@ __global__ __launch_bounds__(256) void k_ccp_candidates_grid(const CcpGridArgs G
             for (int iy = iy0; iy <= iy1; ++iy) {
                 const int row = g.cell0[cl] + iy * nx;
                 const int j0 = G.start[row + ix0], j1 = G.start[row + ix1 + 1];     // (the cells of a row are neighbours in the sort)
-                for (int j = j0; j < j1; ++j) {
-                    const double upd = G.sorted_upd[j];
-                    if (upd == now_s) continue;
-                    const int t = G.sorted_idx[j];
-                    if (taken && taken[t]) continue;
-                    const double dx = G.sorted_ref[3 * (int64_t)j] - px, dy = G.sorted_ref[3 * (int64_t)j + 1] - py,
-                                 dz = G.sorted_ref[3 * (int64_t)j + 2] - pz;
-                    const double dist = sqrt(dot3(dx, dy, dz, dx, dy, dz));
-                    const double age = now_s - upd;
-                    double lo = sp * (age - slack_s), hi = sp * (age + slack_s);
-                    lo = (lo > 0.0) ? lo : 0.0; hi = (hi > 0.0) ? hi : 0.0;
-                    if (!(lo <= dist && dist <= hi)) continue;
-                    c.total += 1;
-                    // keep the kCcpK nearest, the earlier track first among equals
-                    const bool full = c.n >= kCcpK;
-                    if (!full || dist < c.dist[kCcpK - 1] || (dist == c.dist[kCcpK - 1] && t < c.idx[kCcpK - 1])) {
-                        int pos = full ? kCcpK - 1 : c.n;
-#pragma unroll
-                        for (int k = kCcpK - 1; k > 0; --k) {
-                            if (k <= pos && (c.dist[k - 1] > dist || (c.dist[k - 1] == dist && c.idx[k - 1] > t))) {
-                                c.dist[k] = c.dist[k - 1]; c.idx[k] = c.idx[k - 1]; pos = k - 1;
-                            }
+                for (int jb = j0; jb < j1; jb += 64) {
+                    const int j = jb + lane;
+                    bool in = false;
+                    double dist = 0.0;
+                    int t = -1;
+                    if (j < j1) {
+                        const double upd = G.sorted_upd[j];
+                        t = G.sorted_idx[j];
+                        if (upd != now_s && !(taken && taken[t])) {
+                            const double dx = G.sorted_ref[3 * (int64_t)j] - px, dy = G.sorted_ref[3 * (int64_t)j + 1] - py,
+                                         dz = G.sorted_ref[3 * (int64_t)j + 2] - pz;
+                            dist = sqrt(dot3(dx, dy, dz, dx, dy, dz));
+                            const double age = now_s - upd;
+                            double lo = sp * (age - slack_s), hi = sp * (age + slack_s);
+                            lo = (lo > 0.0) ? lo : 0.0; hi = (hi > 0.0) ? hi : 0.0;
+                            in = lo <= dist && dist <= hi;
                         }
-                        c.dist[pos] = dist; c.idx[pos] = t;
-                        if (!full) c.n += 1;
                     }
+                    const unsigned long long ib = __ballot(in);
+                    if (!ib) continue;
+                    const int cnt = (int)__popcll(ib);
+                    total += cnt;
+                    if (nbuf + cnt > kCandBuf) { wave_select_nearest(bd, bi, nbuf); nbuf = nbuf < kCcpK ? nbuf : kCcpK; }
+                    if (in) {
+                        const int pos = nbuf + (int)__popcll(ib & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                        bd[pos] = dist; bi[pos] = t;
+                    }
+                    nbuf += cnt;
                 }
             }
         }
     }
-    out[d] = c;
+    wave_select_nearest(bd, bi, nbuf);
+    const int kept = nbuf < kCcpK ? nbuf : kCcpK;
+    CcpCand *o = out + d;
+    if (lane < kCcpK) { o->dist[lane] = lane < kept ? bd[lane] : __builtin_inf(); o->idx[lane] = lane < kept ? bi[lane] : -1; }
+    if (lane == 0) { o->n = kept; o->total = total; }
 }
 
 // One round of the order-dependent part.  Phase 0: every unresolved detection names the first candidate of its list
@@ -3442,35 +3500,94 @@ __global__ __launch_bounds__(1024) void k_ccp_tail(const CcpStepArgs A, uint8_t 
 {
     __shared__ double s_dist[16];
     __shared__ int s_trk[16];
-    __shared__ int s_pick;
+    // The detections the rounds have left (a tenth of them at configs[1] scale with a salvo in the air), in order.  Stepping through
+    // ALL detections and skipping the settled ones by their state byte -- a dependent load each -- was 1.8 ms of a C2-battery
+    // tick's 2.7, so the open ones are squeezed into a list first, kTailChunk detections at a time; and their kept lists with
+    // those tracks' `taken` bytes are fetched kTailBatch detections TOGETHER (two round trips a batch instead of two a detection),
+    // after which the first wave settles the batch out of LDS, one detection after the other -- the tracks that have gone (picked, or
+    // killed) since the batch was fetched are one per lane, a compare and a vote to look through.
+    // A detection's kept list is the nearest in-gate tracks that were free when the list was made, nearest first (the order the
+    // sequential scan's strict < produces); tracks are only ever taken, so the first entry that is still free IS the scan's
+    // answer, and a complete list with no free entry means "no track".  Only a truncated list whose every entry has been taken
+    // since -- the middle of a salvo that flies in a cluster -- sends the detection through the scan of all tracks below (a salvo
+    // of a thousand missiles two ticks off the rails made this workgroup scan 10^5 tracks a thousand times: 25 ms a tick); the
+    // batch starts afresh behind it.
+    constexpr int kTailChunk = 8192, kTailBatch = 64;
+    __shared__ int s_list[kTailChunk];
+    __shared__ int s_cnt[16];
+    __shared__ int s_n;
+    __shared__ int s_bidx[kTailBatch * kCcpK];
+    __shared__ uint8_t s_btaken[kTailBatch * kCcpK];
+    __shared__ int s_bkill[kTailBatch];
+    __shared__ uint8_t s_bfull[kTailBatch];
+    static_assert(kCcpK <= 64 && (kTailBatch * kCcpK) % 64 == 0, "a lane per kept candidate; the strike-out goes by 64 entries");
     if (counters[3] != 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = A.sizes[0], T = A.sizes[1];
-    for (int d = 0; d < D; ++d) {
-        if (state[d] == 1) continue;
-        // The detection's kept list first: the nearest in-gate tracks that were free when the list was made, nearest first (the
-        // order the sequential scan's strict < produces).  Tracks are only ever taken, so the first entry that is still free IS
-        // the scan's answer; a complete list with no free entry means "no track".  Only a truncated list whose every entry has
-        // been taken since -- the middle of a salvo that flies in a cluster -- sends the detection through the scan of all tracks
-        // (a salvo of a thousand missiles two ticks off the rails made this workgroup scan 10^5 tracks a thousand times: 25 ms a tick).
-        if (wave == 0) {
-            const int n = cand[d].n, total = cand[d].total;
-            const bool free_k = lane < n && lane < kCcpK && taken[cand[d].idx[lane < kCcpK ? lane : 0]] == 0;
-            const unsigned long long b = __ballot(free_k);
-            if (lane == 0) s_pick = b ? cand[d].idx[__builtin_ctzll(b)] : (total <= n ? -1 : -2);
+  for (int base = 0; base < D; base += kTailChunk) {
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int sub = 0; sub < kTailChunk && base + sub < D; sub += 1024) {
+        const int dd = base + sub + tid;
+        const bool open = dd < D && state[dd] != 1;
+        const unsigned long long ob = __ballot(open);
+        if (lane == 0) s_cnt[wave] = (int)__popcll(ob);
+        __syncthreads();
+        int off = s_n, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) off += s_cnt[w]; tot += s_cnt[w]; }
+        if (open) s_list[off + (int)__popcll(ob & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = dd;
+        __syncthreads();
+        if (tid == 0) s_n += tot;
+        __syncthreads();
+    }
+    const int n_open = s_n;
+    for (int q0 = 0; q0 < n_open;) {
+        const int nbat = (n_open - q0 < kTailBatch) ? n_open - q0 : kTailBatch;
+        for (int e = tid; e < nbat * kCcpK; e += 1024) {
+            const int dj = s_list[q0 + e / kCcpK], k = e % kCcpK;
+            const int ix = (k < cand[dj].n) ? cand[dj].idx[k] : -1;
+            s_bidx[e] = ix;
+            s_btaken[e] = (ix >= 0) ? taken[ix] : (uint8_t)1;
+        }
+        if (tid < nbat) {
+            const int dj = s_list[q0 + tid];
+            s_bfull[tid] = (cand[dj].total <= cand[dj].n) ? 1 : 0;       // the list is complete
+            s_bkill[tid] = A.kill[dj];
         }
         __syncthreads();
-        const int pick = s_pick;
-        if (pick != -2) {                            // (the same for every thread)
-            if (tid == 0) {
-                const int32_t kx = A.kill[d];
-                if (pick >= 0) { match[d] = pick; taken[pick] = 1; }
-                else { match[d] = -1; if (kx >= 0) taken[kx] = 1; }
-                state[d] = 1;
+        if (wave == 0) {
+            int done = 0, gone_n = 0;
+            int mine = -1;                                                  // lane p: the p-th track that has gone in this batch
+            for (; done < nbat; ++done) {
+                const int ix = lane < kCcpK ? s_bidx[done * kCcpK + lane] : -1;
+                const bool tk = lane < kCcpK ? s_btaken[done * kCcpK + lane] != 0 : true;
+                unsigned long long fb = __ballot(ix >= 0 && !tk);           // free when the batch was fetched ...
+                int pick = -1;
+                while (fb) {                                                // ... and not gone since (at most kCcpK turns)
+                    const int cand_k = (int)__builtin_ctzll(fb);
+                    const int tr = __builtin_amdgcn_readlane(ix, cand_k);
+                    if (!__ballot(mine == tr)) { pick = tr; break; }
+                    fb &= fb - 1ull;
+                }
+                if (pick < 0 && !s_bfull[done]) break;                      // (wave-uniform: the scan of all tracks)
+                const int gone = pick >= 0 ? pick : s_bkill[done];
+                if (lane == 0) {
+                    const int dj = s_list[q0 + done];
+                    match[dj] = pick;
+                    if (gone >= 0) taken[gone] = 1;
+                    state[dj] = 1;
+                }
+                if (gone >= 0) { if (lane == gone_n) mine = gone; ++gone_n; }
             }
-            __syncthreads();
-            continue;
+            if (lane == 0) s_n = done;                                      // (s_n: free since n_open was read)
         }
+        __syncthreads();
+        const int done = s_n;
+        q0 += done;
+        if (done == nbat) continue;
+        // detection s_list[q0]: its kept list is a prefix and all of it has been taken
+        const int d = s_list[q0];
+        q0 += 1;
         const double px = A.det_pos[3 * d], py = A.det_pos[3 * d + 1], pz = A.det_pos[3 * d + 2], sp = A.det_speed[d];
         double best = __builtin_inf();
         int who = 0x7FFFFFFF;
@@ -3504,6 +3621,8 @@ __global__ __launch_bounds__(1024) void k_ccp_tail(const CcpStepArgs A, uint8_t 
         }
         __syncthreads();                             // (the track is gone before anybody scans for the next detection)
     }
+    __syncthreads();                                 // (the list is everybody's until here)
+  }
     if (tid == 0) counters[3] = 1;
 }
 
@@ -4843,6 +4962,7 @@ ZRK_API int zrk_ccp_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const dou
         hipMemsetAsync(out->status, 0, sizeof(int32_t), s) != hipSuccess)
         return fail(ctx, ZRK_E_HIP, "zrk_ccp_step: memset");
     const int gd = nblocks(dmax, 256), gt = nblocks(std::max<int64_t>(dmax, T), 256);
+    const int gw = nblocks(dmax, 4);                 // (k_ccp_candidates_grid: a wave per detection)
     hipLaunchKernelGGL(k_ccp_gather, dim3(gt), dim3(256), 0, s, A);
     if (use_grid) {
         if (hipMemsetAsync(G.count, 0, 4 * ((size_t)G.cells_cap + 1), s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "zrk_ccp_step: memset");
@@ -4854,7 +4974,7 @@ ZRK_API int zrk_ccp_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const dou
         hipLaunchKernelGGL(k_ccp_grid_scan, dim3(1), dim3(1024), 0, s, G, 1);
         hipLaunchKernelGGL(k_ccp_grid_scan, dim3(sb), dim3(1024), 0, s, G, 2);
         hipLaunchKernelGGL(k_ccp_grid_scatter, dim3(nblocks(T, 256)), dim3(256), 0, s, G);
-        hipLaunchKernelGGL(k_ccp_candidates_grid, dim3(gd), dim3(256), 0, s, G, (const uint8_t *)nullptr, (const uint8_t *)nullptr, cand,
+        hipLaunchKernelGGL(k_ccp_candidates_grid, dim3(gw), dim3(256), 0, s, G, (const uint8_t *)nullptr, (const uint8_t *)nullptr, cand,
                            (const int32_t *)nullptr);
     } else
     hipLaunchKernelGGL(k_ccp_candidates, dim3(gd), dim3(256), 0, s, A.det_pos, A.det_speed, dmax, A.trk_ref, A.trk_upd, T, now_s, slack_s,
@@ -4868,7 +4988,7 @@ ZRK_API int zrk_ccp_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const dou
         hipLaunchKernelGGL(k_ccp_round_end, dim3(gd), dim3(256), 0, s, dmax, A.sizes, only, state, counters);
         hipLaunchKernelGGL(k_ccp_round_flags, dim3(1), dim3(1), 0, s, counters);
         if (use_grid)
-            hipLaunchKernelGGL(k_ccp_candidates_grid, dim3(gd), dim3(256), 0, s, G, (const uint8_t *)taken, (const uint8_t *)only, cand,
+            hipLaunchKernelGGL(k_ccp_candidates_grid, dim3(gw), dim3(256), 0, s, G, (const uint8_t *)taken, (const uint8_t *)only, cand,
                                (const int32_t *)(counters + 4));
         else
         hipLaunchKernelGGL(k_ccp_candidates, dim3(gd), dim3(256), 0, s, A.det_pos, A.det_speed, dmax, A.trk_ref, A.trk_upd, T, now_s, slack_s,
