@@ -295,7 +295,7 @@ def measure_battery(args, device):
     nm = sum(len(l["missiles"]) for l in cfg["missile_launchers"])
     eng = HotPathEngine(device=device, dt_ms=10, seed=S.SEEDS[args.workload.replace("-battery", "")], noise="philox")
     eng.load(ids, sp, vel, 0.0, cfg["radars"], missile_capacity=nm).enable_lists()
-    bat = DeviceBattery(eng, cfg["missile_launchers"], rounds=int(os.environ.get("ZRK_BATTERY_ROUNDS", "4")))
+    bat = DeviceBattery(eng, cfg["missile_launchers"], rounds=int(os.environ.get("ZRK_BATTERY_ROUNDS", "2")))
     steps, warmup = args.steps, args.warmup
     bat.run(warmup)
     torch.cuda.synchronize(device)

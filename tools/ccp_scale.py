@@ -25,7 +25,7 @@ def main():
     lpos = g.uniform(-2e4, 2e4, (8, 3)) * [1, 1, 0]
     caps = np.full(8, 5000, np.int32)
     tab = Table(n)
-    posts = {m: DeviceCommandPost(_ctx(), "cuda:0", n, n, lpos, caps, dmax=n, rounds=8) for m in ("1", "0")}
+    posts = {m: DeviceCommandPost(_ctx(), "cuda:0", n, n, lpos, caps, dmax=n, rounds=int(os.environ.get("ZRK_CCP_ROUNDS", "8"))) for m in ("1", "0")}
     dt, slack = 0.5, 2.0
     pos = p0.copy()
     for k in range(4):

@@ -27,7 +27,7 @@ class DeviceBattery:
     order (main.py:106-110; default: all).  `engine`: a HotPathEngine that has been loaded with the targets and has its
     per-radar lists enabled; the battery appends the magazine's rows to its table."""
 
-    def __init__(self, engine, launchers, ccp_launcher_ids=None, slack_steps=100, rounds=4, log_capacity=None):
+    def __init__(self, engine, launchers, ccp_launcher_ids=None, slack_steps=100, rounds=2, log_capacity=None):
         self.eng = eng = engine
         st = self.st = eng.store
         assert eng.det_idx is not None, "enable_lists() first: the command post reads the per-radar lists"
