@@ -478,7 +478,8 @@ typedef struct {
  * workgroups a pair's compactions are one launch), ZRK_COMPACT_GROUP=0|4|8|16|32 (two-level sums of the workgroup records),
  * ZRK_COMPACT_ITEMS, ZRK_COMPACT_FUSED_MAX_BLOCKS, ZRK_SIDE_CUS=n[,first] / ZRK_SIDE_PRIORITY=high|low (the side stream's
  * place on the device), ZRK_TAIL_COMPUTE=0 / ZRK_TAIL_EVENT=1 (the call's last compaction on the side stream, released by a launch / an event), ZRK_CCP_GRID=0|1 (zrk_ccp_step's
- * candidate pass: all pairs / spatial index), ZRK_MARKS_IN_TAIL=0 (a call's removal marks are carried out by a launch of
+ * candidate pass: all pairs / spatial index), ZRK_SIDE_SETTLE=0 (the side stream's thread does not finish that stream behind a
+ * call's last item), ZRK_MARKS_IN_TAIL=0 (a call's removal marks are carried out by a launch of
  * their own behind the last sweep instead of by extra workgroups of the call's last pair compaction), ZRK_TRACE=1 (host time
  * stamps of a call on stderr as it returns; =2: as the next call starts, outside what a caller times).
  * Every host-side wait is bounded by ZRK_HOST_WAIT_MS (default 30000): if the
