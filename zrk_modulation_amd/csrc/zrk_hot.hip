@@ -3315,6 +3315,24 @@ struct CcpStepArgs {
 };
 
 // sizes, per-detection attributes, per-track references (targets then missiles, the order link_object scans them in)
+struct CcpClearArgs {
+    uint32_t *zero[4];
+    int64_t zero_words[4];
+    uint32_t *ones;                 // 0x7F7F7F7F: "nobody interested"
+    int64_t ones_words;
+    int32_t *status;
+};
+
+__global__ void k_ccp_clear(const CcpClearArgs Z)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (Z.zero[k] && i < Z.zero_words[k]) Z.zero[k][i] = 0u;
+    if (i < Z.ones_words) Z.ones[i] = 0x7F7F7F7Fu;
+    if (i == 0) *Z.status = 0;
+}
+
 __global__ void k_ccp_gather(const CcpStepArgs A)
 {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -4957,15 +4975,23 @@ ZRK_API int zrk_ccp_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const dou
     G.sorted_idx = (int32_t *)p;             p += align256(4 * T);
     G.sorted_ref = (double *)p;              p += align256(24 * T);
     G.sorted_upd = (double *)p;              p += align256(8 * T);
-    if (hipMemsetAsync(taken, 0, (size_t)align256(T), s) != hipSuccess || hipMemsetAsync(state, 0, (size_t)align256(dmax), s) != hipSuccess ||
-        hipMemsetAsync(interest, 0x7F, (size_t)align256(4 * T), s) != hipSuccess || hipMemsetAsync(counters, 0, 256, s) != hipSuccess ||
-        hipMemsetAsync(out->status, 0, sizeof(int32_t), s) != hipSuccess)
-        return fail(ctx, ZRK_E_HIP, "zrk_ccp_step: memset");
+    // (the step's working words cleared by ONE launch: six memsets were six dependent launches of a closed-loop tick's seventy)
+    {
+        CcpClearArgs Z;
+        Z.zero[0] = (uint32_t *)taken;    Z.zero_words[0] = align256(T) / 4;
+        Z.zero[1] = (uint32_t *)state;    Z.zero_words[1] = align256(dmax) / 4;
+        Z.zero[2] = (uint32_t *)counters; Z.zero_words[2] = 64;
+        Z.zero[3] = use_grid ? (uint32_t *)G.count : nullptr; Z.zero_words[3] = use_grid ? (int64_t)G.cells_cap + 1 : 0;
+        Z.ones = (uint32_t *)interest;    Z.ones_words = align256(4 * T) / 4;
+        Z.status = out->status;
+        int64_t most = Z.ones_words;
+        for (int k = 0; k < 4; ++k) most = std::max(most, Z.zero_words[k]);
+        hipLaunchKernelGGL(k_ccp_clear, dim3(nblocks(most, 256)), dim3(256), 0, s, Z);
+    }
     const int gd = nblocks(dmax, 256), gt = nblocks(std::max<int64_t>(dmax, T), 256);
     const int gw = nblocks(dmax, 4);                 // (k_ccp_candidates_grid: a wave per detection)
     hipLaunchKernelGGL(k_ccp_gather, dim3(gt), dim3(256), 0, s, A);
     if (use_grid) {
-        if (hipMemsetAsync(G.count, 0, 4 * ((size_t)G.cells_cap + 1), s) != hipSuccess) return fail(ctx, ZRK_E_HIP, "zrk_ccp_step: memset");
         const int sb = (G.cells_cap + 1 + 4095) / 4096;
         hipLaunchKernelGGL(k_ccp_grid_partials, dim3(G.blocks), dim3(256), 0, s, G);
         hipLaunchKernelGGL(k_ccp_grid_params, dim3(1), dim3(256), 0, s, G);
