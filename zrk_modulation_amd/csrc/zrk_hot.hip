@@ -3897,10 +3897,40 @@ __global__ __launch_bounds__(1024) void k_battery_sequence(const int32_t *__rest
         const int cnt = det_cnt[r] < det_stride ? det_cnt[r] : (int)det_stride;
         const int32_t *list = det_idx + (int64_t)r * det_stride;
         const int run0 = run;
-        run += ordered_ranks_1024(cnt, s_w, &s_carry, [&](int k) { const uint32_t m = vis[list[k] - base_index]; return (m & (0u - m)) == (1u << r); },
-                                  [&](int k, int rank) {
-            if (rank >= 0 && run0 + rank < seq_cap) { const int32_t li = list[k] - base_index; seq[run0 + rank] = row_of_list ? row_of_list[li] : li; }
-        });
+        // (four consecutive entries per thread, 4096 a turn: the entries' loads, then their masks', in flight together)
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        if (tid == 0) s_carry = 0;
+        __syncthreads();
+        for (int base = 0; base < cnt; base += 4096) {
+            const int q0 = base + tid * 4;
+            int32_t li[4];
+            uint32_t m[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) li[j] = list[q0 + j < cnt ? q0 + j : 0] - base_index;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = vis[li[j]];
+            bool f[4];
+            const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            int mine = 0, tot_w = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f[j] = q0 + j < cnt && (m[j] & (0u - m[j])) == (1u << r);          // first mentioned by radar r: its lowest set bit
+                const unsigned long long bb = __ballot(f[j]);
+                mine += (int)__popcll(bb & below); tot_w += (int)__popcll(bb);
+            }
+            if (lane == 0) s_w[wave] = tot_w;
+            __syncthreads();
+            int off = run0 + s_carry + mine, tot = 0;
+            for (int w = 0; w < 16; ++w) { if (w < wave) off += s_w[w]; tot += s_w[w]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (f[j]) { if (off < seq_cap) seq[off] = row_of_list ? row_of_list[li[j]] : li[j]; ++off; }
+            __syncthreads();
+            if (tid == 0) s_carry += tot;
+            __syncthreads();
+        }
+        run += s_carry;
+        __syncthreads();                                  // (the next radar clears the word)
     }
     if (threadIdx.x == 0) *seq_count = run < seq_cap ? run : (int32_t)seq_cap;
 }
