@@ -429,6 +429,12 @@ def main():
     # should not find cores held between its calls); here the warm-up call, the spin-up and the timed call are tens of
     # milliseconds apart, and a helper woken from its sleep at the timed call's entry can cost that call milliseconds
     os.environ.setdefault("ZRK_HELPER_YIELD_MS", "250")
+    # ... and with ONE rank on the node they do not even give up their core in that time (a thread that yields on a host busy
+    # with other tenants' work may not be back for a scheduler's slice: one of forty runs of the driver's command waited 1.1 ms
+    # for the side stream's thread, profiles/r05_driver_regime_distribution.txt).  With several ranks the node's cores are the
+    # ranks' to share: the library's default (1 ms) stands
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1:
+        os.environ.setdefault("ZRK_HELPER_IDLE_MS", "300")
 
     import numpy as np
     import torch

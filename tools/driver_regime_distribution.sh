@@ -1,9 +1,9 @@
 #!/bin/bash
 # The driver's command many times on one box:  gpurun -- bash tools/driver_regime_distribution.sh [runs]
-# -> gpurun_out/r04_dist/summary.txt (copied to profiles/r04_driver_regime_distribution.txt): per run the tick, the time the one
+# -> gpurun_out/${ZRK_DIST_TAG:-r05}_dist/summary.txt (copied to profiles/rNN_driver_regime_distribution.txt): per run the tick, the time the one
 # call took to return, the synchronisation behind it, the span of its ten sweeps and the gaps between them (by the launches' own
 # stamps), and any host-side wait of the library longer than a millisecond (ZRK_STALL_US).
-R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/r04_dist; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/${ZRK_DIST_TAG:-r05}_dist; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
 runs=${1:-40}
 export ZRK_STALL_US=1000
 for i in $(seq 1 $runs); do
