@@ -3379,17 +3379,22 @@ __global__ void k_ccp_round_begin(int32_t *counters)
     counters[0] = 0; counters[1] = 0; counters[2] = 0x7FFFFFFF; counters[4] = 0;
 }
 
-// the round is over: everybody resolved -> done; some lists ran out although more was in gate -> the re-scan below runs
-__global__ void k_ccp_round_end(int64_t dmax, const int32_t *__restrict__ sizes, uint8_t *only, uint8_t *state, int32_t *counters)
+// the round is over: everybody resolved -> done; some lists ran out although more was in gate -> the re-scan below runs.
+// The unresolved detections' interest words cleared for the next round (k_ccp_reset_interest), and who is to be looked at again
+// marked, in one launch: a detection's interest words are its own lists', its state and `only` bytes its own.
+__global__ void k_ccp_round_close(int64_t dmax, const CcpCand *__restrict__ cand, uint8_t *state, int32_t *interest,
+                                  const int32_t *__restrict__ kill, const int32_t *__restrict__ sizes, uint8_t *only, int32_t *counters)
 {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (counters[3] != 0) return;
-    const bool rescan = counters[1] > 0;
-    if (d < dmax && d < sizes[0]) {
-        const bool again = rescan && state[d] == 2;
-        only[d] = again ? 1 : 0;
-        if (again) state[d] = 0;
+    if (counters[3] != 0 || d >= dmax || d >= sizes[0]) return;
+    if (state[d] != 1) {
+        const CcpCand &c = cand[d];
+        for (int k = 0; k < c.n; ++k) interest[c.idx[k]] = 0x7FFFFFFF;
+        if (kill && kill[d] >= 0) interest[kill[d]] = 0x7FFFFFFF;
     }
+    const bool again = counters[1] > 0 && state[d] == 2;
+    only[d] = again ? 1 : 0;
+    if (again) state[d] = 0;
 }
 
 __global__ void k_ccp_round_flags(int32_t *counters)
@@ -5040,8 +5045,7 @@ ZRK_API int zrk_ccp_step(zrk_ctx *ctx, const zrk_entities *e, int cur, const dou
         for (int phase = 0; phase < 3; ++phase)
             hipLaunchKernelGGL(k_ccp_round, dim3(gd), dim3(256), 0, s, phase, dmax, cand, taken, interest, match, state, counters,
                                (const int32_t *)A.kill, (const int32_t *)A.sizes);
-        hipLaunchKernelGGL(k_ccp_reset_interest, dim3(gd), dim3(256), 0, s, dmax, cand, state, interest, A.kill, A.sizes, counters);
-        hipLaunchKernelGGL(k_ccp_round_end, dim3(gd), dim3(256), 0, s, dmax, A.sizes, only, state, counters);
+        hipLaunchKernelGGL(k_ccp_round_close, dim3(gd), dim3(256), 0, s, dmax, cand, state, interest, A.kill, A.sizes, only, counters);
         hipLaunchKernelGGL(k_ccp_round_flags, dim3(1), dim3(1), 0, s, counters);
         if (use_grid)
             hipLaunchKernelGGL(k_ccp_candidates_grid, dim3(gw), dim3(256), 0, s, G, (const uint8_t *)taken, (const uint8_t *)only, cand,
