@@ -6125,8 +6125,10 @@ int run_ticks(zrk_ctx *ctx, const zrk_entities *e, const zrk_missiles *mis, int6
         if (sd->pend_rows < e->capacity) {
             if (sd->pend) (void)hipFree(sd->pend);
             sd->pend = nullptr; sd->pend_rows = 0;
-            if (hipMalloc((void **)&sd->pend, (size_t)e->capacity) != hipSuccess ||
-                hipMemsetAsync(sd->pend, 0, (size_t)e->capacity, s) != hipSuccess)
+            // (a multiple of sixteen bytes past the capacity: MarksArgs reads the marks sixteen at a time)
+            const size_t pend_bytes = ((size_t)e->capacity + 31) & ~(size_t)15;
+            if (hipMalloc((void **)&sd->pend, pend_bytes) != hipSuccess ||
+                hipMemsetAsync(sd->pend, 0, pend_bytes, s) != hipSuccess)
                 return fail(ctx, ZRK_E_HIP, "zrk_run_ticks: the removal marks could not be allocated");
             sd->pend_rows = e->capacity;
         }
